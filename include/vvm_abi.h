@@ -1,0 +1,272 @@
+/*
+ * vvm_abi.h -- C ABI of the MI355X VectorVM executor (libvvm_hip.so).
+ *
+ * Drop-in boundary for the reference entry points
+ *   VectorVM::Runtime::AllocVectorVMState / FreeVectorVMState / ExecVectorVMState
+ *   (Runtime/VectorVM/Public/VectorVMRuntime.h:30-33).
+ * Struct fields keep the order and meaning of FVectorVMExecContext
+ * (VectorVMRuntime.h:10-28) and FDataSetMeta (VectorVM.h:246-273); every
+ * TArrayView<T> is flattened to {T* data; int32 num;} (ArrayView.h:826-827) and
+ * every TArray<int32>* to a pointer to {int32* data; int32 num; int32 max;}.
+ *
+ * Memory spaces for libvvm_hip.so:
+ *   - everything the structs themselves hold (pointer arrays, constant tables,
+ *     counters) is HOST memory;
+ *   - every register stream (InputRegisters.data[i], OutputRegisters.data[i])
+ *     and every ID table payload (vvm_id_table.data) is DEVICE memory.
+ * The CPU oracle (oracle/) uses the same structs with host memory throughout.
+ */
+#ifndef VVM_ABI_H
+#define VVM_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(_WIN32)
+#define VVM_API
+#else
+#define VVM_API __attribute__((visibility("default")))
+#endif
+
+/* ---- status codes (the reference returns void and asserts; see RT.cpp:2184-2187, 2264-2267) ---- */
+enum {
+	VVM_OK                  = 0,
+	VVM_E_INVALID_ARG       = 1,
+	VVM_E_EXTFN_MISMATCH    = 2,  /* ExtFunctionTable.num != NumExtFns: the reference returns silently (RT.cpp:2184) */
+	VVM_E_NO_BYTECODE       = 3,  /* RT.cpp:2264 */
+	VVM_E_UNSUPPORTED_OP    = 4,
+	VVM_E_BAD_BLOB          = 5,
+	VVM_E_HIP               = 6,
+	VVM_E_RCCL              = 7,
+	VVM_E_TOO_LARGE         = 8
+};
+
+/* ---- opcodes: numeric values of EVectorVMOp (VectorVM.h:50-240) ---- */
+enum {
+	VVM_OP_done = 0, VVM_OP_add = 1, VVM_OP_sub = 2, VVM_OP_mul = 3, VVM_OP_div = 4, VVM_OP_mad = 5, VVM_OP_lerp = 6,
+	VVM_OP_rcp = 7, VVM_OP_rsq = 8, VVM_OP_sqrt = 9, VVM_OP_neg = 10, VVM_OP_abs = 11, VVM_OP_exp = 12, VVM_OP_exp2 = 13,
+	VVM_OP_log = 14, VVM_OP_log2 = 15, VVM_OP_sin = 16, VVM_OP_cos = 17, VVM_OP_tan = 18, VVM_OP_asin = 19, VVM_OP_acos = 20,
+	VVM_OP_atan = 21, VVM_OP_atan2 = 22, VVM_OP_ceil = 23, VVM_OP_floor = 24, VVM_OP_fmod = 25, VVM_OP_frac = 26,
+	VVM_OP_trunc = 27, VVM_OP_clamp = 28, VVM_OP_min = 29, VVM_OP_max = 30, VVM_OP_pow = 31, VVM_OP_round = 32,
+	VVM_OP_sign = 33, VVM_OP_step = 34, VVM_OP_random = 35, VVM_OP_noise = 36, VVM_OP_cmplt = 37, VVM_OP_cmple = 38,
+	VVM_OP_cmpgt = 39, VVM_OP_cmpge = 40, VVM_OP_cmpeq = 41, VVM_OP_cmpneq = 42, VVM_OP_select = 43, VVM_OP_addi = 44,
+	VVM_OP_subi = 45, VVM_OP_muli = 46, VVM_OP_divi = 47, VVM_OP_clampi = 48, VVM_OP_mini = 49, VVM_OP_maxi = 50,
+	VVM_OP_absi = 51, VVM_OP_negi = 52, VVM_OP_signi = 53, VVM_OP_randomi = 54, VVM_OP_cmplti = 55, VVM_OP_cmplei = 56,
+	VVM_OP_cmpgti = 57, VVM_OP_cmpgei = 58, VVM_OP_cmpeqi = 59, VVM_OP_cmpneqi = 60, VVM_OP_bit_and = 61, VVM_OP_bit_or = 62,
+	VVM_OP_bit_xor = 63, VVM_OP_bit_not = 64, VVM_OP_bit_lshift = 65, VVM_OP_bit_rshift = 66, VVM_OP_logic_and = 67,
+	VVM_OP_logic_or = 68, VVM_OP_logic_xor = 69, VVM_OP_logic_not = 70, VVM_OP_f2i = 71, VVM_OP_i2f = 72, VVM_OP_f2b = 73,
+	VVM_OP_b2f = 74, VVM_OP_i2b = 75, VVM_OP_b2i = 76, VVM_OP_inputdata_float = 77, VVM_OP_inputdata_int32 = 78,
+	VVM_OP_inputdata_half = 79, VVM_OP_inputdata_noadvance_float = 80, VVM_OP_inputdata_noadvance_int32 = 81,
+	VVM_OP_inputdata_noadvance_half = 82, VVM_OP_outputdata_float = 83, VVM_OP_outputdata_int32 = 84,
+	VVM_OP_outputdata_half = 85, VVM_OP_acquireindex = 86, VVM_OP_external_func_call = 87, VVM_OP_exec_index = 88,
+	VVM_OP_noise2D = 89, VVM_OP_noise3D = 90, VVM_OP_enter_stat_scope = 91, VVM_OP_exit_stat_scope = 92,
+	VVM_OP_update_id = 93, VVM_OP_acquire_id = 94, VVM_OP_half_to_float = 95, VVM_OP_fasi = 96, VVM_OP_iasf = 97,
+	/* merged ops */
+	VVM_OP_exec_indexf = 98, VVM_OP_exec_index_addi = 99, VVM_OP_cmplt_select = 100, VVM_OP_cmple_select = 101,
+	VVM_OP_cmpeq_select = 102, VVM_OP_cmplti_select = 103, VVM_OP_cmplei_select = 104, VVM_OP_cmpeqi_select = 105,
+	VVM_OP_cmplt_logic_and = 106, VVM_OP_cmple_logic_and = 107, VVM_OP_cmpgt_logic_and = 108, VVM_OP_cmpge_logic_and = 109,
+	VVM_OP_cmpeq_logic_and = 110, VVM_OP_cmpne_logic_and = 111, VVM_OP_cmplti_logic_and = 112, VVM_OP_cmplei_logic_and = 113,
+	VVM_OP_cmpgti_logic_and = 114, VVM_OP_cmpgei_logic_and = 115, VVM_OP_cmpeqi_logic_and = 116, VVM_OP_cmpnei_logic_and = 117,
+	VVM_OP_cmplt_logic_or = 118, VVM_OP_cmple_logic_or = 119, VVM_OP_cmpgt_logic_or = 120, VVM_OP_cmpge_logic_or = 121,
+	VVM_OP_cmpeq_logic_or = 122, VVM_OP_cmpne_logic_or = 123, VVM_OP_cmplti_logic_or = 124, VVM_OP_cmplei_logic_or = 125,
+	VVM_OP_cmpgti_logic_or = 126, VVM_OP_cmpgei_logic_or = 127, VVM_OP_cmpeqi_logic_or = 128, VVM_OP_cmpnei_logic_or = 129,
+	VVM_OP_mad_add = 130, VVM_OP_mad_sub0 = 131, VVM_OP_mad_sub1 = 132, VVM_OP_mad_mul = 133, VVM_OP_mad_sqrt = 134,
+	VVM_OP_mad_mad0 = 135, VVM_OP_mad_mad1 = 136, VVM_OP_mul_mad0 = 137, VVM_OP_mul_mad1 = 138, VVM_OP_mul_add = 139,
+	VVM_OP_mul_sub0 = 140, VVM_OP_mul_sub1 = 141, VVM_OP_mul_mul = 142, VVM_OP_mul_max = 143, VVM_OP_mul_2x = 144,
+	VVM_OP_add_mad1 = 145, VVM_OP_add_add = 146, VVM_OP_sub_cmplt1 = 147, VVM_OP_sub_neg = 148, VVM_OP_sub_mul = 149,
+	VVM_OP_div_mad0 = 150, VVM_OP_div_f2i = 151, VVM_OP_div_mul = 152, VVM_OP_muli_addi = 153, VVM_OP_addi_bit_rshift = 154,
+	VVM_OP_addi_muli = 155, VVM_OP_b2i_2x = 156, VVM_OP_i2f_div0 = 157, VVM_OP_i2f_div1 = 158, VVM_OP_i2f_mul = 159,
+	VVM_OP_i2f_mad0 = 160, VVM_OP_i2f_mad1 = 161, VVM_OP_f2i_select1 = 162, VVM_OP_f2i_maxi = 163, VVM_OP_f2i_addi = 164,
+	VVM_OP_fmod_add = 165, VVM_OP_bit_and_i2f = 166, VVM_OP_bit_rshift_bit_and = 167, VVM_OP_neg_cmplt = 168,
+	VVM_OP_bit_or_muli = 169, VVM_OP_bit_lshift_bit_or = 170, VVM_OP_random_add = 171, VVM_OP_random_2x = 172,
+	VVM_OP_max_f2i = 173, VVM_OP_select_mul = 174, VVM_OP_select_add = 175, VVM_OP_sin_cos = 176,
+	VVM_OP_outputdata_float_from_half = 177, VVM_OP_outputdata_half_from_half = 178,
+	VVM_NUM_OPCODES = 179
+};
+
+/* EVectorVMFlags (VectorVM.h:529-536) */
+enum {
+	VVM_FLAG_OPT_SAVE_INTERMEDIATE = 1 << 0,
+	VVM_FLAG_OPT_OMIT_STATS        = 1 << 1,
+	VVM_FLAG_LARGE_SCRIPT          = 1 << 2,
+	VVM_FLAG_HAS_RAND_INSTRUCTION  = 1 << 3,
+	VVM_FLAG_DATA_MAP_CACHE_SETUP  = 1 << 4
+};
+
+/* ---- frozen blob (VectorVMBridge.cpp:14-148): packed little-endian header, then 16-byte aligned sections ---- */
+#define VVM_BLOB_HEADER_PACKED_BYTES 54  /* what the archive writes, VectorVMBridge.cpp:81-101 */
+#define VVM_BLOB_FIRST_SECTION       64  /* Align(sizeof(FRuntimeContextData)=56, 16), VectorVMBridge.cpp:116 */
+#define VVM_BLOB_EXTFN_ENTRY_BYTES   16  /* sizeof(FVectorVMExtFunctionData) = {ptr, int32, int32}, VectorVM.h:360-365 */
+#define VVM_INVALID_REG              0xFFFFu
+
+/* ---- flattened containers ---- */
+typedef struct vvm_id_table {       /* TArray<int32>: GetData(), Num(), Max() */
+	int32_t* data;
+	int32_t  num;
+	int32_t  max;
+} vvm_id_table;
+
+typedef struct vvm_input_register_view {   /* TArrayView<uint8 const* RESTRICT const>, VectorVM.h:248 */
+	const uint8_t* const* data;
+	int32_t               num;
+} vvm_input_register_view;
+
+typedef struct vvm_output_register_view {  /* TArrayView<uint8* RESTRICT const>, VectorVM.h:249 */
+	uint8_t* const* data;
+	int32_t         num;
+} vvm_output_register_view;
+
+/* FDataSetMeta (VectorVM.h:246-273) */
+typedef struct vvm_dataset_meta {
+	vvm_input_register_view  InputRegisters;
+	vvm_output_register_view OutputRegisters;
+	uint32_t InputRegisterTypeOffsets[3];   /* first index of float / int32 / half streams */
+	uint32_t OutputRegisterTypeOffsets[3];
+	int32_t  DataSetAccessIndex;            /* out: survivors - 1 (RT.cpp:2305-2308) */
+	int32_t  InstanceOffset;                /* first instance processed; also base of the outputs */
+	vvm_id_table* IDTable;
+	vvm_id_table* FreeIDTable;
+	vvm_id_table* SpawnedIDsTable;
+	int32_t* NumFreeIDs;
+	int32_t* MaxUsedID;
+	int32_t* NumSpawnedIDs;
+	int32_t  IDAcquireTag;
+} vvm_dataset_meta;
+
+/* External functions.
+ * The reference binds a TDelegate per function (VectorVM.h:358). The GPU executor resolves a
+ * stated built-in set by id; the CPU oracle additionally accepts a host callback with the
+ * reference's register-walk convention (VectorVM.h:315-356, RT.cpp:1442-1489). */
+enum {
+	VVM_EXTFN_HOST_CALLBACK = 0,  /* oracle only */
+	VVM_EXTFN_PERLIN3       = 1,  /* 3 in (x,y,z) -> 1 out : FMath::PerlinNoise3D (UnrealMath.cpp:3658-3699) */
+	VVM_EXTFN_CURL_NOISE3   = 2   /* 3 in (x,y,z) -> 3 out : curl of three offset Perlin potentials */
+};
+
+typedef struct vvm_extfn_context {          /* FVectorVMExternalFunctionContext, VectorVM.h:315-334 */
+	uint32_t** RegisterData;
+	uint8_t*   RegInc;                      /* 0 = constant, 1 = advance one 32-bit element per instance */
+	int32_t    RegReadCount;
+	int32_t    NumRegisters;
+	int32_t    StartInstance;
+	int32_t    NumInstances;
+	int32_t    NumLoops;
+	int32_t    PerInstanceFnInstanceIdx;
+	void**     UserPtrTable;
+	int32_t    NumUserPtrs;
+	void*      RandStream;
+	int32_t**  RandCounters;
+	struct vvm_dataset_meta* DataSets;
+	int32_t    NumDataSets;
+} vvm_extfn_context;
+
+typedef struct vvm_ext_function {           /* stands in for FVMExternalFunction */
+	int32_t builtin_id;                     /* VVM_EXTFN_* */
+	void  (*host_fn)(vvm_extfn_context*);   /* VVM_EXTFN_HOST_CALLBACK only */
+	void*   user;
+} vvm_ext_function;
+
+typedef struct vvm_state vvm_state;         /* FVectorVMState (VectorVMTypes.h:23-75), opaque */
+
+/* FVectorVMExecContext (VectorVMRuntime.h:10-28) */
+typedef struct vvm_exec_context {
+	struct {
+		uint32_t NumBytesRequiredPerBatch;
+		uint32_t PerBatchRegisterDataBytesRequired;
+		uint32_t MaxChunksPerBatch;
+		uint32_t MaxInstancesPerChunk;
+	} Internal;
+	vvm_state* VVMState;
+	struct { vvm_dataset_meta* data; int32_t num; } DataSets;
+	struct { const vvm_ext_function* const* data; int32_t num; } ExtFunctionTable;
+	struct { void** data; int32_t num; } UserPtrTable;
+	int32_t NumInstances;
+	const uint8_t* const* ConstantTableData;
+	const int*            ConstantTableNumBytes;
+	int32_t               ConstantTableCount;
+} vvm_exec_context;
+
+/* Options with no counterpart in FVectorVMExecContext. All zero = reference behaviour. */
+typedef struct vvm_exec_options {
+	uint64_t RandSeed;          /* key of the counter-based generator used by random / randomi / random_add / random_2x */
+	int32_t  ExecIndexBase;     /* added to exec_index*: global index of this shard's first instance */
+	int32_t  RandInstanceBase;  /* added to the instance index that keys the generator (shard-invariant streams) */
+	void*    Stream;            /* hipStream_t to enqueue on; NULL = the state's own stream */
+	uint32_t Flags;             /* VVM_EXEC_* */
+} vvm_exec_options;
+
+enum {
+	VVM_EXEC_NO_VGPR_WIDE = 1u << 0   /* force the one-instance-per-lane kernel (debug / comparison) */
+};
+
+/* ---- entry points ---- */
+
+/* AllocVectorVMState(TConstArrayView<uint8>) -- RT.h:30, RT.cpp:2311-2417.
+ * Returns NULL on an empty or malformed blob (vvm_last_error() says why). Unlike the reference
+ * (VectorVMBridge.cpp:191-198) the state copies what it needs; the blob may be freed afterwards. */
+VVM_API vvm_state* vvm_alloc_state(const uint8_t* blob, size_t num_bytes);
+
+/* FreeVectorVMState -- RT.h:31, RT.cpp:2419-2425. NULL is allowed. */
+VVM_API void vvm_free_state(vvm_state* state);
+
+/* ExecVectorVMState -- RT.h:33, RT.cpp:2182-2309. Synchronous: on return every output stream holds
+ * its compacted survivors in [InstanceOffset, InstanceOffset+S) and DataSets[i].DataSetAccessIndex = S-1.
+ * One Exec at a time per state (the reference mutates its state the same way). */
+VVM_API int vvm_exec(vvm_exec_context* ctx);
+VVM_API int vvm_exec_ex(vvm_exec_context* ctx, const vvm_exec_options* opt);
+
+/* Enqueue-only form of vvm_exec_ex and its completion. Between the two calls the context, its dataset
+ * array and the state must stay alive and untouched. vvm_exec_finish blocks on the stream, then writes
+ * DataSetAccessIndex. Several vvm_exec_async calls on one state may be queued before one finish; the
+ * finish reports the counts of the LAST one. */
+VVM_API int vvm_exec_async(vvm_exec_context* ctx, const vvm_exec_options* opt);
+VVM_API int vvm_exec_finish(vvm_exec_context* ctx);
+
+/* Many independent Execs (one state each, e.g. one per emitter) in ONE kernel launch.
+ * Same result as calling vvm_exec_ex on each context in order. opts may be NULL or an array of n. */
+VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_options* opts);
+
+/* Device pointer (int32[MaxOutputDataSet]) to the survivor counts of the last Exec of this state;
+ * valid after the Exec's kernel has run on its stream. Lets a multi-GPU caller all-gather the
+ * counts without a host round trip. */
+VVM_API const int32_t* vvm_state_device_counts(const vvm_state* state);
+VVM_API int32_t        vvm_state_max_output_dataset(const vvm_state* state);
+
+/* Introspection of the linked program (tests, DESIGN numbers). */
+typedef struct vvm_program_info {
+	uint32_t NumTempRegisters, NumConstBuffers, NumInputBuffers, NumOutputBuffers;
+	uint32_t NumInstructions;       /* linked device instructions */
+	uint32_t NumVirtualRegisters;   /* per-lane registers the kernel needs (temps + output-aliased) */
+	uint32_t InstancesPerLane;      /* 4 = 128-bit stream access, 1 = narrow fallback */
+	uint32_t LdsSpillRegisters;     /* registers living in LDS */
+	uint32_t BytesInPerInstance, BytesOutPerInstance; /* algorithmic stream bytes */
+	uint32_t Flags;
+} vvm_program_info;
+VVM_API int vvm_state_info(const vvm_state* state, vvm_program_info* out);
+
+/* Thread-local text of the last failure in this library. */
+VVM_API const char* vvm_last_error(void);
+
+/* Device memory helpers for callers without a HIP runtime binding of their own. */
+VVM_API void* vvm_device_alloc(size_t num_bytes);
+VVM_API void  vvm_device_free(void* p);
+VVM_API int   vvm_device_upload(void* dst_device, const void* src_host, size_t num_bytes);
+VVM_API int   vvm_device_download(void* dst_host, const void* src_device, size_t num_bytes);
+VVM_API int   vvm_device_memset(void* dst_device, int byte_value, size_t num_bytes);
+VVM_API int   vvm_device_synchronize(void);
+VVM_API int   vvm_device_count(void);
+VVM_API int   vvm_set_device(int ordinal);
+
+/* Timing of the last kernel launch of this state, measured with HIP events on the stream the kernel
+ * was enqueued on. Enabled per state; costs two event records per Exec. */
+VVM_API int   vvm_state_enable_timing(vvm_state* state, int enable);
+VVM_API float vvm_state_last_kernel_ms(vvm_state* state);  /* blocks until the kernel has finished */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VVM_ABI_H */

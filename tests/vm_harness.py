@@ -1,0 +1,108 @@
+"""Shared test helpers: run one script through the CPU oracle or through libvvm_hip.so on the same inputs."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from renderer_amd import abi
+from renderer_amd.assembler import BuiltScript
+
+PAD = 16   # extra elements past N in every stream (the reference needs align4(N) + 16 bytes of slack)
+
+
+def _type_offsets(streams: Sequence[np.ndarray]) -> List[int]:
+    """Streams are ordered float32 first, then int32, then float16 (half)."""
+    nf = sum(1 for s in streams if s.dtype == np.float32)
+    ni = sum(1 for s in streams if s.dtype in (np.int32, np.uint32))
+    return [0, nf, nf + ni]
+
+
+def run_oracle(script: BuiltScript, const_tables: Sequence[bytes], inputs: Sequence[np.ndarray],
+               out_dtypes: Sequence, n: int, instance_offset: int = 0, ext_fns: Sequence = (),
+               seed: int = 0, exec_index_base: int = 0, rand_instance_base: int = 0, strict: bool = False,
+               page_kb: int = 64, out_fill: int = 0xCD) -> Tuple[List[np.ndarray], int, abi.CallFrame]:
+    from oracle_binding import load_oracle
+    be = load_oracle()
+    be.set_strict(strict)
+    be.set_page_kb(page_kb)
+    be.set_options(seed, exec_index_base, rand_instance_base)
+    total = instance_offset + n + PAD
+    ins = []
+    for a in inputs:
+        buf = np.zeros(total, dtype=a.dtype)
+        buf[instance_offset:instance_offset + n] = a[:n]
+        ins.append(buf)
+    outs = [np.frombuffer(bytes([out_fill]) * (total * np.dtype(dt).itemsize), dtype=dt).copy() for dt in out_dtypes]
+    ds = abi.DataSet([a.ctypes.data for a in ins], [a.ctypes.data for a in outs], instance_offset,
+                     _type_offsets(ins), _type_offsets(outs))
+    state = be.alloc_state(script.blob)
+    try:
+        frame = abi.CallFrame(state, [ds], n, const_tables, ext_fns)
+        rc = be.exec(frame)
+        if rc != 0:
+            raise abi.VVMError(rc, "vvm_oracle_exec")
+        surv = frame.survivors(0)
+    finally:
+        be.free_state(state)
+    return outs, surv, frame
+
+
+def run_hip(script: BuiltScript, const_tables: Sequence[bytes], inputs: Sequence[np.ndarray],
+            out_dtypes: Sequence, n: int, instance_offset: int = 0, ext_fns: Sequence = (),
+            seed: int = 0, exec_index_base: int = 0, rand_instance_base: int = 0, flags: int = 0,
+            out_fill: int = 0xCD, repeat: int = 1) -> Tuple[List[np.ndarray], int, abi.ProgramInfo]:
+    """Same contract as run_oracle, through the C ABI of libvvm_hip.so with streams in device memory."""
+    be = abi.load_hip_backend()
+    L = be.lib
+    total = instance_offset + n + PAD
+    dev_in, dev_out, host_out = [], [], []
+    try:
+        for a in inputs:
+            buf = np.zeros(total, dtype=a.dtype)
+            buf[instance_offset:instance_offset + n] = a[:n]
+            p = L.vvm_device_alloc(buf.nbytes)
+            assert p, be.error_text()
+            dev_in.append(p)
+            be._check(L.vvm_device_upload(p, buf.ctypes.data, buf.nbytes), "upload")
+        for dt in out_dtypes:
+            nbytes = total * np.dtype(dt).itemsize
+            p = L.vvm_device_alloc(nbytes)
+            assert p, be.error_text()
+            dev_out.append(p)
+            be._check(L.vvm_device_memset(p, out_fill, nbytes), "memset")
+        in_off = _type_offsets([np.empty(0, a.dtype) for a in inputs])
+        out_off = _type_offsets([np.empty(0, dt) for dt in out_dtypes])
+        ds = abi.DataSet(dev_in, dev_out, instance_offset, in_off, out_off)
+        state = be.alloc_state(script.blob)
+        try:
+            frame = abi.CallFrame(state, [ds], n, const_tables, ext_fns)
+            opt = abi.ExecOptions(seed, exec_index_base, rand_instance_base, None, flags)
+            for _ in range(repeat):
+                be.exec_ex(frame, opt)
+            surv = frame.survivors(0)
+            info = be.info(state)
+        finally:
+            be.free_state(state)
+        for p, dt in zip(dev_out, out_dtypes):
+            h = np.empty(total, dtype=dt)
+            be._check(L.vvm_device_download(h.ctypes.data, p, h.nbytes), "download")
+            host_out.append(h)
+    finally:
+        for p in dev_in + dev_out:
+            L.vvm_device_free(p)
+    return host_out, surv, info
+
+
+def ulp_diff(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """Distance in units in the last place between float32 arrays (NaN == NaN, +0 == -0 counts as 0)."""
+    a = np.asarray(a, dtype=np.float32)
+    b = np.asarray(b, dtype=np.float32)
+    ia = a.view(np.int32).astype(np.int64)
+    ib = b.view(np.int32).astype(np.int64)
+    ia = np.where(ia < 0, -(ia & 0x7FFFFFFF), ia)
+    ib = np.where(ib < 0, -(ib & 0x7FFFFFFF), ib)
+    d = np.abs(ia - ib)
+    both_nan = np.isnan(a) & np.isnan(b)
+    return np.where(both_nan, 0, d)
