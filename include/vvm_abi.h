@@ -248,6 +248,10 @@ typedef struct vvm_program_info {
 } vvm_program_info;
 VVM_API int vvm_state_info(const vvm_state* state, vvm_program_info* out);
 
+/* Thaw and link a blob without touching a device: the checks vvm_alloc_state makes, and the same vvm_program_info.
+ * Lets host-side tooling validate a script on a machine with no GPU. */
+VVM_API int vvm_inspect_blob(const uint8_t* blob, size_t num_bytes, vvm_program_info* out);
+
 /* Thread-local text of the last failure in this library. */
 VVM_API const char* vvm_last_error(void);
 
@@ -261,10 +265,16 @@ VVM_API int   vvm_device_synchronize(void);
 VVM_API int   vvm_device_count(void);
 VVM_API int   vvm_set_device(int ordinal);
 
-/* Timing of the last kernel launch of this state, measured with HIP events on the stream the kernel
- * was enqueued on. Enabled per state; costs two event records per Exec. */
-VVM_API int   vvm_state_enable_timing(vvm_state* state, int enable);
-VVM_API float vvm_state_last_kernel_ms(vvm_state* state);  /* blocks until the kernel has finished */
+/* Kernel timing with HIP events recorded on the stream each kernel is enqueued on.  While enabled, every Exec of the state
+ * records one event pair around its kernel (two event records per Exec, at most 4096 pairs between collects).
+ * vvm_state_collect_kernel_ms blocks until the recorded kernels have finished, returns the sum of their durations and how
+ * many there were, and starts a new collection. */
+VVM_API int vvm_state_enable_timing(vvm_state* state, int enable);
+VVM_API int vvm_state_collect_kernel_ms(vvm_state* state, float* sum_ms, int32_t* launches);
+
+/* Enqueue a device-to-device copy of the state's survivor counts (int32[max(1, MaxOutputDataSet)]) on `stream`
+ * (NULL = the state's stream).  For callers that exchange the counts between GPUs without a host round trip. */
+VVM_API int vvm_state_copy_counts(vvm_state* state, void* dst_device, void* stream);
 
 #ifdef __cplusplus
 }

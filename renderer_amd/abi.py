@@ -263,6 +263,8 @@ class HipBackend(Backend):
         L.vvm_state_max_output_dataset.argtypes = [C.c_void_p]
         L.vvm_state_info.restype = C.c_int
         L.vvm_state_info.argtypes = [C.c_void_p, C.POINTER(ProgramInfo)]
+        L.vvm_inspect_blob.restype = C.c_int
+        L.vvm_inspect_blob.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(ProgramInfo)]
         L.vvm_device_alloc.restype = C.c_void_p
         L.vvm_device_alloc.argtypes = [C.c_size_t]
         L.vvm_device_free.restype = None
@@ -278,8 +280,10 @@ class HipBackend(Backend):
         L.vvm_set_device.argtypes = [C.c_int]
         L.vvm_state_enable_timing.restype = C.c_int
         L.vvm_state_enable_timing.argtypes = [C.c_void_p, C.c_int]
-        L.vvm_state_last_kernel_ms.restype = C.c_float
-        L.vvm_state_last_kernel_ms.argtypes = [C.c_void_p]
+        L.vvm_state_collect_kernel_ms.restype = C.c_int
+        L.vvm_state_collect_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+        L.vvm_state_copy_counts.restype = C.c_int
+        L.vvm_state_copy_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
 
     def _check(self, rc: int, where: str) -> None:
         if rc != VVM_OK:
@@ -303,6 +307,12 @@ class HipBackend(Backend):
         if opts is not None:
             oarr = (ExecOptions * n)(*opts)
         self._check(self.lib.vvm_exec_batch(arr, n, oarr), "vvm_exec_batch")
+
+    def inspect_blob(self, blob: bytes) -> ProgramInfo:
+        """Thaw + link only (no device needed); raises VVMError with the linker's message on a bad script."""
+        pi = ProgramInfo()
+        self._check(self.lib.vvm_inspect_blob(blob, len(blob), C.byref(pi)), "vvm_inspect_blob")
+        return pi
 
     def info(self, state: int) -> ProgramInfo:
         pi = ProgramInfo()

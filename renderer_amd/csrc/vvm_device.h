@@ -1,0 +1,80 @@
+// vvm_device.h -- structures shared by the host launcher and the gfx950 interpreter kernel.
+//
+// The optimized bytecode the reference interprets (VectorVMRuntime.cpp:2135-2175) is byte-packed with
+// unaligned u16 operands.  vvm_alloc_state re-encodes it once into fixed 16-byte device instructions that
+// a wave can fetch with one scalar load; the re-encoding plays the role of the reference's per-Exec
+// register pointer table (VectorVMRuntime.cpp:315-443): it resolves every register index to where the
+// value lives on the GPU (per-lane register, constant, input stream).
+#pragma once
+#include <stdint.h>
+
+#define VVM_BLOCK_THREADS 256
+
+// ---- operand = class (3 bits) | index (13 bits) ----
+enum : uint32_t {
+	VVM_OPC_VREG  = 0,   // per-lane virtual register: index < resident count -> VGPR, else LDS slot
+	VVM_OPC_CONST = 1,   // remapped constant (uniform)
+	VVM_OPC_INPUT = 2,   // advancing 32-bit input stream, read at the instance index
+	VVM_OPC_NOADV = 3,   // no-advance input: element [InstanceOffset] of the stream, uniform (VectorVMRuntime.cpp:381-401)
+	VVM_OPC_HALF  = 4,   // advancing 16-bit input stream (only half_to_float / *_from_half read it)
+	VVM_OPC_NOADV_HALF = 5,
+	VVM_OPC_NONE  = 7    // 0xFFFF in the bytecode: external-function dummy register
+};
+#define VVM_OPND(cls, idx) ((uint32_t)(((cls) << 13) | ((idx) & 0x1FFFu)))
+#define VVM_OPND_CLS(o)    (((o) >> 13) & 7u)
+#define VVM_OPND_IDX(o)    ((o) & 0x1FFFu)
+#define VVM_MAX_OPND_INDEX 0x1FFFu
+
+// ---- device-only opcodes (the reference's opcodes keep their numbers 0..178) ----
+enum : uint32_t {
+	VVM_DOP_LOADN  = 192,  // prefetch up to 8 input streams into consecutive virtual registers
+	VVM_DOP_OUTPUT32 = 193, // up to 3 (src,dst) pairs of outputdata_float / outputdata_int32
+	VVM_DOP_OUTPUT16 = 194, // up to 3 pairs of outputdata_half (float register -> half stream)
+	VVM_DOP_OUTPUT16_FROM16 = 195,
+	VVM_DOP_OUTPUT32_FROM16 = 196
+};
+
+// Device instruction, 16 bytes:
+//   w0: op[0:8) nin[8:11) nout[11:13) aux[16:24) aux2[24:32)
+//   w1: o0 | o1 << 16      w2: o2 | o3 << 16      w3: o4 | o5 << 16
+// For ordinary ops the inputs are o0.. in order and the outputs are o5 (first) and o4 (second).
+struct VvmIns {
+	uint32_t w0, w1, w2, w3;
+};
+#define VVM_INS_W0(op, nin, nout, aux, aux2) \
+	((uint32_t)(op) | ((uint32_t)(nin) << 8) | ((uint32_t)(nout) << 11) | ((uint32_t)(aux) << 16) | ((uint32_t)(aux2) << 24))
+
+// One Exec (one emitter) as the kernel sees it.  Lives in device memory.
+struct VvmExecDesc {
+	const VvmIns*   prog;
+	const uint32_t* consts;        // NumConstBuffers dwords, remapped order
+	const uint64_t* in_ptrs;       // byte address of element [InstanceOffset] of every remapped input stream
+	const uint64_t* out_ptrs;      // byte address of element [InstanceOffset] of every output, by output serial index (0 = none)
+	unsigned long long* status;    // one look-back word per tile of this Exec
+	int32_t*        counts;        // survivor count per output dataset (written by the Exec's last tile)
+	const uint8_t*  perlin;        // 512-byte permutation table when the script calls a noise built-in
+	uint32_t num_instances;
+	uint32_t num_tiles;
+	uint32_t first_tile;           // ticket number of this Exec's first tile within the launch
+	int32_t  exec_index_base;
+	uint32_t rand_seed_lo, rand_seed_hi;
+	int32_t  rand_instance_base;
+	uint32_t flags;
+	uint32_t pad[2];
+};
+
+enum : uint32_t {
+	VVM_DESC_USES_PERLIN = 1u << 0
+};
+
+// Launch-wide words in device memory; the last block to leave a launch re-arms them for the next one.
+struct VvmLaunchState {
+	uint32_t ticket;     // next tile to hand out
+	uint32_t done;       // blocks that have left
+	uint32_t epoch;      // tag that makes a look-back word valid for this launch (never 0)
+	uint32_t pad;
+};
+
+// look-back word: tag[34:64) | flag[32:34) | value[0:32)
+#define VVM_LB_AGGREGATE 1ull
+#define VVM_LB_INCLUSIVE 2ull

@@ -1,0 +1,655 @@
+// vvm_host.cpp -- C ABI of the executor (include/vvm_abi.h): state allocation and the Exec launcher.
+//
+//   vvm_alloc_state / vvm_free_state   <- AllocVectorVMState / FreeVectorVMState   VectorVMRuntime.cpp:2311-2425
+//   vvm_exec*                          <- ExecVectorVMState                        VectorVMRuntime.cpp:2182-2309
+// What the reference does per Exec on the CPU and what happens to it here:
+//   ext-fn table check, zero NumOutputPerDataSet   :2184-2195   -> host, before the launch
+//   VVMBuildMapTableCaches (first Exec)            :2198-2202   -> host, resolve_maps()
+//   constants broadcast                            :2204-2207   -> host packs one dword per constant, the kernel broadcasts
+//   chunking                                       :2210-2261   -> not needed (Internal.* is still filled in for callers that read it)
+//   SetupBatchStatePtrs                            :315-443     -> host packs stream addresses (InstanceOffset applied)
+//   chunk loop                                     :2276-2295   -> ONE kernel launch (vvm_kernels.hip)
+//   DataSetAccessIndex = count - 1                 :2305-2308   -> host, after the 4-byte-per-dataset read-back
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/vvm_abi.h"
+#include "vvm_device.h"
+#include "vvm_kernels.h"
+#include "vvm_program.h"
+
+#include "vvm_perlin_table.inc"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& what)
+{
+	g_last_error = what;
+	return code;
+}
+int hip_fail(hipError_t e, const char* where)
+{
+	g_last_error = std::string(where) + ": " + hipGetErrorString(e);
+	return VVM_E_HIP;
+}
+#define HIP_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_fail(e_, #call); } while (0)
+
+constexpr int kParamSlots = 8;
+
+// Pinned staging + device copy of the per-Exec parameter block, used round-robin so that several Execs can be queued.
+struct ParamRing {
+	uint8_t* host[kParamSlots] = {};
+	uint8_t* dev[kParamSlots] = {};
+	hipEvent_t done[kParamSlots] = {};
+	bool pending[kParamSlots] = {};
+	size_t slot_bytes = 0;
+	int next = 0;
+
+	int reserve(size_t bytes)
+	{
+		if (bytes <= slot_bytes) return VVM_OK;
+		HIP_TRY(hipDeviceSynchronize());
+		release();
+		slot_bytes = std::max<size_t>(4096, (bytes + 4095) & ~(size_t)4095);
+		for (int i = 0; i < kParamSlots; ++i) {
+			HIP_TRY(hipHostMalloc((void**)&host[i], slot_bytes, hipHostMallocDefault));
+			HIP_TRY(hipMalloc((void**)&dev[i], slot_bytes));
+			HIP_TRY(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+			pending[i] = false;
+		}
+		return VVM_OK;
+	}
+	int acquire(int& slot)
+	{
+		slot = next;
+		next = (next + 1) % kParamSlots;
+		if (pending[slot]) { HIP_TRY(hipEventSynchronize(done[slot])); pending[slot] = false; }
+		return VVM_OK;
+	}
+	void release()
+	{
+		for (int i = 0; i < kParamSlots; ++i) {
+			if (host[i]) (void)hipHostFree(host[i]);
+			if (dev[i]) (void)hipFree(dev[i]);
+			if (done[i]) (void)hipEventDestroy(done[i]);
+			host[i] = dev[i] = nullptr; done[i] = nullptr; pending[i] = false;
+		}
+		slot_bytes = 0;
+	}
+};
+
+struct DeviceInfo {
+	int num_cus = 256;
+	bool ready = false;
+};
+DeviceInfo g_dev;
+std::mutex g_dev_mutex;
+
+int ensure_device_info()
+{
+	std::lock_guard<std::mutex> lock(g_dev_mutex);
+	if (g_dev.ready) return VVM_OK;
+	int dev = 0;
+	HIP_TRY(hipGetDevice(&dev));
+	hipDeviceProp_t prop;
+	HIP_TRY(hipGetDeviceProperties(&prop, dev));
+	g_dev.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+	(void)vvm_kernel_max_dynamic_lds();
+	g_dev.ready = true;
+	return VVM_OK;
+}
+
+}  // namespace
+
+struct vvm_state {
+	vvm::ThawedScript script;
+	vvm::LinkedProgram wide, narrow;       // narrow is linked on demand (VVM_EXEC_NO_VGPR_WIDE)
+	bool narrow_ready = false;
+
+	VvmIns* d_code_wide = nullptr;
+	VvmIns* d_code_narrow = nullptr;
+	uint8_t* d_perlin = nullptr;
+	VvmLaunchState* d_launch = nullptr;
+	unsigned long long* d_status = nullptr;
+	uint32_t status_capacity = 0;          // tiles
+	int32_t* d_counts = nullptr;
+	int32_t* h_counts = nullptr;           // pinned: counts, then the launch error word
+	ParamRing ring;
+	hipStream_t stream = nullptr;
+	bool own_stream = false;
+	hipStream_t last_stream = nullptr;
+
+	// map caches, VectorVMRuntime.cpp:485-553 (constants only: inputs are classified at link time)
+	bool maps_ready = false;
+	std::vector<uint8_t>  const_table;     // ConstMapCacheIdx
+	std::vector<uint16_t> const_dword;     // ConstMapCacheSrc
+
+	// kernel timing: one event pair per launch since the last collect, on the stream the kernel runs on
+	bool timing = false;
+	std::vector<hipEvent_t> ev_start, ev_stop;
+	size_t ev_used = 0;
+	uint32_t execs_since_status_reset = 0;
+};
+
+namespace {
+
+int upload_code(const vvm::LinkedProgram& lp, VvmIns** d_code)
+{
+	HIP_TRY(hipMalloc((void**)d_code, lp.code.size() * sizeof(VvmIns)));
+	HIP_TRY(hipMemcpy(*d_code, lp.code.data(), lp.code.size() * sizeof(VvmIns), hipMemcpyHostToDevice));
+	return VVM_OK;
+}
+
+int ensure_status(vvm_state* st, uint32_t tiles)
+{
+	if (tiles <= st->status_capacity) return VVM_OK;
+	if (st->last_stream) HIP_TRY(hipStreamSynchronize(st->last_stream));
+	if (st->d_status) HIP_TRY(hipFree(st->d_status));
+	const uint32_t cap = std::max<uint32_t>(1024, tiles + tiles / 4);
+	HIP_TRY(hipMalloc((void**)&st->d_status, (size_t)cap * 8));
+	HIP_TRY(hipMemset(st->d_status, 0, (size_t)cap * 8));     // tag 0 is never valid
+	st->status_capacity = cap;
+	return VVM_OK;
+}
+
+int resolve_maps(vvm_state* st, const vvm_exec_context* ctx)
+{
+	const vvm::ThawedScript& s = st->script;
+	if (ctx->ConstantTableCount > 0xFF) return fail(VVM_E_INVALID_ARG, "more than 255 constant tables");     // RT.cpp:488
+	st->const_table.assign(s.num_consts, 0);
+	st->const_dword.assign(s.num_consts, 0);
+	for (uint32_t i = 0; i < s.num_consts; ++i) {
+		const uint32_t remapped = s.const_remap[i];
+		uint32_t acc = 0;
+		bool found = false;
+		for (int j = 0; j < ctx->ConstantTableCount; ++j) {
+			const uint32_t ndw = (uint32_t)ctx->ConstantTableNumBytes[j] >> 2;
+			if (acc + ndw > remapped) {
+				st->const_table[i] = (uint8_t)j;
+				st->const_dword[i] = (uint16_t)(remapped - acc);
+				found = true;
+				break;
+			}
+			acc += ndw;
+		}
+		if (!found) return fail(VVM_E_INVALID_ARG, "a constant the script reads lies past the end of the constant tables");
+	}
+	st->maps_ready = true;
+	return VVM_OK;
+}
+
+struct PreparedExec {
+	const vvm::LinkedProgram* lp = nullptr;
+	const VvmIns* d_code = nullptr;
+	uint32_t tiles = 0;
+	size_t bytes = 0;           // parameter block: desc + consts + in_ptrs + out_ptrs
+	size_t off_consts = 0, off_in = 0, off_out = 0;
+};
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) & ~(a - 1); }
+
+// Validates the context and sizes its parameter block.
+int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, PreparedExec& pe)
+{
+	const vvm::ThawedScript& s = st->script;
+	if ((uint32_t)ctx->ExtFunctionTable.num != s.num_ext_fns)                                         // RT.cpp:2184-2187
+		return fail(VVM_E_EXTFN_MISMATCH, "ExtFunctionTable.num differs from the script's external function count");
+	if (s.bytecode.empty()) return fail(VVM_E_NO_BYTECODE, "state has no bytecode");                    // RT.cpp:2264-2267
+	if (ctx->NumInstances < 0) return fail(VVM_E_INVALID_ARG, "negative NumInstances");
+	const bool narrow = opt && (opt->Flags & VVM_EXEC_NO_VGPR_WIDE);
+	if (narrow && st->wide.instances_per_lane != 1) {
+		if (!st->narrow_ready) {
+			std::string err;
+			int rc = vvm::link_program(s, true, st->narrow, err);
+			if (rc != VVM_OK) return fail(rc, err);
+			rc = upload_code(st->narrow, &st->d_code_narrow);
+			if (rc != VVM_OK) return rc;
+			st->narrow_ready = true;
+		}
+		pe.lp = &st->narrow; pe.d_code = st->d_code_narrow;
+	} else {
+		pe.lp = &st->wide; pe.d_code = st->d_code_wide;
+	}
+	for (uint32_t i = 0; i < s.num_ext_fns; ++i) {
+		const vvm_ext_function* f = ctx->ExtFunctionTable.data[i];
+		const int want = (s.ext_num_outputs[i] == 1) ? VVM_EXTFN_PERLIN3 : VVM_EXTFN_CURL_NOISE3;
+		if (!f || f->builtin_id != want)
+			return fail(VVM_E_UNSUPPORTED_OP, "external function is not one of the GPU built-ins (perlin3: 3 in/1 out, curl_noise3: 3 in/3 out)");
+	}
+	if (!st->maps_ready) {                                                                             // RT.cpp:2198-2202
+		int rc = resolve_maps(st, ctx);
+		if (rc != VVM_OK) return rc;
+	}
+	const uint32_t tile = VVM_BLOCK_THREADS * pe.lp->instances_per_lane;
+	pe.tiles = ((uint32_t)ctx->NumInstances + tile - 1) / tile;
+	const uint32_t O = std::max<uint32_t>(s.num_outputs_remapped, s.num_output_instructions);
+	pe.off_consts = align_up(sizeof(VvmExecDesc), 16);
+	pe.off_in = align_up(pe.off_consts + 4u * (size_t)s.num_consts, 16);
+	pe.off_out = align_up(pe.off_in + 8u * (size_t)s.num_inputs, 16);
+	pe.bytes = align_up(pe.off_out + 8u * (size_t)O, 256);
+	return VVM_OK;
+}
+
+// Fills one parameter block at `host` that will live at device address `dev`.
+int fill_params(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, const PreparedExec& pe, uint8_t* host,
+                uint8_t* dev, unsigned long long* d_status, uint32_t first_tile)
+{
+	const vvm::ThawedScript& s = st->script;
+	const vvm::LinkedProgram& lp = *pe.lp;
+	VvmExecDesc* d = (VvmExecDesc*)host;
+	memset(d, 0, sizeof(*d));
+	d->prog = pe.d_code;
+	d->consts = (const uint32_t*)(dev + pe.off_consts);
+	d->in_ptrs = (const uint64_t*)(dev + pe.off_in);
+	d->out_ptrs = (const uint64_t*)(dev + pe.off_out);
+	d->status = d_status;
+	d->counts = st->d_counts;
+	d->perlin = st->d_perlin;
+	d->num_instances = (uint32_t)ctx->NumInstances;
+	d->num_tiles = pe.tiles;
+	d->first_tile = first_tile;
+	d->exec_index_base = opt ? opt->ExecIndexBase : 0;
+	d->rand_seed_lo = opt ? (uint32_t)opt->RandSeed : 0;
+	d->rand_seed_hi = opt ? (uint32_t)(opt->RandSeed >> 32) : 0;
+	d->rand_instance_base = opt ? opt->RandInstanceBase : 0;
+	d->flags = lp.uses_perlin ? VVM_DESC_USES_PERLIN : 0;
+
+	uint32_t* consts = (uint32_t*)(host + pe.off_consts);                                               // RT.cpp:2204-2207
+	for (uint32_t i = 0; i < s.num_consts; ++i) {
+		const uint8_t* table = ctx->ConstantTableData[st->const_table[i]];
+		memcpy(&consts[i], table + 4u * (size_t)st->const_dword[i], 4);
+	}
+	uint64_t* in_ptrs = (uint64_t*)(host + pe.off_in);                                                  // RT.cpp:366-416
+	for (uint32_t i = 0; i < s.num_inputs; ++i) {
+		const vvm::InputInfo& in = lp.inputs[i];
+		if ((int)in.dataset >= ctx->DataSets.num) return fail(VVM_E_INVALID_ARG, "script reads a dataset the context does not provide");
+		const vvm_dataset_meta& ds = ctx->DataSets.data[in.dataset];
+		const uint32_t idx = ds.InputRegisterTypeOffsets[in.type] + in.reg;
+		if ((int)idx >= ds.InputRegisters.num) return fail(VVM_E_INVALID_ARG, "input register index past InputRegisters.num");
+		const uint64_t stride = (in.type == 2) ? 2 : 4;
+		in_ptrs[i] = (uint64_t)(uintptr_t)ds.InputRegisters.data[idx] + (uint64_t)(int64_t)ds.InstanceOffset * stride;
+	}
+	uint64_t* out_ptrs = (uint64_t*)(host + pe.off_out);                                                // RT.cpp:418-441
+	const uint32_t O = std::max<uint32_t>(s.num_outputs_remapped, s.num_output_instructions);
+	for (uint32_t i = 0; i < O; ++i) {
+		out_ptrs[i] = 0;
+		if (i >= s.num_outputs_remapped || s.out_dst[i] == 0xFFFF) continue;
+		const uint8_t dsi = s.out_dataset[i];
+		const uint16_t ty = s.out_type[i];
+		if ((int)dsi >= ctx->DataSets.num || ty > 2) return fail(VVM_E_INVALID_ARG, "script writes a dataset the context does not provide");
+		const vvm_dataset_meta& ds = ctx->DataSets.data[dsi];
+		const uint32_t idx = ds.OutputRegisterTypeOffsets[ty] + s.out_dst[i];
+		if ((int)idx >= ds.OutputRegisters.num) return fail(VVM_E_INVALID_ARG, "output register index past OutputRegisters.num");
+		const uint64_t stride = (ty == 2) ? 2 : 4;
+		out_ptrs[i] = (uint64_t)(uintptr_t)ds.OutputRegisters.data[idx] + (uint64_t)(int64_t)ds.InstanceOffset * stride;
+	}
+	// the reference's chunk bookkeeping has no meaning here; report one chunk that holds everything
+	ctx->Internal.NumBytesRequiredPerBatch = 0;
+	ctx->Internal.PerBatchRegisterDataBytesRequired = 0;
+	ctx->Internal.MaxChunksPerBatch = 1;
+	ctx->Internal.MaxInstancesPerChunk = ((uint32_t)ctx->NumInstances + 3u) & ~3u;
+	return VVM_OK;
+}
+
+uint32_t grid_for(uint32_t tiles)
+{
+	const uint32_t resident = (uint32_t)g_dev.num_cus * 8u;
+	return std::max<uint32_t>(1, std::min<uint32_t>(tiles, resident));
+}
+
+int write_back_counts(vvm_state* st, vvm_exec_context* ctx, bool ran_kernel)
+{
+	const vvm::ThawedScript& s = st->script;
+	for (uint32_t i = 0; i < s.max_output_dataset && (int)i < ctx->DataSets.num; ++i) {             // RT.cpp:2305-2308
+		int32_t n = 0;
+		if (ran_kernel && i < st->wide.acquires_dataset.size() && st->wide.acquires_dataset[i]) n = st->h_counts[i];
+		ctx->DataSets.data[i].DataSetAccessIndex = n - 1;
+	}
+	return VVM_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+extern "C" {
+
+VVM_API const char* vvm_last_error(void) { return g_last_error.c_str(); }
+
+VVM_API vvm_state* vvm_alloc_state(const uint8_t* blob, size_t num_bytes)
+{
+	vvm_state* st = new vvm_state();
+	std::string err;
+	int rc = vvm::thaw_blob(blob, num_bytes, st->script, err);
+	if (rc == VVM_OK) rc = vvm::link_program(st->script, false, st->wide, err);
+	if (rc != VVM_OK) { fail(rc, err); delete st; return nullptr; }
+	auto bail = [&](hipError_t e, const char* where) -> vvm_state* { hip_fail(e, where); vvm_free_state(st); return nullptr; };
+	if (ensure_device_info() != VVM_OK) { vvm_free_state(st); return nullptr; }
+	if (upload_code(st->wide, &st->d_code_wide) != VVM_OK) { vvm_free_state(st); return nullptr; }
+	hipError_t e;
+	if (st->wide.uses_perlin) {
+		if ((e = hipMalloc((void**)&st->d_perlin, 512)) != hipSuccess) return bail(e, "hipMalloc(perlin)");
+		if ((e = hipMemcpy(st->d_perlin, k_perlin_perm_host, 512, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(perlin)");
+	}
+	const VvmLaunchState init{0, 0, 1, 0};
+	if ((e = hipMalloc((void**)&st->d_launch, sizeof(VvmLaunchState))) != hipSuccess) return bail(e, "hipMalloc(launch state)");
+	if ((e = hipMemcpy(st->d_launch, &init, sizeof(init), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(launch state)");
+	const size_t ncounts = std::max<uint32_t>(st->script.max_output_dataset, 1) + 4;
+	if ((e = hipMalloc((void**)&st->d_counts, ncounts * 4)) != hipSuccess) return bail(e, "hipMalloc(counts)");
+	if ((e = hipMemset(st->d_counts, 0, ncounts * 4)) != hipSuccess) return bail(e, "hipMemset(counts)");
+	if ((e = hipHostMalloc((void**)&st->h_counts, ncounts * 4 + sizeof(VvmLaunchState), hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc(counts)");
+	memset(st->h_counts, 0, ncounts * 4 + sizeof(VvmLaunchState));
+	if ((e = hipStreamCreateWithFlags(&st->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+	st->own_stream = true;
+	return st;
+}
+
+VVM_API void vvm_free_state(vvm_state* st)
+{
+	if (!st) return;
+	if (st->last_stream) (void)hipStreamSynchronize(st->last_stream);
+	st->ring.release();
+	if (st->d_code_wide) (void)hipFree(st->d_code_wide);
+	if (st->d_code_narrow) (void)hipFree(st->d_code_narrow);
+	if (st->d_perlin) (void)hipFree(st->d_perlin);
+	if (st->d_launch) (void)hipFree(st->d_launch);
+	if (st->d_status) (void)hipFree(st->d_status);
+	if (st->d_counts) (void)hipFree(st->d_counts);
+	if (st->h_counts) (void)hipHostFree(st->h_counts);
+	for (hipEvent_t e : st->ev_start) (void)hipEventDestroy(e);
+	for (hipEvent_t e : st->ev_stop) (void)hipEventDestroy(e);
+	if (st->own_stream && st->stream) (void)hipStreamDestroy(st->stream);
+	delete st;
+}
+
+VVM_API int vvm_exec_async(vvm_exec_context* ctx, const vvm_exec_options* opt)
+{
+	if (!ctx || !ctx->VVMState) return fail(VVM_E_INVALID_ARG, "null context or state");
+	vvm_state* st = ctx->VVMState;
+	PreparedExec pe;
+	int rc = prepare(st, ctx, opt, pe);
+	if (rc != VVM_OK) return rc;
+	hipStream_t stream = (opt && opt->Stream) ? (hipStream_t)opt->Stream : st->stream;
+	if (st->last_stream && st->last_stream != stream) HIP_TRY(hipStreamSynchronize(st->last_stream));
+	st->last_stream = stream;
+	if (pe.tiles == 0) {     // nothing to run: zero chunks in the reference too (RT.cpp:2277)
+		st->h_counts[0] = 0;
+		for (uint32_t i = 0; i < st->script.max_output_dataset; ++i) st->h_counts[i] = 0;
+		return VVM_OK;
+	}
+	rc = ensure_status(st, pe.tiles);
+	if (rc != VVM_OK) return rc;
+	rc = st->ring.reserve(pe.bytes);
+	if (rc != VVM_OK) return rc;
+	int slot = 0;
+	rc = st->ring.acquire(slot);
+	if (rc != VVM_OK) return rc;
+	rc = fill_params(st, ctx, opt, pe, st->ring.host[slot], st->ring.dev[slot], st->d_status, 0);
+	if (rc != VVM_OK) return rc;
+	HIP_TRY(hipMemcpyAsync(st->ring.dev[slot], st->ring.host[slot], pe.bytes, hipMemcpyHostToDevice, stream));
+	const bool timed = st->timing && st->ev_used < 4096;
+	if (timed) {
+		if (st->ev_used == st->ev_start.size()) {
+			hipEvent_t a = nullptr, b = nullptr;
+			HIP_TRY(hipEventCreate(&a));
+			HIP_TRY(hipEventCreate(&b));
+			st->ev_start.push_back(a); st->ev_stop.push_back(b);
+		}
+		HIP_TRY(hipEventRecord(st->ev_start[st->ev_used], stream));
+	}
+	const int lrc = vvm_launch_exec_kernel((int)pe.lp->instances_per_lane, (const VvmExecDesc*)st->ring.dev[slot], 1, pe.tiles, st->d_launch,
+	                                       pe.lp->lds_spill_slots, pe.lp->full_kernel ? 1 : 0, grid_for(pe.tiles), stream);
+	if (lrc != 0) return hip_fail((hipError_t)lrc, "kernel launch");
+	if (timed) { HIP_TRY(hipEventRecord(st->ev_stop[st->ev_used], stream)); st->ev_used++; }
+	HIP_TRY(hipEventRecord(st->ring.done[slot], stream));
+	st->ring.pending[slot] = true;
+	const size_t ncounts = std::max<uint32_t>(st->script.max_output_dataset, 1);
+	HIP_TRY(hipMemcpyAsync(st->h_counts, st->d_counts, ncounts * 4, hipMemcpyDeviceToHost, stream));
+	HIP_TRY(hipMemcpyAsync(st->h_counts + ncounts + 4, st->d_launch, sizeof(VvmLaunchState), hipMemcpyDeviceToHost, stream));
+	return VVM_OK;
+}
+
+VVM_API int vvm_exec_finish(vvm_exec_context* ctx)
+{
+	if (!ctx || !ctx->VVMState) return fail(VVM_E_INVALID_ARG, "null context or state");
+	vvm_state* st = ctx->VVMState;
+	const bool ran = ctx->NumInstances > 0;
+	if (st->last_stream) HIP_TRY(hipStreamSynchronize(st->last_stream));
+	if (ran) {
+		const size_t ncounts = std::max<uint32_t>(st->script.max_output_dataset, 1);
+		const VvmLaunchState* ls = (const VvmLaunchState*)(st->h_counts + ncounts + 4);
+		if (ls->pad != 0) {
+			const VvmLaunchState init{0, 0, 1, 0};
+			(void)hipMemcpy(st->d_launch, &init, sizeof(init), hipMemcpyHostToDevice);
+			if (st->d_status) (void)hipMemset(st->d_status, 0, (size_t)st->status_capacity * 8);
+			return fail(VVM_E_HIP, "look-back timed out inside the kernel (a tile never published its count)");
+		}
+	}
+	return write_back_counts(st, ctx, ran);
+}
+
+VVM_API int vvm_exec_ex(vvm_exec_context* ctx, const vvm_exec_options* opt)
+{
+	int rc = vvm_exec_async(ctx, opt);
+	if (rc != VVM_OK) return rc;
+	return vvm_exec_finish(ctx);
+}
+
+VVM_API int vvm_exec(vvm_exec_context* ctx) { return vvm_exec_ex(ctx, nullptr); }
+
+// --- batched launch ---------------------------------------------------------------------------------
+namespace {
+struct BatchWorkspace {
+	std::mutex mutex;
+	uint8_t* host = nullptr; uint8_t* dev = nullptr; size_t bytes = 0;
+	unsigned long long* d_status = nullptr; uint32_t status_capacity = 0;
+	VvmLaunchState* d_launch[8] = {};
+	VvmLaunchState* h_launch = nullptr;
+	hipStream_t stream = nullptr;
+};
+BatchWorkspace g_batch;
+}  // namespace
+
+VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_options* opts)
+{
+	if (n < 0 || (n > 0 && !ctxs)) return fail(VVM_E_INVALID_ARG, "bad batch");
+	if (n == 0) return VVM_OK;
+	std::lock_guard<std::mutex> lock(g_batch.mutex);
+	int rc = ensure_device_info();
+	if (rc != VVM_OK) return rc;
+	std::vector<PreparedExec> pes((size_t)n);
+	// group by kernel shape: (instances per lane, spill, full)
+	struct Group { int key; std::vector<int> members; uint32_t tiles = 0; uint32_t spill = 0; };
+	std::vector<Group> groups;
+	size_t total_bytes = 0; uint32_t total_tiles = 0;
+	for (int i = 0; i < n; ++i) {
+		if (!ctxs[i].VVMState) return fail(VVM_E_INVALID_ARG, "null state in batch");
+		for (int j = 0; j < i; ++j)
+			if (ctxs[j].VVMState == ctxs[i].VVMState) return fail(VVM_E_INVALID_ARG, "a state appears twice in one batch (one Exec at a time per state)");
+		rc = prepare(ctxs[i].VVMState, &ctxs[i], opts ? &opts[i] : nullptr, pes[(size_t)i]);
+		if (rc != VVM_OK) return rc;
+		vvm_state* st = ctxs[i].VVMState;
+		if (st->last_stream) { HIP_TRY(hipStreamSynchronize(st->last_stream)); }
+		const vvm::LinkedProgram& lp = *pes[(size_t)i].lp;
+		const int key = (int)lp.instances_per_lane * 4 + (lp.lds_spill_slots ? 2 : 0) + (lp.full_kernel ? 1 : 0);
+		Group* g = nullptr;
+		for (Group& c : groups) if (c.key == key) g = &c;
+		if (!g) { groups.push_back(Group{key, {}, 0, 0}); g = &groups.back(); }
+		g->members.push_back(i);
+		g->spill = std::max(g->spill, lp.lds_spill_slots);
+		total_bytes += pes[(size_t)i].bytes;
+		total_tiles += pes[(size_t)i].tiles;
+	}
+	if (groups.size() > 8) return fail(VVM_E_TOO_LARGE, "too many kernel shapes in one batch");
+	if (!g_batch.stream) HIP_TRY(hipStreamCreateWithFlags(&g_batch.stream, hipStreamNonBlocking));
+	if (total_tiles > g_batch.status_capacity) {
+		if (g_batch.d_status) (void)hipFree(g_batch.d_status);
+		g_batch.status_capacity = total_tiles + total_tiles / 4 + 1024;
+		HIP_TRY(hipMalloc((void**)&g_batch.d_status, (size_t)g_batch.status_capacity * 8));
+		HIP_TRY(hipMemset(g_batch.d_status, 0, (size_t)g_batch.status_capacity * 8));
+	}
+	if (!g_batch.h_launch) HIP_TRY(hipHostMalloc((void**)&g_batch.h_launch, 8 * sizeof(VvmLaunchState), hipHostMallocDefault));
+	for (size_t g = 0; g < groups.size(); ++g)
+		if (!g_batch.d_launch[g]) {
+			const VvmLaunchState init{0, 0, 1, 0};
+			HIP_TRY(hipMalloc((void**)&g_batch.d_launch[g], sizeof(VvmLaunchState)));
+			HIP_TRY(hipMemcpy(g_batch.d_launch[g], &init, sizeof(init), hipMemcpyHostToDevice));
+		}
+
+	// Descriptors of one group are contiguous (the kernel indexes them); their tables follow all descriptors.
+	size_t desc_off = 0;
+	size_t table_off = align_up((size_t)n * sizeof(VvmExecDesc), 256);
+	uint32_t status_off = 0;
+	std::vector<size_t> group_desc_off(groups.size());
+	// per-exec parameter blocks are laid out as [desc | tables] by fill_params; here desc and tables are split, so fill into a
+	// scratch block and scatter
+	std::vector<uint8_t> scratch;
+	const size_t total_needed = table_off + total_bytes;
+	if (total_needed > g_batch.bytes) {
+		if (g_batch.host) (void)hipHostFree(g_batch.host);
+		if (g_batch.dev) (void)hipFree(g_batch.dev);
+		g_batch.bytes = align_up(total_needed + total_needed / 4, 4096);
+		HIP_TRY(hipHostMalloc((void**)&g_batch.host, g_batch.bytes, hipHostMallocDefault));
+		HIP_TRY(hipMalloc((void**)&g_batch.dev, g_batch.bytes));
+	}
+	for (size_t g = 0; g < groups.size(); ++g) {
+		group_desc_off[g] = desc_off;
+		uint32_t first_tile = 0;
+		for (int i : groups[g].members) {
+			PreparedExec& pe = pes[(size_t)i];
+			vvm_state* st = ctxs[i].VVMState;
+			scratch.assign(pe.bytes, 0);
+			// tables live at table_off in the device buffer; fill_params computes table addresses as dev + pe.off_*
+			uint8_t* dev_block = g_batch.dev + table_off;
+			rc = fill_params(st, &ctxs[i], opts ? &opts[i] : nullptr, pe, scratch.data(), dev_block, g_batch.d_status + status_off, first_tile);
+			if (rc != VVM_OK) return rc;
+			memcpy(g_batch.host + desc_off, scratch.data(), sizeof(VvmExecDesc));
+			memcpy(g_batch.host + table_off, scratch.data(), pe.bytes);
+			desc_off += sizeof(VvmExecDesc);
+			table_off += pe.bytes;
+			status_off += pe.tiles;
+			first_tile += pe.tiles;
+		}
+		groups[g].tiles = first_tile;
+	}
+	HIP_TRY(hipMemcpyAsync(g_batch.dev, g_batch.host, table_off, hipMemcpyHostToDevice, g_batch.stream));
+	for (size_t g = 0; g < groups.size(); ++g) {
+		if (groups[g].tiles == 0) continue;
+		const vvm::LinkedProgram& lp = *pes[(size_t)groups[g].members[0]].lp;
+		const int lrc = vvm_launch_exec_kernel((int)lp.instances_per_lane, (const VvmExecDesc*)(g_batch.dev + group_desc_off[g]),
+		                                       (uint32_t)groups[g].members.size(), groups[g].tiles, g_batch.d_launch[g], groups[g].spill,
+		                                       lp.full_kernel ? 1 : 0, grid_for(groups[g].tiles), g_batch.stream);
+		if (lrc != 0) return hip_fail((hipError_t)lrc, "batched kernel launch");
+		HIP_TRY(hipMemcpyAsync(&g_batch.h_launch[g], g_batch.d_launch[g], sizeof(VvmLaunchState), hipMemcpyDeviceToHost, g_batch.stream));
+	}
+	for (int i = 0; i < n; ++i) {
+		vvm_state* st = ctxs[i].VVMState;
+		const size_t ncounts = std::max<uint32_t>(st->script.max_output_dataset, 1);
+		HIP_TRY(hipMemcpyAsync(st->h_counts, st->d_counts, ncounts * 4, hipMemcpyDeviceToHost, g_batch.stream));
+	}
+	HIP_TRY(hipStreamSynchronize(g_batch.stream));
+	for (size_t g = 0; g < groups.size(); ++g)
+		if (groups[g].tiles && g_batch.h_launch[g].pad != 0) {
+			const VvmLaunchState init{0, 0, 1, 0};
+			(void)hipMemcpy(g_batch.d_launch[g], &init, sizeof(init), hipMemcpyHostToDevice);
+			(void)hipMemset(g_batch.d_status, 0, (size_t)g_batch.status_capacity * 8);
+			return fail(VVM_E_HIP, "look-back timed out inside the batched kernel");
+		}
+	for (int i = 0; i < n; ++i) write_back_counts(ctxs[i].VVMState, &ctxs[i], ctxs[i].NumInstances > 0);
+	return VVM_OK;
+}
+
+// --- introspection / helpers ------------------------------------------------------------------------
+VVM_API const int32_t* vvm_state_device_counts(const vvm_state* st) { return st ? st->d_counts : nullptr; }
+VVM_API int32_t vvm_state_max_output_dataset(const vvm_state* st) { return st ? (int32_t)st->script.max_output_dataset : 0; }
+
+static void fill_info(const vvm::ThawedScript& s, const vvm::LinkedProgram& lp, vvm_program_info* out)
+{
+	out->NumTempRegisters = s.num_temps;
+	out->NumConstBuffers = s.num_consts;
+	out->NumInputBuffers = s.num_inputs;
+	out->NumOutputBuffers = s.num_output_instructions;
+	out->NumInstructions = (uint32_t)lp.code.size();
+	out->NumVirtualRegisters = lp.num_vregs;
+	out->InstancesPerLane = lp.instances_per_lane;
+	out->LdsSpillRegisters = lp.lds_spill_slots;
+	out->BytesInPerInstance = lp.bytes_in_per_instance;
+	out->BytesOutPerInstance = lp.bytes_out_per_instance;
+	out->Flags = s.flags | (lp.full_kernel ? 0x10000u : 0u);
+}
+
+VVM_API int vvm_state_info(const vvm_state* st, vvm_program_info* out)
+{
+	if (!st || !out) return fail(VVM_E_INVALID_ARG, "null argument");
+	fill_info(st->script, st->wide, out);
+	return VVM_OK;
+}
+
+VVM_API int vvm_inspect_blob(const uint8_t* blob, size_t num_bytes, vvm_program_info* out)
+{
+	if (!out) return fail(VVM_E_INVALID_ARG, "null argument");
+	vvm::ThawedScript s;
+	vvm::LinkedProgram lp;
+	std::string err;
+	int rc = vvm::thaw_blob(blob, num_bytes, s, err);
+	if (rc == VVM_OK) rc = vvm::link_program(s, false, lp, err);
+	if (rc != VVM_OK) return fail(rc, err);
+	fill_info(s, lp, out);
+	return VVM_OK;
+}
+
+VVM_API void* vvm_device_alloc(size_t num_bytes)
+{
+	void* p = nullptr;
+	hipError_t e = hipMalloc(&p, num_bytes ? num_bytes : 1);
+	if (e != hipSuccess) { hip_fail(e, "hipMalloc"); return nullptr; }
+	return p;
+}
+VVM_API void vvm_device_free(void* p) { if (p) (void)hipFree(p); }
+VVM_API int vvm_device_upload(void* dst, const void* src, size_t n) { HIP_TRY(hipMemcpy(dst, src, n, hipMemcpyHostToDevice)); return VVM_OK; }
+VVM_API int vvm_device_download(void* dst, const void* src, size_t n) { HIP_TRY(hipMemcpy(dst, src, n, hipMemcpyDeviceToHost)); return VVM_OK; }
+VVM_API int vvm_device_memset(void* dst, int v, size_t n) { HIP_TRY(hipMemset(dst, v, n)); return VVM_OK; }
+VVM_API int vvm_device_synchronize(void) { HIP_TRY(hipDeviceSynchronize()); return VVM_OK; }
+VVM_API int vvm_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+VVM_API int vvm_set_device(int ordinal) { HIP_TRY(hipSetDevice(ordinal)); return VVM_OK; }
+
+VVM_API int vvm_state_enable_timing(vvm_state* st, int enable)
+{
+	if (!st) return fail(VVM_E_INVALID_ARG, "null state");
+	st->timing = enable != 0;
+	st->ev_used = 0;
+	return VVM_OK;
+}
+
+VVM_API int vvm_state_collect_kernel_ms(vvm_state* st, float* sum_ms, int32_t* launches)
+{
+	if (!st || !sum_ms || !launches) return fail(VVM_E_INVALID_ARG, "null argument");
+	float total = 0.0f;
+	for (size_t i = 0; i < st->ev_used; ++i) {
+		HIP_TRY(hipEventSynchronize(st->ev_stop[i]));
+		float ms = 0.0f;
+		HIP_TRY(hipEventElapsedTime(&ms, st->ev_start[i], st->ev_stop[i]));
+		total += ms;
+	}
+	*sum_ms = total;
+	*launches = (int32_t)st->ev_used;
+	st->ev_used = 0;
+	return VVM_OK;
+}
+
+VVM_API int vvm_state_copy_counts(vvm_state* st, void* dst_device, void* stream)
+{
+	if (!st || !dst_device) return fail(VVM_E_INVALID_ARG, "null argument");
+	const size_t ncounts = std::max<uint32_t>(st->script.max_output_dataset, 1);
+	HIP_TRY(hipMemcpyAsync(dst_device, st->d_counts, ncounts * 4, hipMemcpyDeviceToDevice, stream ? (hipStream_t)stream : st->stream));
+	return VVM_OK;
+}
+
+}  // extern "C"

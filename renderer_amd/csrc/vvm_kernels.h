@@ -1,0 +1,15 @@
+// vvm_kernels.h -- host-callable entry points of vvm_kernels.hip.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+#include "vvm_device.h"
+
+extern "C" {
+// Enqueue the interpreter over `total_tiles` tiles described by `descs` (device memory).  instances_per_lane is 4 or 1;
+// full != 0 selects the kernel that also implements the transcendental ops and the noise built-ins.
+int vvm_launch_exec_kernel(int instances_per_lane, const VvmExecDesc* descs, uint32_t num_execs, uint32_t total_tiles,
+                           VvmLaunchState* ls, uint32_t lds_spill_slots, int full, uint32_t grid, hipStream_t stream);
+int vvm_kernel_max_dynamic_lds(void);
+uint32_t vvm_kernel_resident_registers(int instances_per_lane);
+uint32_t vvm_kernel_lds_fixed_bytes(void);
+}

@@ -1,0 +1,1049 @@
+// vvm_kernels.hip -- the gfx950 VectorVM interpreter kernel.
+//
+// Replaces the reference's chunk loop (ExecVectorVMState step 8, VectorVMRuntime.cpp:2276-2295, with
+// ExecChunkMultipleLoops :2157-2175 and the per-op dispatch loops :1558-1904).  Where the reference runs
+// chunks serially and every op makes a 4-wide SSE pass over a chunk, here a 256-thread workgroup owns a
+// tile of 256*V consecutive instances, every lane owns V consecutive instances (V = 4: one 128-bit access
+// per stream per lane), and the instruction stream is decoded once per wave from scalar memory.
+//
+//   registers   per-lane virtual registers live in a VGPR vector indexed through the scalar GPR-index mode
+//               (uniform index), the rest in LDS laid out [register][thread]
+//   inputs      VVM_DOP_LOADN issues up to 8 stream loads back to back before the first use
+//   acquireindex  sign bit of the predicate -> wave ballots + popcounts -> 4-wave scan in LDS -> decoupled
+//               look-back over per-tile words in global memory for the exclusive prefix across tiles.
+//               Survivors keep instance order (VectorVMRuntime.cpp:786-804, 824-878).
+//   outputs     written at InstanceOffset + prefix + rank; a tile with no deaths stores 128 bits per lane
+//
+// Arithmetic follows the reference's SSE math layer lane by lane (citations at each helper); it is compiled
+// with -ffp-contract=off so that every multiply-add keeps two roundings (UE_PLATFORM_MATH_USE_FMA3 = 0).
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "../../include/vvm_abi.h"
+#include "vvm_device.h"
+#include "vvm_kernels.h"
+
+typedef float    f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint16_t h4u __attribute__((ext_vector_type(4), aligned(2)));
+typedef float    f4a __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64;
+typedef __attribute__((address_space(1))) u64 gu64;
+typedef __attribute__((address_space(1))) uint32_t gu32;
+
+#define DEV __device__ __forceinline__
+#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+// Uniform tables (program, constants, stream pointers, descriptors) are never written while a launch runs, so they
+// are read through the constant address space: the compiler then issues scalar loads and keeps the values in SGPRs,
+// which is what lets a register index drive the GPR-index mode instead of a per-lane select chain.
+typedef const __attribute__((address_space(4))) uint32_t* cu32p;
+typedef const __attribute__((address_space(4))) uint64_t* cu64p;
+// (the builtin returns a signed int: the cast keeps a 64-bit composition from sign-extending its low half)
+#define SCALAR(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+__device__ __forceinline__ uint32_t sload32(const void* p, uint32_t i) { return SCALAR(((cu32p)(uintptr_t)p)[i]); }
+__device__ __forceinline__ uint64_t sload64(const void* p, uint32_t i)
+{
+	const uint64_t v = ((cu64p)(uintptr_t)p)[i];
+	return ((uint64_t)SCALAR((uint32_t)(v >> 32)) << 32) | (uint64_t)SCALAR((uint32_t)v);
+}
+
+// VGPR-resident virtual registers: one vector per instance slot of the lane, R<k>[i] = register i of the lane's k-th
+// instance.  The vectors are plain local values that are passed to helpers BY VALUE and assigned back: handed around by
+// reference they stay in a stack object whose run-time-indexed element stores the compiler leaves in scratch memory; as
+// values each one is an SSA vector indexed through the scalar GPR-index mode (s_set_gpr_idx_on + v_mov_b32).
+typedef float vec16f __attribute__((ext_vector_type(16)));
+typedef float vec32f __attribute__((ext_vector_type(32)));
+template <int V> struct RegTraits;
+template <> struct RegTraits<4> { typedef vec16f vec; static constexpr uint32_t RV = 16; };
+template <> struct RegTraits<1> { typedef vec32f vec; static constexpr uint32_t RV = 32; };
+template <typename VEC> __device__ __forceinline__ float vget(VEC v, uint32_t i) { return v[i]; }
+template <typename VEC> __device__ __forceinline__ VEC vset(VEC v, uint32_t i, float x) { v[i] = x; return v; }
+
+// LDS carve (dynamic region only, every offset a multiple of 16)
+#define LDS_CTRL_WORDS   32        // uint32: [0..3] wave totals, [8] ticket, [9] prefix, [10] flag
+#define LDS_PERLIN_OFF   128       // 512 bytes
+#define LDS_SPILL_OFF    640
+
+DEV uint32_t fbits(float f) { return __float_as_uint(f); }
+DEV float    bitsf(uint32_t u) { return __uint_as_float(u); }
+DEV float    mask(bool b) { return bitsf(b ? 0xFFFFFFFFu : 0u); }
+
+// ---- lane arithmetic ---------------------------------------------------------------------------------
+DEV float f_sel(float m, float a, float b) { uint32_t M = fbits(m); return bitsf((M & fbits(a)) | (~M & fbits(b))); }   // SSE.h:1805-1810
+DEV float f_min(float a, float b) { return (a < b) ? a : b; }                  // _mm_min_ps: second operand when unordered or equal, SSE.h:2380-2383
+DEV float f_max(float a, float b) { return (a > b) ? a : b; }                  // SSE.h:2404-2407
+DEV float f_abs(float a) { return bitsf(fbits(a) & 0x7FFFFFFFu); }             // SSE.h:1287-1290
+DEV float f_neg(float a) { return 0.0f - a; }                                  // SSE.h:1311-1314
+DEV float f_mad(float a, float b, float c) { return (a * b) + c; }             // SSE.h:1411-1418 with FMA3 off
+DEV float f_div(float a, float b) { return (f_abs(b) > 1.e-8f) ? (a / b) : 0.0f; }            // RT.cpp:1909
+DEV float f_sqrtg(float a) { return (a > 1.e-8f) ? __fsqrt_rn(a) : 0.0f; }                    // RT.cpp:1914
+DEV float f_rsq(float a) { return (a > 1.e-8f) ? (1.0f / __fsqrt_rn(a)) : 0.0f; }             // RT.cpp:1913, SSE.h:2014-2022
+DEV float f_rcp(float a) { return (f_abs(a) > 1.e-8f) ? __builtin_amdgcn_rcpf(a) : 0.0f; }    // RT.cpp:1912 (hardware estimate, SSE.h:2121-2125)
+DEV float f_lerp(float a, float b, float c) { return f_mad(b, c, a * (1.0f - c)); }           // VCOMMON.inl:532-536
+DEV float f_clamp(float a, float b, float c) { return f_min(f_max(a, b), c); }                // VCOMMON.inl:495-498
+DEV float f_sign(float a) { return (a >= 0.0f) ? 1.0f : -1.0f; }                              // SSE.h:2911-2915
+DEV float f_step(float a) { return (a >= 0.0f) ? 1.0f : 0.0f; }                               // SSE.h:2923-2927
+DEV float f_frac(float a) { return a - truncf(a); }                                           // VCOMMON.inl:883-886
+// libm-class functions stay out of line: inlined V times each into the dispatch switch they would set the kernel's register
+// allocation (and with it the occupancy of every script, including the ones that never call them)
+__device__ __noinline__ float lib_fmod(float a, float b) { return fmodf(a, b); }
+__device__ __noinline__ float lib_exp2(float a) { return powf(2.0f, a); }                       // SSE.h:2960-2972, GPM.h:491
+__device__ __noinline__ float lib_log2(float a) { return logf(a) * 1.4426950f; }                // SSE.h:3015-3027, GPM.h:502
+__device__ __noinline__ float lib_tan(float a) { return tanf(a); }                              // SSE.h:3188-3201
+__device__ __noinline__ float lib_atan(float a) { return atanf(a); }                            // SSE.h:3279-3292
+DEV float f_fmod(float a, float b) { return (f_abs(b) <= 1.e-8f) ? 0.0f : lib_fmod(a, b); }   // SSE.h:2867-2886
+// _mm_cvttps_epi32 / _mm_cvtps_epi32: 0x80000000 for NaN and out-of-range (SSE.h:3409-3412)
+DEV int32_t cvtt(float a) { return (a >= -2147483648.0f && a < 2147483648.0f) ? (int32_t)a : (int32_t)0x80000000; }
+DEV int32_t cvtr(float a) { return (a >= -2147483648.0f && a < 2147483648.0f) ? __float2int_rn(a) : (int32_t)0x80000000; }
+DEV float   i2f(int32_t a) { return (float)a; }                                               // SSE.h:3407
+
+DEV float ue_atan2(float Y, float X)                                                          // GenericPlatformMath.cpp:33-76
+{
+	const float PI = 3.1415926535897932f;
+	const float ax = f_abs(X), ay = f_abs(Y);
+	const bool ybig = ay > ax;
+	float t0 = ybig ? ay : ax, t1 = ybig ? ax : ay;
+	if (t0 == 0.f) return 0.f;
+	float t3 = t1 / t0, t4 = t3 * t3;
+	t0 = +7.2128853633444123e-03f;
+	t0 = t0 * t4 + -3.5059680836411644e-02f;
+	t0 = t0 * t4 + +8.1675882859940430e-02f;
+	t0 = t0 * t4 + -1.3374657325451267e-01f;
+	t0 = t0 * t4 + +1.9856563505717162e-01f;
+	t0 = t0 * t4 + -3.3324998579202170e-01f;
+	t0 = t0 * t4 + 1.0f;
+	t3 = t0 * t3;
+	t3 = ybig ? (0.5f * PI) - t3 : t3;
+	t3 = (X < 0.0f) ? PI - t3 : t3;
+	t3 = (Y < 0.0f) ? -t3 : t3;
+	return t3;
+}
+DEV float f_acos(float a) { return ue_atan2(f_sqrtg((1.0f - a) * (1.0f + a)), a); }           // RT.cpp:1924
+DEV float f_asin(float a) { return (3.14159265359f * 0.25f) - f_acos(a); }                    // RT.cpp:1925 with :111
+
+// sse_mathfun sin/cos/exp/log: third-party header outside the reference tree (Core/Private/Math/UnrealMathSSE.cpp:8-9);
+// restated from its published algorithm (Cephes single-precision polynomials), same operation order.
+DEV float mf_log(float x)
+{
+	const bool invalid = (x <= 0.0f);
+	x = (x > bitsf(0x00800000u)) ? x : bitsf(0x00800000u);                 // _mm_max_ps(x, min_norm_pos)
+	int32_t e0 = (int32_t)(fbits(x) >> 23);
+	x = bitsf((fbits(x) & ~0x7f800000u) | fbits(0.5f));
+	e0 -= 0x7f;
+	float e = (float)e0 + 1.0f;
+	const bool lt = x < 0.707106781186547524f;
+	float tmp = lt ? x : 0.0f;
+	x = x - 1.0f;
+	e = e - (lt ? 1.0f : 0.0f);
+	x = x + tmp;
+	float z = x * x;
+	float y = 7.0376836292E-2f;
+	y = y * x + -1.1514610310E-1f;
+	y = y * x + 1.1676998740E-1f;
+	y = y * x + -1.2420140846E-1f;
+	y = y * x + 1.4249322787E-1f;
+	y = y * x + -1.6668057665E-1f;
+	y = y * x + 2.0000714765E-1f;
+	y = y * x + -2.4999993993E-1f;
+	y = y * x + 3.3333331174E-1f;
+	y = y * x;
+	y = y * z;
+	y = y + e * -2.12194440e-4f;
+	y = y - z * 0.5f;
+	tmp = e * 0.693359375f;
+	x = x + y;
+	x = x + tmp;
+	return invalid ? bitsf(0xFFFFFFFFu) : x;                                // x | invalid_mask
+}
+
+DEV float mf_exp(float x)
+{
+	x = (x < 88.3762626647949f) ? x : 88.3762626647949f;                   // _mm_min_ps
+	x = (x > -88.3762626647949f) ? x : -88.3762626647949f;                 // _mm_max_ps
+	float fx = x * 1.44269504088896341f + 0.5f;
+	float tmp = (float)cvtt(fx);
+	fx = tmp - ((tmp > fx) ? 1.0f : 0.0f);
+	tmp = fx * 0.693359375f;
+	float z = fx * -2.12194440e-4f;
+	x = x - tmp;
+	x = x - z;
+	z = x * x;
+	float y = 1.9875691500E-4f;
+	y = y * x + 1.3981999507E-3f;
+	y = y * x + 8.3334519073E-3f;
+	y = y * x + 4.1665795894E-2f;
+	y = y * x + 1.6666665459E-1f;
+	y = y * x + 5.0000001201E-1f;
+	y = y * z + x;
+	y = y + 1.0f;
+	const uint32_t n = (uint32_t)(cvtt(fx) + 0x7f) << 23;
+	return y * bitsf(n);
+}
+
+DEV float mf_reduce(float ax, int32_t& j)
+{
+	float y = ax * 1.27323954473516f;
+	j = (cvtt(y) + 1) & ~1;
+	y = (float)j;
+	ax = ax + y * -0.78515625f;
+	ax = ax + y * -2.4187564849853515625e-4f;
+	ax = ax + y * -3.77489497744594108e-8f;
+	return ax;
+}
+DEV void mf_polys(float x, float& ysin, float& ycos)
+{
+	float z = x * x;
+	float y = 2.443315711809948E-005f;
+	y = y * z + -1.388731625493765E-003f;
+	y = y * z + 4.166664568298827E-002f;
+	y = y * z;
+	y = y * z;
+	y = y - z * 0.5f;
+	ycos = y + 1.0f;
+	float y2 = -1.9515295891E-4f;
+	y2 = y2 * z + 8.3321608736E-3f;
+	y2 = y2 * z + -1.6666654611E-1f;
+	y2 = y2 * z;
+	y2 = y2 * x;
+	ysin = y2 + x;
+}
+DEV float mf_sin(float x)
+{
+	uint32_t sign = fbits(x) & 0x80000000u;
+	int32_t j;
+	float r = mf_reduce(f_abs(x), j);
+	sign ^= (uint32_t)(j & 4) << 29;
+	float ys, yc;
+	mf_polys(r, ys, yc);
+	float y = ((j & 2) == 0) ? (0.0f + ys) : (yc + 0.0f);
+	return bitsf(fbits(y) ^ sign);
+}
+DEV float mf_cos(float x)
+{
+	int32_t j;
+	float r = mf_reduce(f_abs(x), j);
+	j -= 2;
+	uint32_t sign = (uint32_t)(~j & 4) << 29;
+	float ys, yc;
+	mf_polys(r, ys, yc);
+	float y = ((j & 2) == 0) ? (0.0f + ys) : (yc + 0.0f);
+	return bitsf(fbits(y) ^ sign);
+}
+DEV float f_log(float a) { return (a > 0.0f) ? mf_log(a) : 0.0f; }                            // RT.cpp:1919
+DEV float f_pow(float a, float b) { return (a > 1.e-8f) ? mf_exp(mf_log(a) * b) : 0.0f; }     // RT.cpp:1936, SSE.h:1941-1948
+
+DEV void f_sincos(float a, float& s_out, float& c_out)                                        // SSE.h:3118-3172
+{
+	const float PI = 3.1415926535897932f;
+	float q = a * (1.0f / (2.0f * PI));
+	q = (float)cvtr(q);
+	float x = a - ((2.0f * PI) * q);
+	const uint32_t sgn = fbits(x) & 0x80000000u;
+	const float c = bitsf(fbits(PI) | sgn);
+	const float rflx = c - x;
+	const bool comp = f_abs(x) > (0.5f * PI);
+	x = comp ? rflx : x;
+	const float sign = comp ? -1.0f : 1.0f;
+	const float x2 = x * x;
+	float S = -2.3889859e-08f;
+	S = f_mad(x2, S, 2.7525562e-06f);
+	S = f_mad(x2, S, -0.00019840874f);
+	S = f_mad(x2, S, 0.0083333310f);
+	S = f_mad(x2, S, -0.16666667f);
+	S = f_mad(x2, S, 1.0f);
+	s_out = S * x;
+	float C = -2.6051615e-07f;
+	C = f_mad(x2, C, 2.4760495e-05f);
+	C = f_mad(x2, C, -0.0013888378f);
+	C = f_mad(x2, C, 0.041666638f);
+	C = f_mad(x2, C, -0.5f);
+	C = f_mad(x2, C, 1.0f);
+	c_out = C * sign;
+}
+
+DEV int32_t i_div(int32_t n, int32_t d)                                                        // RT.cpp:958-973
+{
+	if (d == 0) return 0;
+	if (d == -1 && n == (int32_t)0x80000000) return 0x7FFFFFFF;
+	return n / d;
+}
+DEV int32_t i_min(int32_t a, int32_t b) { return a < b ? a : b; }
+DEV int32_t i_max(int32_t a, int32_t b) { return a > b ? a : b; }
+DEV int32_t i_abs(int32_t a) { return a < 0 ? (int32_t)(0u - (uint32_t)a) : a; }             // _mm_abs_epi32: INT_MIN stays
+DEV uint32_t i_shl(uint32_t a, uint32_t b) { return a << (b & 31u); }                         // VectorVMPlatformGeneric.h:76-89
+DEV uint32_t i_shr(uint32_t a, uint32_t b) { return a >> (b & 31u); }                         // VectorVMPlatformGeneric.h:61-74
+
+// half <-> float, GenericPlatformMath.h:34-61 and :68-123 (round to nearest even)
+DEV float load_half(uint32_t h)
+{
+	const uint32_t shifted_exp = 0x7c00u << 13;
+	uint32_t u = (h & 0x7fffu) << 13;
+	const uint32_t e = shifted_exp & u;
+	u += (127u - 15u) << 23;
+	if (e == shifted_exp) u += (128u - 16u) << 23;
+	else if (e == 0) { u += 1u << 23; u = fbits(bitsf(u) - bitsf(113u << 23)); }
+	u |= (h & 0x8000u) << 16;
+	return bitsf(u);
+}
+DEV uint32_t store_half(float x)
+{
+	uint32_t u = fbits(x);
+	const uint32_t f32infty = 255u << 23, f16max = (127u + 16u) << 23, dm = ((127u - 15u) + (23u - 10u) + 1u) << 23;
+	const uint32_t sign = u & 0x80000000u;
+	uint32_t o;
+	u ^= sign;
+	if (u >= f16max) o = (u > f32infty) ? 0x7e00u : 0x7c00u;
+	else if (u < (113u << 23)) { o = (fbits(bitsf(u) + bitsf(dm)) - dm) & 0xFFFFu; }
+	else { const uint32_t odd = (u >> 13) & 1u; u += ((uint32_t)(15 - 127) << 23) + 0xfffu; u += odd; o = (u >> 13) & 0xFFFFu; }
+	return o | (sign >> 16);
+}
+
+// counter-based generator keyed by (seed, instance, ordinal of the random op); value mapping RT.cpp:953-956
+DEV uint32_t rand_u32(uint32_t seed_lo, uint32_t seed_hi, uint32_t instance, uint32_t ordinal)
+{
+	uint32_t h = instance * 0x9E3779B1u + seed_lo;
+	h ^= ordinal * 0x85EBCA77u + seed_hi;
+	h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+	h += ordinal * 0x27D4EB2Fu + instance;
+	h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+	return h;
+}
+DEV float rand01(uint32_t r) { return bitsf((r >> 9) | 0x3F800000u) - 1.0f; }
+
+// ---- noise built-ins ---------------------------------------------------------------------------------
+DEV float p_grad3(uint32_t h, float x, float y, float z)                                      // UnrealMath.cpp:3577-3602
+{
+	switch (h & 15u) {
+	case 0: return x + z;   case 1: return x + y;   case 2: return y + z;   case 3: return -x + y;
+	case 4: return -x + z;  case 5: return -x - y;  case 6: return -y + z;  case 7: return x - y;
+	case 8: return x - z;   case 9: return y - z;   case 10: return -x - z; case 11: return -y - z;
+	case 12: return x + y;  case 13: return -x + y; case 14: return -y + z; default: return -y - z;
+	}
+}
+DEV float p_smooth(float x) { return x * x * x * (x * (x * 6.0f - 15.0f) + 10.0f); }          // UnrealMath.cpp:3605-3608
+DEV float p_lerp(float a, float b, float t) { return a + t * (b - a); }                       // UnrealMathUtility.h:1187-1190
+
+__device__ __noinline__ float perlin3(const uint8_t* P, float px, float py, float pz)                             // UnrealMath.cpp:3658-3699
+{
+	const float xf = floorf(px), yf = floorf(py), zf = floorf(pz);
+	const int xi = (int)xf & 255, yi = (int)yf & 255, zi = (int)zf & 255;
+	const float x = px - xf, y = py - yf, z = pz - zf;
+	const float xm = x - 1.0f, ym = y - 1.0f, zm = z - 1.0f;
+	const int a = P[xi] + yi, aa = P[a] + zi, ab = P[a + 1] + zi;
+	const int b = P[xi + 1] + yi, ba = P[b] + zi, bb = P[b + 1] + zi;
+	const float u = p_smooth(x), v = p_smooth(y), w = p_smooth(z);
+	const float r = 0.97f * p_lerp(
+		p_lerp(p_lerp(p_grad3(P[aa], x, y, z), p_grad3(P[ba], xm, y, z), u),
+		       p_lerp(p_grad3(P[ab], x, ym, z), p_grad3(P[bb], xm, ym, z), u), v),
+		p_lerp(p_lerp(p_grad3(P[aa + 1], x, y, zm), p_grad3(P[ba + 1], xm, y, zm), u),
+		       p_lerp(p_grad3(P[ab + 1], x, ym, zm), p_grad3(P[bb + 1], xm, ym, zm), u), v), w);
+	return r < -1.0f ? -1.0f : (r < 1.0f ? r : 1.0f);
+}
+
+// curl of three Perlin potentials at fixed offsets, central differences with step 1/64
+__device__ __noinline__ void curl_noise3(const uint8_t* P, float x, float y, float z, float& ox, float& oy, float& oz)
+{
+	const float e = 0.015625f, inv2e = 32.0f;
+	const float o1x = 31.416f, o1y = -47.853f, o1z = 12.793f;
+	const float o2x = -233.145f, o2y = -113.408f, o2z = -185.31f;
+	const float p2_dy = perlin3(P, x + o2x, (y + e) + o2y, z + o2z) - perlin3(P, x + o2x, (y - e) + o2y, z + o2z);
+	const float p1_dz = perlin3(P, x + o1x, y + o1y, (z + e) + o1z) - perlin3(P, x + o1x, y + o1y, (z - e) + o1z);
+	const float p0_dz = perlin3(P, x, y, z + e) - perlin3(P, x, y, z - e);
+	const float p2_dx = perlin3(P, (x + e) + o2x, y + o2y, z + o2z) - perlin3(P, (x - e) + o2x, y + o2y, z + o2z);
+	const float p1_dx = perlin3(P, (x + e) + o1x, y + o1y, z + o1z) - perlin3(P, (x - e) + o1x, y + o1y, z + o1z);
+	const float p0_dy = perlin3(P, x, y + e, z) - perlin3(P, x, y - e, z);
+	ox = (p2_dy - p1_dz) * inv2e;
+	oy = (p0_dz - p2_dx) * inv2e;
+	oz = (p1_dx - p0_dy) * inv2e;
+}
+
+// ---- wave helpers --------------------------------------------------------------------------------------
+DEV uint32_t lanes_below(u64 m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
+DEV uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+	return v;
+}
+
+// ---- per-tile interpreter state ----------------------------------------------------------------------
+#define RVEC typename RegTraits<V>::vec
+#define CREGS RVEC R0, RVEC R1, RVEC R2, RVEC R3
+#define RARGS R0, R1, R2, R3
+template <int V>
+struct Tile {
+	uint32_t keep;          // bit k: instance k of this lane survives
+	uint32_t rank;          // tile-local output rank of the lane's first survivor
+	uint32_t block_total;   // survivors in the tile
+	uint32_t out_base;      // exclusive prefix over the Exec's previous tiles
+	uint32_t acquired_ds;   // dataset the acquireindex named, or ~0u
+};
+
+struct Ctx {
+	const uint32_t* consts;
+	const uint64_t* in_ptrs;
+	const uint64_t* out_ptrs;
+	const uint8_t*  perlin_lds;
+	float*          spill;        // LDS, [slot][thread] (V floats per thread and slot)
+	uint32_t tid;
+	uint32_t inst0;               // index (within the Exec) of the lane's first instance
+	uint32_t num_instances;
+	bool     full;                // the whole tile is inside [0, num_instances)
+};
+
+// Register access.  The index is wave-uniform.  The VGPR vectors are read and written unconditionally (a branch around an
+// element insert makes the compiler keep two copies of the whole vector); a write to a register that lives in LDS puts
+// the old value back into the element it aliases.
+template <int V, bool SPILL> DEV void reg_read(CREGS, const Ctx& c, uint32_t idx, float (&out)[V])
+{
+	constexpr uint32_t RV = RegTraits<V>::RV;
+	const uint32_t i = idx & (RV - 1);
+	out[0] = vget(R0, i);
+	if constexpr (V == 4) { out[1] = vget(R1, i); out[2] = vget(R2, i); out[3] = vget(R3, i); }
+	if constexpr (SPILL) {
+		if (idx >= RV) {
+			const float* p = c.spill + ((idx - RV) * VVM_BLOCK_THREADS + c.tid) * V;
+			if constexpr (V == 4) { const f4a v = *(const f4a*)p; out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w; }
+			else out[0] = p[0];
+		}
+	}
+}
+template <int V, bool SPILL> DEV RVEC reg_put(RVEC Rk, bool enable, uint32_t idx, float x)
+{
+	constexpr uint32_t RV = RegTraits<V>::RV;
+	const uint32_t i = idx & (RV - 1);
+	if constexpr (SPILL) enable = enable && (idx < RV);
+	return vset(Rk, i, enable ? x : vget(Rk, i));
+}
+template <int V, bool SPILL> DEV void reg_spill(const Ctx& c, bool enable, uint32_t idx, const float (&in)[V])
+{
+	constexpr uint32_t RV = RegTraits<V>::RV;
+	if constexpr (SPILL) {
+		if (enable && idx >= RV) {
+			float* p = c.spill + ((idx - RV) * VVM_BLOCK_THREADS + c.tid) * V;
+			if constexpr (V == 4) { f4a v; v.x = in[0]; v.y = in[1]; v.z = in[2]; v.w = in[3]; *(f4a*)p = v; }
+			else p[0] = in[0];
+		}
+	}
+}
+// statement: if `enable` (wave-uniform), write the V values of `arr` to virtual register `idx`.  The element insert itself is
+// unconditional (a disabled write re-inserts the old value) so that no control flow ever merges two versions of a vector.
+#define REG_WRITE_IF(enable, idx, arr) do { \
+		const bool en_ = (enable); const uint32_t idx_ = (idx); \
+		R0 = reg_put<V, SPILL>(R0, en_, idx_, (arr)[0]); \
+		if constexpr (V == 4) { R1 = reg_put<V, SPILL>(R1, en_, idx_, (arr)[1]); R2 = reg_put<V, SPILL>(R2, en_, idx_, (arr)[2]); R3 = reg_put<V, SPILL>(R3, en_, idx_, (arr)[3]); } \
+		reg_spill<V, SPILL>(c, en_, idx_, (arr)); \
+	} while (0)
+#define REG_WRITE(idx, arr) REG_WRITE_IF(true, idx, arr)
+
+template <int V> DEV void load_stream32(const Ctx& c, uint64_t base, float (&out)[V])
+{
+	const float* p = (const float*)base + c.inst0;
+	if (c.full) {
+		if constexpr (V == 4) { const f4u v = *(const f4u*)p; out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w; }
+		else out[0] = p[0];
+	} else {
+#pragma unroll
+		for (int k = 0; k < V; ++k) out[k] = (c.inst0 + k < c.num_instances) ? p[k] : 0.0f;
+	}
+}
+template <int V> DEV void load_stream16(const Ctx& c, uint64_t base, uint32_t (&out)[V])
+{
+	const uint16_t* p = (const uint16_t*)base + c.inst0;
+	if (c.full) {
+		if constexpr (V == 4) { const h4u v = *(const h4u*)p; out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w; }
+		else out[0] = p[0];
+	} else {
+#pragma unroll
+		for (int k = 0; k < V; ++k) out[k] = (c.inst0 + k < c.num_instances) ? p[k] : 0u;
+	}
+}
+
+// operand fetch; the class and index are wave-uniform, so every branch below is a scalar branch
+template <int V, bool SPILL> DEV void fetch(CREGS, const Ctx& c, uint32_t o, float (&out)[V])
+{
+	const uint32_t cls = VVM_OPND_CLS(o), idx = VVM_OPND_IDX(o);
+	if (cls == VVM_OPC_VREG) {
+		reg_read<V, SPILL>(RARGS, c, idx, out);
+	} else if (cls == VVM_OPC_CONST) {
+		const float v = bitsf(sload32(c.consts, idx));
+#pragma unroll
+		for (int k = 0; k < V; ++k) out[k] = v;
+	} else if (cls == VVM_OPC_INPUT) {
+		load_stream32<V>(c, sload64(c.in_ptrs, idx), out);
+	} else if (cls == VVM_OPC_NOADV) {
+		const float v = bitsf(sload32((const void*)sload64(c.in_ptrs, idx), 0));
+#pragma unroll
+		for (int k = 0; k < V; ++k) out[k] = v;
+	} else if (cls == VVM_OPC_HALF) {   // raw half bits, zero-extended
+		uint32_t h[V];
+		load_stream16<V>(c, sload64(c.in_ptrs, idx), h);
+#pragma unroll
+		for (int k = 0; k < V; ++k) out[k] = bitsf(h[k]);
+	} else if (cls == VVM_OPC_NOADV_HALF) {   // converted once, like VectorVMRuntime.cpp:388-394
+		const float v = load_half(*(const uint16_t*)sload64(c.in_ptrs, idx));
+#pragma unroll
+		for (int k = 0; k < V; ++k) out[k] = v;
+	} else {
+#pragma unroll
+		for (int k = 0; k < V; ++k) out[k] = 0.0f;
+	}
+}
+
+// decoupled look-back over the Exec's tile words; called by wave 0 only.  Returns the exclusive prefix.
+DEV uint32_t look_back(gu64* status, uint32_t tile, uint32_t tag, uint32_t lane, gu32* error_word)
+{
+	uint32_t sum = 0;
+	int32_t first = (int32_t)tile - 1;
+	for (;;) {
+		const int32_t mine = first - (int32_t)lane;
+		u64 w = 0;
+		uint32_t spins = 0;
+		for (;;) {
+			bool ok = true;
+			if (mine >= 0) {
+				w = __hip_atomic_load(status + mine, RLX_AGENT);
+				ok = (uint32_t)(w >> 34) == tag;
+			} else {
+				w = ((u64)tag << 34) | (VVM_LB_INCLUSIVE << 32);
+			}
+			if (__all(ok)) break;
+			if (++spins > (1u << 22)) {     // a predecessor never published: give up rather than hang the device
+				if (lane == 0) __hip_atomic_store(error_word, 1u, RLX_AGENT);
+				return sum;
+			}
+			__builtin_amdgcn_s_sleep(2);
+		}
+		const uint32_t val = (uint32_t)w;
+		const bool inclusive = ((w >> 32) & 3ull) == VVM_LB_INCLUSIVE;
+		const u64 inc_mask = __ballot(inclusive);
+		if (inc_mask != 0) {
+			const uint32_t nearest = (uint32_t)__builtin_ctzll(inc_mask);
+			sum += wave_sum(lane <= nearest ? val : 0u);
+			return sum;
+		}
+		sum += wave_sum(val);
+		first -= 64;
+	}
+}
+
+struct KernelEnv {
+	const VvmExecDesc* descs;
+	uint32_t num_execs;
+	uint32_t total_tiles;
+	VvmLaunchState* ls;
+	uint32_t lds_spill_slots;
+	uint32_t debug_skip;     // bring-up aid (VVM_DEBUG_SKIP): bit 0 tiles, 1 stream loads, 2 look-back words, 3 stream stores, 4 counts
+};
+
+// ------------------------------------------------------------------------------------------------------
+template <int V, bool SPILL, bool FULL>
+DEV void run_tile(const VvmExecDesc& d, const Ctx& c, uint32_t* lds_ctrl, uint32_t tile_local, uint32_t tag, gu32* error_word, uint32_t dbg)
+{
+	Tile<V> t;
+	RVEC R0 = 0.0f, R1 = 0.0f, R2 = 0.0f, R3 = 0.0f;
+	t.keep = 0; t.rank = 0; t.block_total = 0; t.out_base = 0; t.acquired_ds = ~0u;
+	const uint32_t lane = c.tid & 63u, wave = c.tid >> 6;
+	const VvmIns* prog = d.prog;
+
+	// Prologue: the program starts with its VVM_DOP_LOADN instructions.  They run in a loop of their own so that the main
+	// loop below has exactly one place that inserts into the register vectors (with two, the compiler keeps a second copy
+	// of the whole register file alive across the loop).
+	uint32_t pc0 = 0;
+	for (;; ++pc0) {
+		VvmIns ins;
+		ins.w0 = sload32(prog, pc0 * 4 + 0);
+		if ((ins.w0 & 0xFFu) != VVM_DOP_LOADN) break;
+		ins.w1 = sload32(prog, pc0 * 4 + 1); ins.w2 = sload32(prog, pc0 * 4 + 2); ins.w3 = sload32(prog, pc0 * 4 + 3);
+		const uint32_t aux = (ins.w0 >> 16) & 0xFFu, aux2 = ins.w0 >> 24;
+		{
+			// aux = count (1..8), aux2 = first destination register; eight 12-bit stream indices in w1..w3
+			float st[8][V];
+			const u64 lo = (u64)ins.w1 | ((u64)ins.w2 << 32);
+#pragma unroll
+			for (int j = 0; j < 8; ++j) {
+				if ((uint32_t)j < aux) {
+					const uint32_t idx = (j < 5) ? (uint32_t)(lo >> (12 * j)) & 0xFFFu
+					                    : (j == 5) ? (uint32_t)((lo >> 60) | ((u64)(ins.w3 & 0xFFu) << 4)) & 0xFFFu
+					                               : (ins.w3 >> (8 + 12 * (j - 6))) & 0xFFFu;
+					if (!(dbg & 2u)) load_stream32<V>(c, sload64(c.in_ptrs, idx), st[j]);
+					else { _Pragma("unroll") for (int k = 0; k < V; ++k) st[j][k] = 0.0f; }
+				}
+			}
+#pragma unroll
+			for (int j = 0; j < 8; ++j)
+				REG_WRITE_IF((uint32_t)j < aux, aux2 + j, st[j]);
+		}
+
+	}
+
+	for (uint32_t pc = pc0;; ++pc) {
+		VvmIns ins;
+		ins.w0 = sload32(prog, pc * 4 + 0); ins.w1 = sload32(prog, pc * 4 + 1);
+		ins.w2 = sload32(prog, pc * 4 + 2); ins.w3 = sload32(prog, pc * 4 + 3);
+		const uint32_t w0 = ins.w0;
+		const uint32_t op = w0 & 0xFFu, nin = (w0 >> 8) & 7u, nout = (w0 >> 11) & 3u, aux = (w0 >> 16) & 0xFFu, aux2 = w0 >> 24;
+		const uint32_t o0 = ins.w1 & 0xFFFFu, o1 = ins.w1 >> 16, o2 = ins.w2 & 0xFFFFu, o3 = ins.w2 >> 16, o4 = ins.w3 & 0xFFFFu, o5 = ins.w3 >> 16;
+		if (op == VVM_OP_done) break;
+
+		// results of this instruction, written to registers at the single write site at the end of the loop body; instructions
+		// that produce none leave the enables false (the write site then re-inserts the old element values)
+		float r[V], r2[V], r3[V];
+		bool w1 = false, w2 = false, w3 = false;
+		uint32_t d1 = 0, d2 = 0, d3 = 0;
+#pragma unroll
+		for (int k = 0; k < V; ++k) { r[k] = 0.0f; r2[k] = 0.0f; r3[k] = 0.0f; }
+		if (op == VVM_OP_acquireindex) {
+			// sign bit of the predicate = keep (VectorVMRuntime.cpp:838-841); instances past the end never survive (:846-857)
+			float p[V];
+			fetch<V, SPILL>(RARGS, c, o0, p);
+			uint32_t kb = 0;
+#pragma unroll
+			for (int k = 0; k < V; ++k)
+				if ((fbits(p[k]) >> 31) && (c.inst0 + k < c.num_instances)) kb |= 1u << k;
+			uint32_t below = 0, wave_total = 0;
+#pragma unroll
+			for (int k = 0; k < V; ++k) {
+				const u64 b = __ballot((kb >> k) & 1u);
+				below += lanes_below(b);
+				wave_total += (uint32_t)__popcll(b);
+			}
+			__syncthreads();
+			if (lane == 0) lds_ctrl[wave] = wave_total;
+			__syncthreads();
+			uint32_t wave_off = 0, total = 0;
+#pragma unroll
+			for (uint32_t w = 0; w < VVM_BLOCK_THREADS / 64; ++w) {
+				const uint32_t x = lds_ctrl[w];
+				wave_off += (w < wave) ? x : 0u;
+				total += x;
+			}
+			total = __builtin_amdgcn_readfirstlane(total);
+			t.keep = kb; t.rank = wave_off + below; t.block_total = total; t.acquired_ds = aux;
+			// publish this tile's count, then resolve the prefix over the previous tiles
+			gu64* status = (gu64*)d.status;
+			uint32_t base = 0;
+			if (tile_local == 0) {
+				if (c.tid == 0 && !(dbg & 4u)) __hip_atomic_store(status, ((u64)tag << 34) | (VVM_LB_INCLUSIVE << 32) | total, RLX_AGENT);
+			} else {
+				if (c.tid == 0) __hip_atomic_store(status + tile_local, ((u64)tag << 34) | (VVM_LB_AGGREGATE << 32) | total, RLX_AGENT);
+				if (wave == 0) {
+					const uint32_t ex = look_back(status, tile_local, tag, lane, error_word);
+					if (lane == 0) {
+						lds_ctrl[9] = ex;
+						__hip_atomic_store(status + tile_local, ((u64)tag << 34) | (VVM_LB_INCLUSIVE << 32) | (ex + total), RLX_AGENT);
+					}
+				}
+				__syncthreads();
+				base = __builtin_amdgcn_readfirstlane(lds_ctrl[9]);
+			}
+			t.out_base = base;
+			if (tile_local + 1 == d.num_tiles && c.tid == 0 && !(dbg & 16u)) d.counts[aux] = (int32_t)(base + total);
+		}
+
+		else if (op >= VVM_DOP_OUTPUT32 && op <= VVM_DOP_OUTPUT32_FROM16) {
+			// aux = pair count (1..3), aux2 = dataset; pairs (o0,o1) (o2,o3) (o4,o5) = (source, output serial index)
+			const bool mine = (aux2 == t.acquired_ds);
+			const uint32_t total = mine ? t.block_total : 0u;    // no acquireindex for this dataset: nothing is written (VectorVMRuntime.cpp:565, 769)
+			const uint32_t valid = min(c.num_instances - (c.inst0 - c.tid * V), (uint32_t)(VVM_BLOCK_THREADS * V));
+			const bool all_alive = (total == valid) && c.full;
+#pragma unroll
+			for (int j = 0; j < 3; ++j) {
+				if ((uint32_t)j >= aux) break;
+				const uint32_t src = (j == 0) ? o0 : (j == 1) ? o2 : o4;
+				const uint32_t dst = (j == 0) ? o1 : (j == 1) ? o3 : o5;
+				const uint64_t base = sload64(c.out_ptrs, dst);
+				if (base == 0 || total == 0 || (dbg & 8u)) continue;
+				float v[V];
+				fetch<V, SPILL>(RARGS, c, src, v);
+				if (op == VVM_DOP_OUTPUT32) {
+					float* p = (float*)base + t.out_base;
+					if (all_alive) {
+						if constexpr (V == 4) { f4u q; q.x = v[0]; q.y = v[1]; q.z = v[2]; q.w = v[3]; *(f4u*)(p + c.tid * 4) = q; }
+						else p[c.tid] = v[0];
+					} else {
+						uint32_t r = t.rank;
+#pragma unroll
+						for (int k = 0; k < V; ++k)
+							if ((t.keep >> k) & 1u) { p[r] = v[k]; ++r; }
+					}
+				} else {
+					uint32_t r = t.rank;
+					if (op == VVM_DOP_OUTPUT32_FROM16) {          // half bits -> float stream (the reference's handler is an empty stub, :573-577)
+						float* p = (float*)base + t.out_base;
+#pragma unroll
+						for (int k = 0; k < V; ++k)
+							if ((t.keep >> k) & 1u) { p[r] = load_half(fbits(v[k])); ++r; }
+					} else {
+						uint16_t* p = (uint16_t*)base + t.out_base;
+#pragma unroll
+						for (int k = 0; k < V; ++k)
+							if ((t.keep >> k) & 1u) {
+								p[r] = (uint16_t)((op == VVM_DOP_OUTPUT16) ? store_half(v[k]) : fbits(v[k]));
+								++r;
+							}
+					}
+				}
+			}
+		}
+
+		else {
+		// ---- ordinary ops: fetch nin operands, compute, write nout registers ----
+		// The instance index is made opaque once per instruction: otherwise everything the index-dependent cases derive from it
+		// (hash rounds of the random ops, int->float conversions of exec_index) is hoisted out of the interpreter loop and
+		// held in registers for the whole tile by every script, whether it has such an op or not.
+		uint32_t inst_i = c.inst0;
+		asm volatile("" : "+v"(inst_i));
+		float a[V], b[V], cc[V], dd[V], ee[V];
+		w1 = true; w2 = (nout == 2);
+		d1 = VVM_OPND_IDX(o5); d2 = VVM_OPND_IDX(o4);
+		if (nin > 0) fetch<V, SPILL>(RARGS, c, o0, a);
+		if (nin > 1) fetch<V, SPILL>(RARGS, c, o1, b);
+		if (nin > 2) fetch<V, SPILL>(RARGS, c, o2, cc);
+		if (nin > 3) fetch<V, SPILL>(RARGS, c, o3, dd);
+		if (nin > 4) fetch<V, SPILL>(RARGS, c, o4, ee);
+
+#define LANES for (int k = 0; k < V; ++k)
+#define A a[k]
+#define B b[k]
+#define C cc[k]
+#define D dd[k]
+#define E ee[k]
+#define IA ((int32_t)fbits(a[k]))
+#define IB ((int32_t)fbits(b[k]))
+#define IC ((int32_t)fbits(cc[k]))
+#define UA fbits(a[k])
+#define UB fbits(b[k])
+#define UC fbits(cc[k])
+#define SETF(expr) { _Pragma("unroll") LANES r[k] = (expr); } break
+#define SETI(expr) { _Pragma("unroll") LANES r[k] = bitsf((uint32_t)(expr)); } break
+#define SETM(expr) { _Pragma("unroll") LANES r[k] = mask(expr); } break
+		switch (op) {
+		case VVM_OP_add: SETF(A + B);
+		case VVM_OP_sub: SETF(A - B);
+		case VVM_OP_mul: SETF(A * B);
+		case VVM_OP_div: SETF(f_div(A, B));
+		case VVM_OP_mad: SETF(f_mad(A, B, C));
+		case VVM_OP_lerp: SETF(f_lerp(A, B, C));
+		case VVM_OP_rcp: SETF(f_rcp(A));
+		case VVM_OP_rsq: SETF(f_rsq(A));
+		case VVM_OP_sqrt: SETF(f_sqrtg(A));
+		case VVM_OP_neg: SETF(f_neg(A));
+		case VVM_OP_abs: SETF(f_abs(A));
+		case VVM_OP_exp: if constexpr (FULL) SETF(mf_exp(A));
+		case VVM_OP_exp2: if constexpr (FULL) SETF(lib_exp2(A));
+		case VVM_OP_log: if constexpr (FULL) SETF(f_log(A));
+		case VVM_OP_log2: if constexpr (FULL) SETF(lib_log2(A));
+		case VVM_OP_sin: if constexpr (FULL) SETF(mf_sin(A));
+		case VVM_OP_cos: if constexpr (FULL) SETF(mf_cos(A));
+		case VVM_OP_tan: if constexpr (FULL) SETF(lib_tan(A));
+		case VVM_OP_asin: if constexpr (FULL) SETF(f_asin(A));
+		case VVM_OP_acos: if constexpr (FULL) SETF(f_acos(A));
+		case VVM_OP_atan: if constexpr (FULL) SETF(lib_atan(A));
+		case VVM_OP_atan2: if constexpr (FULL) SETF(ue_atan2(A, B));
+		case VVM_OP_ceil: SETF(ceilf(A));
+		case VVM_OP_floor: SETF(floorf(A));
+		case VVM_OP_fmod: if constexpr (FULL) SETF(f_fmod(A, B));
+		case VVM_OP_frac: SETF(f_frac(A));
+		case VVM_OP_trunc: SETF(truncf(A));
+		case VVM_OP_clamp: SETF(f_clamp(A, B, C));
+		case VVM_OP_min: SETF(f_min(A, B));
+		case VVM_OP_max: SETF(f_max(A, B));
+		case VVM_OP_pow: if constexpr (FULL) SETF(f_pow(A, B));
+		case VVM_OP_round: SETF(rintf(A));                         // SSE.h:2819-2822 (nearest even)
+		case VVM_OP_sign: SETF(f_sign(A));
+		case VVM_OP_step: SETF(f_step(B - A));                     // RT.cpp:1939
+		case VVM_OP_cmplt: SETM(A < B);
+		case VVM_OP_cmple: SETM(A <= B);
+		case VVM_OP_cmpgt: SETM(A > B);
+		case VVM_OP_cmpge: SETM(A >= B);
+		case VVM_OP_cmpeq: SETM(A == B);
+		case VVM_OP_cmpneq: SETM(A != B);
+		case VVM_OP_select: SETF(f_sel(A, B, C));
+		case VVM_OP_addi: SETI(UA + UB);
+		case VVM_OP_subi: SETI(UA - UB);
+		case VVM_OP_muli: SETI(UA * UB);
+		case VVM_OP_divi: SETI(i_div(IA, IB));
+		case VVM_OP_clampi: SETI(i_min(i_max(IA, IB), IC));
+		case VVM_OP_mini: SETI(i_min(IA, IB));
+		case VVM_OP_maxi: SETI(i_max(IA, IB));
+		case VVM_OP_absi: SETI(i_abs(IA));
+		case VVM_OP_negi: SETI(0u - UA);
+		case VVM_OP_signi: SETI(IA >= 0 ? 1 : -1);
+		case VVM_OP_cmplti: SETM(IA < IB);
+		case VVM_OP_cmplei: SETM(IA <= IB);
+		case VVM_OP_cmpgti: SETM(IA > IB);
+		case VVM_OP_cmpgei: SETM(IA >= IB);
+		case VVM_OP_cmpeqi: SETM(IA == IB);
+		case VVM_OP_cmpneqi: SETM(IA != IB);
+		case VVM_OP_bit_and: case VVM_OP_logic_and: SETI(UA & UB);
+		case VVM_OP_bit_or: case VVM_OP_logic_or: SETI(UA | UB);
+		case VVM_OP_bit_xor: case VVM_OP_logic_xor: SETI(UA ^ UB);
+		case VVM_OP_bit_not: case VVM_OP_logic_not: SETI(~UA);
+		case VVM_OP_bit_lshift: SETI(i_shl(UA, UB));
+		case VVM_OP_bit_rshift: SETI(i_shr(UA, UB));
+		case VVM_OP_f2i: SETI(cvtt(A));
+		case VVM_OP_i2f: SETF(i2f(IA));
+		case VVM_OP_f2b: SETM(A > 0.0f);
+		case VVM_OP_b2f: SETF(f_sel(A, 1.0f, 0.0f));
+		case VVM_OP_i2b: SETM(IA > 0);
+		case VVM_OP_b2i: case VVM_OP_b2i_2x: SETI(UA & 1u);
+		case VVM_OP_mul_2x: SETF(A * B);
+		// merged ops, VectorVMRuntime.cpp:1999-2074
+		case VVM_OP_cmplt_select: SETF(f_sel(mask(A < B), C, D));
+		case VVM_OP_cmple_select: SETF(f_sel(mask(A <= B), C, D));
+		case VVM_OP_cmpeq_select: SETF(f_sel(mask(A == B), C, D));
+		case VVM_OP_cmplti_select: SETF(f_sel(mask(IA < IB), C, D));
+		case VVM_OP_cmplei_select: SETF(f_sel(mask(IA <= IB), C, D));
+		case VVM_OP_cmpeqi_select: SETF(f_sel(mask(IA == IB), C, D));
+		case VVM_OP_cmplt_logic_and: SETI((A < B ? ~0u : 0u) & UC);
+		case VVM_OP_cmple_logic_and: SETI((A <= B ? ~0u : 0u) & UC);
+		case VVM_OP_cmpgt_logic_and: SETI((A > B ? ~0u : 0u) & UC);
+		case VVM_OP_cmpge_logic_and: SETI((A >= B ? ~0u : 0u) & UC);
+		case VVM_OP_cmpeq_logic_and: SETI((A == B ? ~0u : 0u) & UC);
+		case VVM_OP_cmpne_logic_and: SETI((A != B ? ~0u : 0u) & UC);
+		case VVM_OP_cmplti_logic_and: SETI((IA < IB ? ~0u : 0u) & UC);
+		case VVM_OP_cmplei_logic_and: SETI((IA <= IB ? ~0u : 0u) & UC);
+		case VVM_OP_cmpgti_logic_and: SETI((IA > IB ? ~0u : 0u) & UC);
+		case VVM_OP_cmpgei_logic_and: SETI((IA >= IB ? ~0u : 0u) & UC);
+		case VVM_OP_cmpeqi_logic_and: SETI((IA == IB ? ~0u : 0u) & UC);
+		case VVM_OP_cmpnei_logic_and: SETI((IA != IB ? ~0u : 0u) & UC);
+		case VVM_OP_cmplt_logic_or: SETI((A < B ? ~0u : 0u) | UC);
+		case VVM_OP_cmple_logic_or: SETI((A <= B ? ~0u : 0u) | UC);
+		case VVM_OP_cmpgt_logic_or: SETI((A > B ? ~0u : 0u) | UC);
+		case VVM_OP_cmpge_logic_or: SETI((A >= B ? ~0u : 0u) | UC);
+		case VVM_OP_cmpeq_logic_or: SETI((A == B ? ~0u : 0u) | UC);
+		case VVM_OP_cmpne_logic_or: SETI((A != B ? ~0u : 0u) | UC);
+		case VVM_OP_cmplti_logic_or: SETI((IA < IB ? ~0u : 0u) | UC);
+		case VVM_OP_cmplei_logic_or: SETI((IA <= IB ? ~0u : 0u) | UC);
+		case VVM_OP_cmpgti_logic_or: SETI((IA > IB ? ~0u : 0u) | UC);
+		case VVM_OP_cmpgei_logic_or: SETI((IA >= IB ? ~0u : 0u) | UC);
+		case VVM_OP_cmpeqi_logic_or: SETI((IA == IB ? ~0u : 0u) | UC);
+		case VVM_OP_cmpnei_logic_or: SETI((IA != IB ? ~0u : 0u) | UC);
+		case VVM_OP_mad_add: SETF(f_mad(A, B, C) + D);
+		case VVM_OP_mad_sub0: SETF(f_mad(A, B, C) - D);
+		case VVM_OP_mad_sub1: SETF(D - f_mad(A, B, C));
+		case VVM_OP_mad_mul: SETF(f_mad(A, B, C) * D);
+		case VVM_OP_mad_sqrt: SETF(__fsqrt_rn(f_mad(A, B, C)));      // unguarded, RT.cpp:2033
+		case VVM_OP_mad_mad0: SETF(f_mad(D, E, f_mad(A, B, C)));
+		case VVM_OP_mad_mad1: SETF(f_mad(f_mad(A, B, C), D, E));
+		case VVM_OP_mul_mad0: SETF(f_mad(A * B, C, D));
+		case VVM_OP_mul_mad1: SETF(f_mad(C, D, A * B));
+		case VVM_OP_mul_add: SETF((A * B) + C);
+		case VVM_OP_mul_sub0: SETF((A * B) - C);
+		case VVM_OP_mul_sub1: SETF(C - (A * B));
+		case VVM_OP_mul_mul: SETF((A * B) * C);
+		case VVM_OP_mul_max: SETF(f_max(A * B, C));
+		case VVM_OP_add_mad1: SETF(f_mad(C, D, A + B));
+		case VVM_OP_add_add: SETF((A + B) + C);
+		case VVM_OP_sub_cmplt1: SETM(C < (A - B));
+		case VVM_OP_sub_neg: SETF(f_neg(A - B));
+		case VVM_OP_sub_mul: SETF((A - B) * C);
+		case VVM_OP_div_mad0: SETF(f_mad(f_div(A, B), C, D));
+		case VVM_OP_div_f2i: SETI(cvtt(f_div(A, B)));
+		case VVM_OP_div_mul: SETF(f_div(A, B) * C);
+		case VVM_OP_muli_addi: SETI(UA * UB + UC);
+		case VVM_OP_addi_bit_rshift: SETI(i_shr(UA + UB, UC));
+		case VVM_OP_addi_muli: SETI((UA + UB) * UC);
+		case VVM_OP_i2f_div0: SETF(f_div(i2f(IA), B));
+		case VVM_OP_i2f_div1: SETF(f_div(B, i2f(IA)));
+		case VVM_OP_i2f_mul: SETF(i2f(IA) * B);
+		case VVM_OP_i2f_mad0: SETF(f_mad(i2f(IA), B, C));
+		case VVM_OP_i2f_mad1: SETF(f_mad(A, B, i2f(IC)));
+		case VVM_OP_f2i_select1: SETI((UA & (uint32_t)cvtt(B)) | (~UA & UC));
+		case VVM_OP_f2i_maxi: SETI(i_max(cvtt(A), IB));
+		case VVM_OP_f2i_addi: SETI((uint32_t)cvtt(A) + UB);
+		case VVM_OP_fmod_add: if constexpr (FULL) SETF(f_fmod(A, B) + C);
+		case VVM_OP_bit_and_i2f: SETF(i2f((int32_t)(UA & UB)));
+		case VVM_OP_bit_rshift_bit_and: SETI(i_shr(UA, UB) & UC);
+		case VVM_OP_neg_cmplt: SETM(f_neg(A) < B);
+		case VVM_OP_bit_or_muli: SETI((UA | UB) * UC);
+		case VVM_OP_bit_lshift_bit_or: SETI(i_shl(UA, UB) | UC);
+		case VVM_OP_max_f2i: SETI(cvtt(f_max(A, B)));
+		case VVM_OP_select_mul: SETF(f_sel(A, B, C) * D);
+		case VVM_OP_select_add: SETF(f_sel(A, B, C) + D);
+		case VVM_OP_sin_cos: if constexpr (FULL) { _Pragma("unroll") LANES f_sincos(A, r[k], r2[k]); } break;
+		case VVM_OP_half_to_float: SETF(load_half(UA));             // RT.cpp:1113-1127
+		case VVM_OP_exec_index: SETI((uint32_t)d.exec_index_base + inst_i + k);                       // RT.cpp:880-900
+		case VVM_OP_exec_indexf: SETF(i2f((int32_t)((uint32_t)d.exec_index_base + inst_i + k)));      // RT.cpp:902-923
+		case VVM_OP_exec_index_addi: SETI((uint32_t)d.exec_index_base + inst_i + k + UA);             // RT.cpp:925-951
+		// aux2 = ordinal of the random op within the script
+		case VVM_OP_random: SETF(rand01(rand_u32(d.rand_seed_lo, d.rand_seed_hi, (uint32_t)d.rand_instance_base + inst_i + k, aux2)) * A);
+		case VVM_OP_randomi: SETI(cvtt(rand01(rand_u32(d.rand_seed_lo, d.rand_seed_hi, (uint32_t)d.rand_instance_base + inst_i + k, aux2)) * i2f(IA)));
+		case VVM_OP_random_add: SETF(rand01(rand_u32(d.rand_seed_lo, d.rand_seed_hi, (uint32_t)d.rand_instance_base + inst_i + k, aux2)) * A + B);
+		case VVM_OP_random_2x: { _Pragma("unroll") LANES {
+			r[k] = rand01(rand_u32(d.rand_seed_lo, d.rand_seed_hi, (uint32_t)d.rand_instance_base + inst_i + k, aux2)) * A;
+			r2[k] = rand01(rand_u32(d.rand_seed_lo, d.rand_seed_hi, (uint32_t)d.rand_instance_base + inst_i + k, aux2 + 1u)) * A; } } break;
+		case VVM_OP_external_func_call:
+			// aux = built-in id; operands in order: inputs o0..o2, then outputs o3, o4, o5 (VectorVMRuntime.cpp:1450-1464);
+			// an output the script does not use is the dummy register class
+			if constexpr (FULL) {
+				if (aux == VVM_EXTFN_PERLIN3) {
+					_Pragma("unroll") LANES r[k] = perlin3(c.perlin_lds, A, B, C);
+					w1 = VVM_OPND_CLS(o3) == VVM_OPC_VREG; d1 = VVM_OPND_IDX(o3); w2 = false;
+				} else if (aux == VVM_EXTFN_CURL_NOISE3) {
+					_Pragma("unroll") LANES curl_noise3(c.perlin_lds, A, B, C, r[k], r2[k], r3[k]);
+					w1 = VVM_OPND_CLS(o3) == VVM_OPC_VREG; d1 = VVM_OPND_IDX(o3);
+					w2 = VVM_OPND_CLS(o4) == VVM_OPC_VREG; d2 = VVM_OPND_IDX(o4);
+					w3 = VVM_OPND_CLS(o5) == VVM_OPC_VREG; d3 = VVM_OPND_IDX(o5);
+				} else { w1 = false; w2 = false; }
+			}
+			break;
+		default: { _Pragma("unroll") LANES r[k] = 0.0f; } break;
+		}
+#undef LANES
+#undef A
+#undef B
+#undef C
+#undef D
+#undef E
+#undef IA
+#undef IB
+#undef IC
+#undef UA
+#undef UB
+#undef UC
+#undef SETF
+#undef SETI
+#undef SETM
+		if (nout == 2) {
+			if (op == VVM_OP_mul_2x || op == VVM_OP_b2i_2x) {
+#pragma unroll
+				for (int k = 0; k < V; ++k) r2[k] = r[k];
+			}
+		}
+		}
+		// the one place where the main loop writes registers
+		if constexpr (FULL) REG_WRITE_IF(w3, d3, r3);
+		REG_WRITE_IF(w2, d2, r2);
+		REG_WRITE_IF(w1, d1, r);
+	}
+}
+
+template <int V, bool SPILL, bool FULL>
+__global__ void __launch_bounds__(VVM_BLOCK_THREADS, (FULL ? 2 : (V == 4 ? 3 : 8))) vvm_exec_kernel(KernelEnv env)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+	uint32_t* lds_ctrl = (uint32_t*)lds;
+	uint8_t* lds_perlin = lds + LDS_PERLIN_OFF;
+	float* lds_spill = (float*)(lds + LDS_SPILL_OFF);
+	const uint32_t tid = threadIdx.x;
+	gu32* ticket_word = (gu32*)&env.ls->ticket;
+	gu32* error_word = (gu32*)&env.ls->pad;
+	const uint32_t tag = SCALAR(__hip_atomic_load((gu32*)&env.ls->epoch, RLX_AGENT)) & 0x3FFFFFFFu;
+	bool perlin_ready = false;
+
+	for (;;) {
+		__syncthreads();
+		if (tid == 0) lds_ctrl[8] = __hip_atomic_fetch_add(ticket_word, 1u, RLX_AGENT);
+		__syncthreads();
+		const uint32_t ticket = __builtin_amdgcn_readfirstlane(lds_ctrl[8]);
+		if (ticket >= env.total_tiles) break;
+
+		// which Exec owns this ticket: the last descriptor with first_tile <= ticket
+		uint32_t e = 0;
+		if (env.num_execs > 1) {
+			uint32_t lo = 0, hi = env.num_execs;
+			while (hi - lo > 1) {
+				const uint32_t mid = (lo + hi) >> 1;
+				if (sload32(env.descs + mid, offsetof(VvmExecDesc, first_tile) / 4) <= ticket) lo = mid; else hi = mid;
+			}
+			e = lo;
+		}
+		VvmExecDesc d;
+		{
+			const void* dp = env.descs + e;
+			d.prog = (const VvmIns*)sload64(dp, offsetof(VvmExecDesc, prog) / 8);
+			d.consts = (const uint32_t*)sload64(dp, offsetof(VvmExecDesc, consts) / 8);
+			d.in_ptrs = (const uint64_t*)sload64(dp, offsetof(VvmExecDesc, in_ptrs) / 8);
+			d.out_ptrs = (const uint64_t*)sload64(dp, offsetof(VvmExecDesc, out_ptrs) / 8);
+			d.status = (unsigned long long*)sload64(dp, offsetof(VvmExecDesc, status) / 8);
+			d.counts = (int32_t*)sload64(dp, offsetof(VvmExecDesc, counts) / 8);
+			d.perlin = (const uint8_t*)sload64(dp, offsetof(VvmExecDesc, perlin) / 8);
+			d.num_instances = sload32(dp, offsetof(VvmExecDesc, num_instances) / 4);
+			d.num_tiles = sload32(dp, offsetof(VvmExecDesc, num_tiles) / 4);
+			d.first_tile = sload32(dp, offsetof(VvmExecDesc, first_tile) / 4);
+			d.exec_index_base = (int32_t)sload32(dp, offsetof(VvmExecDesc, exec_index_base) / 4);
+			d.rand_seed_lo = sload32(dp, offsetof(VvmExecDesc, rand_seed_lo) / 4);
+			d.rand_seed_hi = sload32(dp, offsetof(VvmExecDesc, rand_seed_hi) / 4);
+			d.rand_instance_base = (int32_t)sload32(dp, offsetof(VvmExecDesc, rand_instance_base) / 4);
+			d.flags = sload32(dp, offsetof(VvmExecDesc, flags) / 4);
+		}
+		const uint32_t tile_local = ticket - d.first_tile;
+		const uint32_t tile_first = tile_local * (VVM_BLOCK_THREADS * V);
+
+		if (FULL && (d.flags & VVM_DESC_USES_PERLIN) && !perlin_ready) {
+			for (uint32_t i = tid; i < 512; i += VVM_BLOCK_THREADS) lds_perlin[i] = d.perlin[i];
+			perlin_ready = true;
+			__syncthreads();
+		}
+
+		Ctx c;
+		c.consts = d.consts; c.in_ptrs = d.in_ptrs; c.out_ptrs = d.out_ptrs;
+		c.perlin_lds = lds_perlin; c.spill = lds_spill; c.tid = tid;
+		c.inst0 = tile_first + tid * V;
+		c.num_instances = d.num_instances;
+		c.full = (tile_first + VVM_BLOCK_THREADS * V) <= d.num_instances;
+		if (!(env.debug_skip & 1u)) run_tile<V, SPILL, FULL>(d, c, lds_ctrl, tile_local, tag, error_word, env.debug_skip);
+	}
+
+	// the last block to leave re-arms the launch words for the next launch
+	__syncthreads();
+	if (tid == 0) {
+		const uint32_t n = __hip_atomic_fetch_add((gu32*)&env.ls->done, 1u, RLX_AGENT);
+		if (n + 1 == gridDim.x) {
+			uint32_t next = (env.ls->epoch + 1u) & 0x3FFFFFFFu;
+			if (next == 0) next = 1;
+			__hip_atomic_store((gu32*)&env.ls->epoch, next, RLX_AGENT);
+			__hip_atomic_store((gu32*)&env.ls->done, 0u, RLX_AGENT);
+			__hip_atomic_store(ticket_word, 0u, RLX_AGENT);
+		}
+	}
+}
+
+// ---- host-callable launcher --------------------------------------------------------------------------
+extern "C" int vvm_launch_exec_kernel(int instances_per_lane, const VvmExecDesc* descs, uint32_t num_execs, uint32_t total_tiles,
+                                      VvmLaunchState* ls, uint32_t lds_spill_slots, int full, uint32_t grid, hipStream_t stream)
+{
+	KernelEnv env;
+	env.descs = descs; env.num_execs = num_execs; env.total_tiles = total_tiles; env.ls = ls; env.lds_spill_slots = lds_spill_slots;
+	{ const char* dbg = getenv("VVM_DEBUG_SKIP"); env.debug_skip = dbg ? (uint32_t)strtoul(dbg, nullptr, 0) : 0u; }
+	const size_t lds_bytes = LDS_SPILL_OFF + (size_t)lds_spill_slots * VVM_BLOCK_THREADS * 4u * (size_t)instances_per_lane;
+	const bool spill = lds_spill_slots > 0;
+#ifdef VVM_EXPERIMENT_ONE_KERNEL
+	(void)spill; (void)full; hipLaunchKernelGGL((vvm_exec_kernel<VVM_EXPERIMENT_ONE_KERNEL>), dim3(grid), dim3(VVM_BLOCK_THREADS), lds_bytes, stream, env);
+	return (int)hipGetLastError();
+#else
+#define VVM_LAUNCH(V, S, F) hipLaunchKernelGGL((vvm_exec_kernel<V, S, F>), dim3(grid), dim3(VVM_BLOCK_THREADS), lds_bytes, stream, env)
+	if (instances_per_lane == 4) {
+		if (full) { if (spill) VVM_LAUNCH(4, true, true); else VVM_LAUNCH(4, false, true); }
+		else      { if (spill) VVM_LAUNCH(4, true, false); else VVM_LAUNCH(4, false, false); }
+	} else {
+		if (full) { if (spill) VVM_LAUNCH(1, true, true); else VVM_LAUNCH(1, false, true); }
+		else      { if (spill) VVM_LAUNCH(1, true, false); else VVM_LAUNCH(1, false, false); }
+	}
+#undef VVM_LAUNCH
+#endif
+	return (int)hipGetLastError();
+}
+
+extern "C" int vvm_kernel_max_dynamic_lds(void)
+{
+	static int done = 0;
+#ifndef VVM_EXPERIMENT_ONE_KERNEL
+	if (!done) {
+		(void)hipFuncSetAttribute((const void*)vvm_exec_kernel<4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+		(void)hipFuncSetAttribute((const void*)vvm_exec_kernel<1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+		(void)hipFuncSetAttribute((const void*)vvm_exec_kernel<4, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+		(void)hipFuncSetAttribute((const void*)vvm_exec_kernel<1, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+		done = 1;
+	}
+#endif
+	(void)done;
+	return 160 * 1024 - 64;
+}
+
+extern "C" uint32_t vvm_kernel_resident_registers(int instances_per_lane) { return instances_per_lane == 4 ? RegTraits<4>::RV : RegTraits<1>::RV; }
+extern "C" uint32_t vvm_kernel_lds_fixed_bytes(void) { return LDS_SPILL_OFF; }

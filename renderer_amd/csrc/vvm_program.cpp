@@ -1,0 +1,438 @@
+// vvm_program.cpp -- blob thaw, optimized-bytecode decoding and linking into the device program.
+//
+// Reference behaviour reproduced here:
+//   ThawRuntimeContext                         VectorVMBridge.cpp:181-199 (layout :81-148)
+//   register index space of the bytecode       VectorVMRuntime.cpp:345-349 (temps | consts | inputs | input copies | outputs)
+//   instruction encodings                      VectorVMRuntime.cpp:555-569 (outputs), :826-828 (acquireindex), :1444-1450
+//                                              (external call), :1131-1134 / :1406 (ids), :1558-1904 (ops)
+//   input classification                       VectorVMRuntime.cpp:510-552 (VVMBuildMapTableCaches)
+#include "vvm_program.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+
+namespace vvm {
+
+static uint32_t rd32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+static uint16_t rd16(const uint8_t* p) { uint16_t v; memcpy(&v, p, 2); return v; }
+static uint64_t rd64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
+static size_t al16(size_t n) { return (n + 15) & ~(size_t)15; }
+
+int thaw_blob(const uint8_t* blob, size_t n, ThawedScript& s, std::string& err)
+{
+	if (!blob || n == 0) { err = "empty blob"; return VVM_E_BAD_BLOB; }   // RT.cpp:2313-2316
+	if (n < VVM_BLOB_FIRST_SECTION) { err = "blob shorter than its header"; return VVM_E_BAD_BLOB; }
+	const uint8_t* h = blob;
+	// packed archive order, VectorVMBridge.cpp:81-101
+	const uint32_t num_bytecode = rd32(h + 0);
+	s.max_output_dataset = rd32(h + 4);
+	/* NumConstsAlloced = rd16(h + 8) */
+	s.num_temps = rd32(h + 10);
+	s.num_consts = rd16(h + 14);
+	s.num_inputs = rd16(h + 16);
+	s.num_noadvance = rd16(h + 18);
+	s.num_input_datasets = rd16(h + 20);
+	s.num_outputs_remapped = rd16(h + 22);
+	s.num_output_instructions = rd16(h + 24);
+	s.num_ext_fns = rd32(h + 26);
+	s.max_ext_fn_registers = rd32(h + 30);
+	s.num_dummy_regs = rd32(h + 34);
+	/* MaxExtFnUsed = rd32(h + 38) */
+	s.flags = rd32(h + 42) & ~(uint32_t)VVM_FLAG_DATA_MAP_CACHE_SETUP;   // RT.cpp:2384
+	s.hash_id = rd64(h + 46);
+
+	const size_t off_bc  = VVM_BLOB_FIRST_SECTION;
+	const size_t off_cr  = al16(off_bc + num_bytecode);
+	const size_t off_ir  = al16(off_cr + 2u * (size_t)s.num_consts);
+	const size_t off_ido = al16(off_ir + 2u * (size_t)s.num_inputs);
+	const size_t off_ods = al16(off_ido + 16u * (size_t)s.num_input_datasets);
+	const size_t off_ot  = al16(off_ods + (size_t)s.num_outputs_remapped);
+	const size_t off_od  = al16(off_ot + 2u * (size_t)s.num_outputs_remapped);
+	const size_t off_ext = al16(off_od + 2u * (size_t)s.num_outputs_remapped);
+	const size_t total   = al16(off_ext + (size_t)VVM_BLOB_EXTFN_ENTRY_BYTES * s.num_ext_fns);
+	if (total > n) { err = "blob sections run past its end"; return VVM_E_BAD_BLOB; }
+	if (s.max_output_dataset > 255 || s.num_ext_fns > 4096) { err = "implausible header"; return VVM_E_BAD_BLOB; }
+
+	s.bytecode.assign(blob + off_bc, blob + off_bc + num_bytecode);
+	auto copy16 = [&](std::vector<uint16_t>& v, size_t off, size_t count) {
+		v.resize(count);
+		if (count) memcpy(v.data(), blob + off, 2 * count);
+	};
+	copy16(s.const_remap, off_cr, s.num_consts);
+	copy16(s.input_remap, off_ir, s.num_inputs);
+	copy16(s.input_dataset_offsets, off_ido, 8u * (size_t)s.num_input_datasets);
+	s.out_dataset.assign(blob + off_ods, blob + off_ods + s.num_outputs_remapped);
+	copy16(s.out_type, off_ot, s.num_outputs_remapped);
+	copy16(s.out_dst, off_od, s.num_outputs_remapped);
+	s.ext_num_inputs.resize(s.num_ext_fns);
+	s.ext_num_outputs.resize(s.num_ext_fns);
+	for (uint32_t i = 0; i < s.num_ext_fns; ++i) {
+		const uint8_t* e = blob + off_ext + (size_t)VVM_BLOB_EXTFN_ENTRY_BYTES * i;
+		s.ext_num_inputs[i] = (int32_t)rd32(e + 8);
+		s.ext_num_outputs[i] = (int32_t)rd32(e + 12);
+	}
+	return VVM_OK;
+}
+
+// ---- opcode table ------------------------------------------------------------------------------------
+enum OpKind : uint8_t { K_INVALID = 0, K_ORD, K_DST_ONLY, K_ACQUIRE, K_OUTPUT, K_EXTFN, K_IDS, K_DONE };
+struct OpInfo { uint8_t kind, nin, nout; bool heavy; };
+
+static OpInfo g_ops[256];
+static bool g_ops_ready = false;
+
+static void build_op_table()
+{
+	if (g_ops_ready) return;
+	memset(g_ops, 0, sizeof(g_ops));
+	auto set = [](std::initializer_list<int> ops, uint8_t nin, uint8_t nout) {
+		for (int o : ops) g_ops[o] = OpInfo{K_ORD, nin, nout, false};
+	};
+	set({VVM_OP_rcp, VVM_OP_rsq, VVM_OP_sqrt, VVM_OP_neg, VVM_OP_abs, VVM_OP_exp, VVM_OP_exp2, VVM_OP_log, VVM_OP_log2, VVM_OP_sin,
+	     VVM_OP_cos, VVM_OP_tan, VVM_OP_asin, VVM_OP_acos, VVM_OP_atan, VVM_OP_ceil, VVM_OP_floor, VVM_OP_frac, VVM_OP_trunc,
+	     VVM_OP_round, VVM_OP_sign, VVM_OP_absi, VVM_OP_negi, VVM_OP_signi, VVM_OP_bit_not, VVM_OP_logic_not, VVM_OP_f2i, VVM_OP_i2f,
+	     VVM_OP_f2b, VVM_OP_b2f, VVM_OP_i2b, VVM_OP_b2i, VVM_OP_random, VVM_OP_randomi, VVM_OP_half_to_float, VVM_OP_exec_index_addi}, 1, 1);
+	set({VVM_OP_add, VVM_OP_sub, VVM_OP_mul, VVM_OP_div, VVM_OP_atan2, VVM_OP_fmod, VVM_OP_min, VVM_OP_max, VVM_OP_pow, VVM_OP_step,
+	     VVM_OP_cmplt, VVM_OP_cmple, VVM_OP_cmpgt, VVM_OP_cmpge, VVM_OP_cmpeq, VVM_OP_cmpneq, VVM_OP_addi, VVM_OP_subi, VVM_OP_muli,
+	     VVM_OP_divi, VVM_OP_mini, VVM_OP_maxi, VVM_OP_cmplti, VVM_OP_cmplei, VVM_OP_cmpgti, VVM_OP_cmpgei, VVM_OP_cmpeqi, VVM_OP_cmpneqi,
+	     VVM_OP_bit_and, VVM_OP_bit_or, VVM_OP_bit_xor, VVM_OP_bit_lshift, VVM_OP_bit_rshift, VVM_OP_logic_and, VVM_OP_logic_or,
+	     VVM_OP_logic_xor, VVM_OP_sub_neg, VVM_OP_div_f2i, VVM_OP_i2f_div0, VVM_OP_i2f_div1, VVM_OP_i2f_mul, VVM_OP_f2i_maxi,
+	     VVM_OP_f2i_addi, VVM_OP_bit_and_i2f, VVM_OP_neg_cmplt, VVM_OP_max_f2i, VVM_OP_random_add}, 2, 1);
+	set({VVM_OP_mad, VVM_OP_lerp, VVM_OP_clamp, VVM_OP_select, VVM_OP_clampi, VVM_OP_mad_sqrt, VVM_OP_mul_add, VVM_OP_mul_sub0,
+	     VVM_OP_mul_sub1, VVM_OP_mul_mul, VVM_OP_mul_max, VVM_OP_add_add, VVM_OP_sub_cmplt1, VVM_OP_sub_mul, VVM_OP_div_mul,
+	     VVM_OP_muli_addi, VVM_OP_addi_bit_rshift, VVM_OP_addi_muli, VVM_OP_i2f_mad0, VVM_OP_i2f_mad1, VVM_OP_f2i_select1,
+	     VVM_OP_fmod_add, VVM_OP_bit_rshift_bit_and, VVM_OP_bit_or_muli, VVM_OP_bit_lshift_bit_or}, 3, 1);
+	for (int o = VVM_OP_cmplt_logic_and; o <= VVM_OP_cmpnei_logic_or; ++o) g_ops[o] = OpInfo{K_ORD, 3, 1, false};
+	set({VVM_OP_cmplt_select, VVM_OP_cmple_select, VVM_OP_cmpeq_select, VVM_OP_cmplti_select, VVM_OP_cmplei_select,
+	     VVM_OP_cmpeqi_select, VVM_OP_mad_add, VVM_OP_mad_sub0, VVM_OP_mad_sub1, VVM_OP_mad_mul, VVM_OP_mul_mad0, VVM_OP_mul_mad1,
+	     VVM_OP_add_mad1, VVM_OP_div_mad0, VVM_OP_select_mul, VVM_OP_select_add}, 4, 1);
+	set({VVM_OP_mad_mad0, VVM_OP_mad_mad1}, 5, 1);
+	set({VVM_OP_mul_2x}, 2, 2);
+	set({VVM_OP_b2i_2x, VVM_OP_random_2x, VVM_OP_sin_cos}, 1, 2);
+	for (int o : {VVM_OP_exp, VVM_OP_exp2, VVM_OP_log, VVM_OP_log2, VVM_OP_sin, VVM_OP_cos, VVM_OP_tan, VVM_OP_asin, VVM_OP_acos,
+	              VVM_OP_atan, VVM_OP_atan2, VVM_OP_fmod, VVM_OP_pow, VVM_OP_fmod_add, VVM_OP_sin_cos})
+		g_ops[o].heavy = true;
+	g_ops[VVM_OP_done] = OpInfo{K_DONE, 0, 0, false};
+	g_ops[VVM_OP_exec_index] = OpInfo{K_DST_ONLY, 0, 1, false};
+	g_ops[VVM_OP_exec_indexf] = OpInfo{K_DST_ONLY, 0, 1, false};
+	g_ops[VVM_OP_acquireindex] = OpInfo{K_ACQUIRE, 1, 0, false};
+	for (int o : {VVM_OP_outputdata_float, VVM_OP_outputdata_int32, VVM_OP_outputdata_half, VVM_OP_outputdata_float_from_half,
+	              VVM_OP_outputdata_half_from_half})
+		g_ops[o] = OpInfo{K_OUTPUT, 0, 0, false};
+	g_ops[VVM_OP_external_func_call] = OpInfo{K_EXTFN, 0, 0, true};
+	g_ops[VVM_OP_update_id] = OpInfo{K_IDS, 2, 0, false};
+	g_ops[VVM_OP_acquire_id] = OpInfo{K_IDS, 0, 2, false};
+	g_ops_ready = true;
+}
+
+// ---- decoded instruction -----------------------------------------------------------------------------
+struct Decoded {
+	uint8_t op = 0, kind = 0;
+	std::vector<uint16_t> in, out;                 // bytecode register indices
+	std::vector<std::pair<uint16_t, uint16_t>> pairs;   // output instructions: (src, dst)
+	uint8_t dataset = 0;
+	uint16_t fn = 0;
+};
+
+static int decode(const ThawedScript& s, std::vector<Decoded>& out, std::string& err)
+{
+	build_op_table();
+	const std::vector<uint8_t>& bc = s.bytecode;
+	size_t ip = 0;
+	char msg[160];
+	auto need = [&](size_t nbytes) { return ip + nbytes <= bc.size(); };
+	for (;;) {
+		if (!need(1)) { err = "bytecode ends without a done"; return VVM_E_BAD_BLOB; }
+		const uint8_t op = bc[ip++];
+		const OpInfo& info = g_ops[op];
+		Decoded d;
+		d.op = op; d.kind = info.kind;
+		if (info.kind == K_DONE) break;
+		switch (info.kind) {
+		case K_ORD: {
+			const size_t n = (size_t)info.nin + info.nout;
+			if (!need(2 * n)) { err = "truncated op"; return VVM_E_BAD_BLOB; }
+			for (size_t i = 0; i < info.nin; ++i) d.in.push_back(rd16(&bc[ip + 2 * i]));
+			for (size_t i = 0; i < info.nout; ++i) d.out.push_back(rd16(&bc[ip + 2 * (info.nin + i)]));
+			ip += 2 * n;
+			break;
+		}
+		case K_DST_ONLY:
+			if (!need(2)) { err = "truncated exec_index"; return VVM_E_BAD_BLOB; }
+			d.out.push_back(rd16(&bc[ip])); ip += 2;
+			break;
+		case K_ACQUIRE:
+			if (!need(3)) { err = "truncated acquireindex"; return VVM_E_BAD_BLOB; }
+			d.in.push_back(rd16(&bc[ip])); d.dataset = bc[ip + 2]; ip += 3;
+			break;
+		case K_OUTPUT: {
+			if (!need(2)) { err = "truncated output"; return VVM_E_BAD_BLOB; }
+			const size_t n = bc[ip];
+			d.dataset = bc[ip + 1];
+			if (!need(2 + 4 * n)) { err = "truncated output"; return VVM_E_BAD_BLOB; }
+			for (size_t j = 0; j < n; ++j)
+				d.pairs.emplace_back(rd16(&bc[ip + 2 + 2 * j]), rd16(&bc[ip + 2 + 2 * (n + j)]));
+			ip += 2 + 4 * n;
+			break;
+		}
+		case K_EXTFN: {
+			if (!need(2)) { err = "truncated external call"; return VVM_E_BAD_BLOB; }
+			d.fn = rd16(&bc[ip]);
+			if (d.fn >= s.num_ext_fns) { err = "external function index out of range"; return VVM_E_BAD_BLOB; }
+			const size_t ni = (size_t)s.ext_num_inputs[d.fn], no = (size_t)s.ext_num_outputs[d.fn];
+			if (!need(2 + 2 * (ni + no))) { err = "truncated external call"; return VVM_E_BAD_BLOB; }
+			for (size_t i = 0; i < ni; ++i) d.in.push_back(rd16(&bc[ip + 2 + 2 * i]));
+			for (size_t i = 0; i < no; ++i) d.out.push_back(rd16(&bc[ip + 2 + 2 * (ni + i)]));
+			ip += 2 + 2 * (ni + no);
+			break;
+		}
+		case K_IDS:
+			if (!need(5)) { err = "truncated id op"; return VVM_E_BAD_BLOB; }
+			if (op == VVM_OP_update_id) { d.in.push_back(rd16(&bc[ip])); d.in.push_back(rd16(&bc[ip + 2])); }
+			else { d.out.push_back(rd16(&bc[ip])); d.out.push_back(rd16(&bc[ip + 2])); }
+			d.dataset = bc[ip + 4]; ip += 5;
+			break;
+		default:
+			// inputs, stat scopes, fasi/iasf and the noise ops are never emitted in the optimized format
+			// (VectorVMOptimizer.cpp:3044-3046, 3112-3113); the reference's handlers for them are empty stubs
+			snprintf(msg, sizeof(msg), "opcode %u at byte %zu has no optimized-format encoding", (unsigned)op, ip - 1);
+			err = msg;
+			return VVM_E_UNSUPPORTED_OP;
+		}
+		out.push_back(std::move(d));
+	}
+	return VVM_OK;
+}
+
+// ---- linker ------------------------------------------------------------------------------------------
+static const uint32_t kMaxSpillWide = 12;      // LDS register slots of the 4-instances-per-lane kernel (4 KB each per workgroup)
+static const uint32_t kMaxSpillNarrow = 128;   // 1 KB each
+
+int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, std::string& err)
+{
+	std::vector<Decoded> ins;
+	int rc = decode(s, ins, err);
+	if (rc != VVM_OK) return rc;
+	char msg[200];
+
+	const uint32_t T = s.num_temps, C = s.num_consts, I = s.num_inputs;
+	const uint32_t O = std::max<uint32_t>(s.num_outputs_remapped, s.num_output_instructions);
+	const uint32_t out0 = T + C + 2 * I;
+	if (C > VVM_MAX_OPND_INDEX || I > 0xFFF || O > VVM_MAX_OPND_INDEX) { err = "script exceeds the device operand index range"; return VVM_E_TOO_LARGE; }
+
+	// classify inputs from InputDataSetOffsets: per dataset float,int,half then no-advance float,int,half (RT.cpp:515-550)
+	lp.inputs.assign(I, InputInfo{0, 0, false, 0});
+	{
+		uint32_t counter = 0;
+		for (uint32_t ds = 0; ds < s.num_input_datasets; ++ds) {
+			const uint16_t* off = &s.input_dataset_offsets[ds * 8];
+			for (int j = 0; j < 3; ++j)
+				for (uint32_t k = off[j]; k < off[j + 1]; ++k) {
+					if (counter >= I || k >= I) { err = "InputDataSetOffsets inconsistent with NumInputsRemapped"; return VVM_E_BAD_BLOB; }
+					lp.inputs[counter++] = InputInfo{(uint8_t)ds, (uint8_t)j, false, s.input_remap[k]};
+				}
+			if (off[7] > 0)
+				for (int j = 0; j < 3; ++j)
+					for (uint32_t k = off[j + 3]; k < off[j + 4]; ++k) {
+						if (counter >= I || k >= I) { err = "InputDataSetOffsets inconsistent with NumInputsRemapped"; return VVM_E_BAD_BLOB; }
+						lp.inputs[counter++] = InputInfo{(uint8_t)ds, (uint8_t)j, true, s.input_remap[k]};
+					}
+		}
+		if (counter != I) { err = "InputDataSetOffsets do not cover every remapped input"; return VVM_E_BAD_BLOB; }   // RT.cpp:551
+	}
+
+	// which output registers are used as op operands (temps aliased onto output buffers, VectorVMOptimizer.cpp:2855-2978)
+	std::vector<int32_t> out_vreg(O, -1);
+	std::vector<uint32_t> vreg_uses;      // access count per virtual register
+	uint32_t nv = T;
+	vreg_uses.assign(T, 0);
+	auto reg_class_ok = [&](uint16_t r) { return r == VVM_INVALID_REG || r < out0 + O; };
+	auto touch = [&](uint16_t r) {
+		if (r == VVM_INVALID_REG) return;
+		if (r < T) { vreg_uses[r]++; return; }
+		if (r >= out0) {
+			const uint32_t o = r - out0;
+			if (out_vreg[o] < 0) { out_vreg[o] = (int32_t)nv++; vreg_uses.push_back(0); }
+			vreg_uses[(size_t)out_vreg[o]]++;
+		}
+	};
+	lp.acquires_dataset.assign(std::max<uint32_t>(s.max_output_dataset, 1), 0);
+	bool heavy = false, uses_perlin = false;
+	for (const Decoded& d : ins) {
+		for (uint16_t r : d.in) if (!reg_class_ok(r)) { err = "register index out of range"; return VVM_E_BAD_BLOB; }
+		for (uint16_t r : d.out) if (!reg_class_ok(r)) { err = "register index out of range"; return VVM_E_BAD_BLOB; }
+		if (g_ops[d.op].heavy) heavy = true;
+		if (d.kind == K_EXTFN) uses_perlin = true;
+		if (d.kind == K_IDS) lp.uses_ids = true;
+		if (d.kind == K_OUTPUT) {
+			for (auto& p : d.pairs) {
+				if (!reg_class_ok(p.first) || p.second < out0 || p.second >= out0 + O) { err = "output operand out of range"; return VVM_E_BAD_BLOB; }
+				// an output register as a SOURCE is a value some op stored there
+				if (p.first >= out0 || p.first < T) touch(p.first);
+			}
+			continue;
+		}
+		if (d.kind == K_ACQUIRE) {
+			if (d.dataset >= lp.acquires_dataset.size()) { err = "acquireindex names a dataset past MaxOutputDataSet"; return VVM_E_BAD_BLOB; }
+			if (lp.acquires_dataset[d.dataset]) { err = "more than one acquireindex for a dataset"; return VVM_E_UNSUPPORTED_OP; }
+			lp.acquires_dataset[d.dataset] = 1;
+		}
+		for (uint16_t r : d.in) touch(r);
+		for (uint16_t r : d.out) {
+			if (r != VVM_INVALID_REG && r >= T && r < out0) { err = "an op writes a constant or input register"; return VVM_E_BAD_BLOB; }
+			touch(r);
+		}
+	}
+	if (lp.uses_ids) { err = "update_id / acquire_id are not implemented by the GPU executor yet"; return VVM_E_UNSUPPORTED_OP; }
+	uint32_t acquired = 0;
+	for (uint8_t a : lp.acquires_dataset) acquired += a;
+	if (acquired > 1) { err = "acquireindex on more than one dataset in one script is not supported by the GPU executor"; return VVM_E_UNSUPPORTED_OP; }
+
+	// choose the kernel shape
+	uint32_t V = 4, RV = 16;
+	if (force_narrow || nv > RV + kMaxSpillWide) { V = 1; RV = 32; }
+	if (nv > RV + (V == 4 ? kMaxSpillWide : kMaxSpillNarrow)) {
+		snprintf(msg, sizeof(msg), "script needs %u per-lane registers; the executor holds at most %u", nv, RV + kMaxSpillNarrow);
+		err = msg;
+		return VVM_E_TOO_LARGE;
+	}
+
+	// place virtual registers: the most used ones take the VGPR-resident slots, the rest go to LDS slots
+	std::vector<uint32_t> place(nv);
+	{
+		std::vector<uint32_t> order(nv);
+		for (uint32_t i = 0; i < nv; ++i) order[i] = i;
+		if (nv > RV) std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return vreg_uses[a] > vreg_uses[b]; });
+		for (uint32_t i = 0; i < nv; ++i) place[order[i]] = i;
+	}
+	uint32_t next_vreg = nv;
+
+	// prefetch: advancing 32-bit inputs go to the free resident registers, in order of first use, eight per VVM_DOP_LOADN
+	std::vector<int32_t> input_vreg(I, -1);
+	std::vector<uint32_t> prefetch;
+	if (next_vreg < RV) {
+		for (const Decoded& d : ins) {
+			auto consider = [&](uint16_t r) {
+				if (r == VVM_INVALID_REG || r < T + C || r >= T + C + I) return;
+				const uint32_t i = r - (T + C);
+				if (input_vreg[i] >= 0 || lp.inputs[i].noadvance || lp.inputs[i].type == 2) return;
+				if (next_vreg >= RV) return;
+				input_vreg[i] = (int32_t)next_vreg++;
+				prefetch.push_back(i);
+			};
+			for (uint16_t r : d.in) consider(r);
+			for (auto& p : d.pairs) consider(p.first);
+		}
+	}
+	lp.num_prefetched_inputs = (uint32_t)prefetch.size();
+	lp.num_vregs = next_vreg;
+	lp.instances_per_lane = V;
+	lp.resident_regs = RV;
+	lp.lds_spill_slots = next_vreg > RV ? next_vreg - RV : 0;
+	lp.full_kernel = heavy;
+	lp.uses_perlin = uses_perlin;
+
+	auto operand = [&](uint16_t r) -> uint32_t {
+		if (r == VVM_INVALID_REG) return VVM_OPND(VVM_OPC_NONE, 0);
+		if (r < T) return VVM_OPND(VVM_OPC_VREG, place[r]);
+		if (r < T + C) return VVM_OPND(VVM_OPC_CONST, r - T);
+		if (r < T + C + I) {
+			const uint32_t i = r - (T + C);
+			if (input_vreg[i] >= 0) return VVM_OPND(VVM_OPC_VREG, (uint32_t)input_vreg[i]);
+			const InputInfo& in = lp.inputs[i];
+			if (in.type == 2) return VVM_OPND(in.noadvance ? VVM_OPC_NOADV_HALF : VVM_OPC_HALF, i);
+			return VVM_OPND(in.noadvance ? VVM_OPC_NOADV : VVM_OPC_INPUT, i);
+		}
+		if (r < out0) return VVM_OPND(VVM_OPC_NONE, 0);   // input base copies: never operands
+		return VVM_OPND(VVM_OPC_VREG, place[(size_t)out_vreg[r - out0]]);
+	};
+
+	// ---- emit ----
+	lp.code.clear();
+	for (size_t i = 0; i < prefetch.size(); i += 8) {
+		const size_t n = std::min<size_t>(8, prefetch.size() - i);
+		uint64_t lo = 0; uint32_t hi = 0;     // eight 12-bit stream indices in 96 bits
+		for (size_t j = 0; j < n; ++j) {
+			const uint64_t idx = prefetch[i + j] & 0xFFFu;
+			const unsigned bit = 12u * (unsigned)j;
+			if (bit < 64) { lo |= idx << bit; if (bit + 12 > 64) hi |= (uint32_t)(idx >> (64 - bit)); }
+			else hi |= (uint32_t)(idx << (bit - 64));
+		}
+		VvmIns k;
+		k.w0 = VVM_INS_W0(VVM_DOP_LOADN, 0, 0, n, (uint32_t)input_vreg[prefetch[i]]);
+		k.w1 = (uint32_t)lo; k.w2 = (uint32_t)(lo >> 32); k.w3 = hi;
+		lp.code.push_back(k);
+	}
+	uint32_t rand_ordinal = 0;
+	for (const Decoded& d : ins) {
+		VvmIns k{0, 0, 0, 0};
+		switch (d.kind) {
+		case K_ORD: case K_DST_ONLY: {
+			uint32_t o[6] = {0, 0, 0, 0, 0, 0};
+			for (size_t i = 0; i < d.in.size(); ++i) o[i] = operand(d.in[i]);
+			if (d.out.size() >= 1) o[5] = operand(d.out[0]);
+			if (d.out.size() >= 2) o[4] = operand(d.out[1]);
+			for (size_t i = 0; i < d.out.size(); ++i)
+				if (VVM_OPND_CLS(operand(d.out[i])) != VVM_OPC_VREG) { err = "an op destination is not a temp or output register"; return VVM_E_BAD_BLOB; }
+			uint32_t aux2 = 0;
+			if (d.op == VVM_OP_random || d.op == VVM_OP_randomi || d.op == VVM_OP_random_add) aux2 = rand_ordinal++;
+			else if (d.op == VVM_OP_random_2x) { aux2 = rand_ordinal; rand_ordinal += 2; }
+			if (rand_ordinal > 255) { err = "more than 255 random draws in one script"; return VVM_E_TOO_LARGE; }
+			k.w0 = VVM_INS_W0(d.op, d.in.size(), d.out.size(), 0, aux2);
+			k.w1 = o[0] | (o[1] << 16); k.w2 = o[2] | (o[3] << 16); k.w3 = o[4] | (o[5] << 16);
+			lp.code.push_back(k);
+			break;
+		}
+		case K_ACQUIRE:
+			k.w0 = VVM_INS_W0(VVM_OP_acquireindex, 1, 0, d.dataset, 0);
+			k.w1 = operand(d.in[0]);
+			lp.code.push_back(k);
+			break;
+		case K_OUTPUT: {
+			uint32_t dop = VVM_DOP_OUTPUT32;
+			if (d.op == VVM_OP_outputdata_half) dop = VVM_DOP_OUTPUT16;
+			else if (d.op == VVM_OP_outputdata_half_from_half) dop = VVM_DOP_OUTPUT16_FROM16;
+			else if (d.op == VVM_OP_outputdata_float_from_half) dop = VVM_DOP_OUTPUT32_FROM16;
+			for (size_t i = 0; i < d.pairs.size(); i += 3) {
+				const size_t n = std::min<size_t>(3, d.pairs.size() - i);
+				uint32_t o[6] = {0, 0, 0, 0, 0, 0};
+				for (size_t j = 0; j < n; ++j) {
+					o[2 * j] = operand(d.pairs[i + j].first);
+					o[2 * j + 1] = d.pairs[i + j].second - out0;     // output serial index
+				}
+				k.w0 = VVM_INS_W0(dop, 0, 0, n, d.dataset);
+				k.w1 = o[0] | (o[1] << 16); k.w2 = o[2] | (o[3] << 16); k.w3 = o[4] | (o[5] << 16);
+				lp.code.push_back(k);
+			}
+			break;
+		}
+		case K_EXTFN: {
+			// the built-in is bound at Exec time through ExtFunctionTable; only the shapes of the stated built-in set link
+			const int ni = s.ext_num_inputs[d.fn], no = s.ext_num_outputs[d.fn];
+			if (!(ni == 3 && (no == 1 || no == 3))) {
+				snprintf(msg, sizeof(msg), "external function %u has %d inputs / %d outputs; the GPU built-ins are perlin3 (3/1) and curl_noise3 (3/3)", (unsigned)d.fn, ni, no);
+				err = msg;
+				return VVM_E_UNSUPPORTED_OP;
+			}
+			uint32_t o[6] = {0, 0, 0, 0, 0, 0};
+			for (int i = 0; i < 3; ++i) o[i] = operand(d.in[(size_t)i]);
+			for (int i = 0; i < no; ++i) o[3 + i] = operand(d.out[(size_t)i]);
+			for (int i = no; i < 3; ++i) o[3 + i] = VVM_OPND(VVM_OPC_NONE, 0);
+			// aux is patched per Exec with the built-in id; aux2 carries the function index
+			k.w0 = VVM_INS_W0(VVM_OP_external_func_call, 3, 0, no == 1 ? VVM_EXTFN_PERLIN3 : VVM_EXTFN_CURL_NOISE3, d.fn);
+			k.w1 = o[0] | (o[1] << 16); k.w2 = o[2] | (o[3] << 16); k.w3 = o[4] | (o[5] << 16);
+			lp.code.push_back(k);
+			break;
+		}
+		default: break;
+		}
+	}
+	lp.code.push_back(VvmIns{VVM_INS_W0(VVM_OP_done, 0, 0, 0, 0), 0, 0, 0});
+
+	for (const InputInfo& in : lp.inputs) if (!in.noadvance) lp.bytes_in_per_instance += (in.type == 2) ? 2 : 4;
+	for (uint32_t i = 0; i < s.num_outputs_remapped; ++i) if (s.out_dst[i] != 0xFFFF) lp.bytes_out_per_instance += (s.out_type[i] == 2) ? 2 : 4;
+	return VVM_OK;
+}
+
+}  // namespace vvm

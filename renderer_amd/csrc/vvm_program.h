@@ -1,0 +1,55 @@
+// vvm_program.h -- host side: frozen-blob thaw, bytecode decoding and linking into the device program.
+#pragma once
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/vvm_abi.h"
+#include "vvm_device.h"
+
+namespace vvm {
+
+// Everything ThawRuntimeContext recovers from a blob (VectorVMBridge.cpp:181-199), copied out of it.
+struct ThawedScript {
+	std::vector<uint8_t>  bytecode;
+	std::vector<uint16_t> const_remap;            // ConstRemap[1]: remapped const -> original dword index
+	std::vector<uint16_t> input_remap;            // InputRemapTable
+	std::vector<uint16_t> input_dataset_offsets;  // 8 per input dataset
+	std::vector<uint8_t>  out_dataset;            // OutputRemapDataSetIdx
+	std::vector<uint16_t> out_type;               // OutputRemapDataType: 0 f32, 1 i32, 2 f16
+	std::vector<uint16_t> out_dst;                // OutputRemapDst (0xFFFF = none)
+	std::vector<int32_t>  ext_num_inputs, ext_num_outputs;
+	uint32_t num_temps = 0, num_consts = 0, num_inputs = 0, num_noadvance = 0, num_input_datasets = 0;
+	uint32_t num_outputs_remapped = 0, num_output_instructions = 0, max_output_dataset = 0;
+	uint32_t num_ext_fns = 0, max_ext_fn_registers = 0, num_dummy_regs = 0, flags = 0;
+	uint64_t hash_id = 0;
+};
+
+// One remapped input, classified from InputDataSetOffsets the way VVMBuildMapTableCaches does (VectorVMRuntime.cpp:510-552).
+struct InputInfo {
+	uint8_t  dataset;
+	uint8_t  type;        // 0 f32, 1 i32, 2 f16
+	bool     noadvance;
+	uint16_t reg;         // per-type register index inside the dataset (InputRemapTable entry)
+};
+
+struct LinkedProgram {
+	std::vector<VvmIns> code;          // device instructions, terminated by a `done`
+	std::vector<InputInfo> inputs;
+	uint32_t num_vregs = 0;            // per-lane registers used
+	uint32_t instances_per_lane = 4;   // 4 or 1
+	uint32_t resident_regs = 16;
+	uint32_t lds_spill_slots = 0;
+	bool     full_kernel = false;      // needs the transcendental / noise kernel
+	bool     uses_perlin = false;
+	bool     uses_ids = false;
+	std::vector<uint8_t> acquires_dataset;   // per output dataset: the script runs acquireindex for it
+	uint32_t bytes_in_per_instance = 0, bytes_out_per_instance = 0;
+	uint32_t num_prefetched_inputs = 0;
+};
+
+// Returns VVM_OK or an error code with `err` filled.
+int thaw_blob(const uint8_t* blob, size_t n, ThawedScript& out, std::string& err);
+int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& out, std::string& err);
+
+}  // namespace vvm
