@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Headline benchmark: particle updates per second of the VectorVM executor on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is one Exec of the fountain update script (8 float32 streams in, 8 out, kill by acquireindex) over one
+batch of synthetic particles that is already resident in HBM.  At N = 1 the batch is 64 Mi particles
+(BASELINE.json configs[1]); at N > 1 every rank runs the same-sized shard of a larger emitter (weak scaling), with
+exec_index / random streams based at the shard's first global instance, and every step ends with the all-gather
+of the per-rank survivor counts (RCCL) from which each rank's global acquireindex offset follows.
+
+Rank 0 prints ONE JSON line.  `roofline` prices the interpreter kernel against HBM: algorithmic bytes per launch
+(4 bytes x (input streams x instances + output streams x survivors)) over the kernel's mean duration, which is
+measured here with HIP events recorded on the kernel's own stream around every launch of the timed region.
+`cpu_baseline` is the CPU oracle (a restatement of the reference interpreter in its own structure: interpreted
+bytecode, 4-wide SSE, 64 KB-page chunks, one thread) timed on a bounded sample on the host's cores.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E peak
+PAD = 64
+
+
+def cpu_baseline(workload_name, seconds=12.0, n=1 << 20):
+    """Times the oracle (tests/oracle_binding.py) on `n` instances, repeating whole Execs for about `seconds`."""
+    import numpy as np
+    from renderer_amd import abi, scripts
+    from oracle_binding import load_oracle
+    be = load_oracle()
+    be.set_strict(False)
+    be.set_page_kb(64)
+    be.set_options(0, 0, 0)
+    w = scripts.fountain()
+    kill = workload_name == "fountain_kill_half"
+    ins = [np.concatenate([a, np.zeros(PAD, np.float32)]) for a in scripts.fountain_streams_np(0, n, kill_half=kill)]
+    outs = [np.zeros(n + PAD, np.float32) for _ in range(8)]
+    ds = abi.DataSet([a.ctypes.data for a in ins], [a.ctypes.data for a in outs], 0)
+    state = be.alloc_state(w.script.blob)
+    frame = abi.CallFrame(state, [ds], n, [w.constants], ())
+    for _ in range(2):
+        be.exec(frame)
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        be.exec(frame)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el >= seconds:
+            break
+    be.free_state(state)
+    return {"value": n * reps / el, "unit": "particle updates/s", "cores": 1, "kind": "port",
+            "sample": "%d Execs of %d particles (fountain script, BASELINE.json configs[0] size) in %.1f s; CPU restatement in "
+                      "reference structure (interpreted, 4-wide SSE, 64 KB-page chunks), not the reference's own binary" % (reps, n, el)}
+
+
+class _DevPtr:
+    """Zero-copy torch view of a raw device pointer (through __cuda_array_interface__)."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (ptr, False), "version": 2}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="fountain", choices=["fountain", "fountain_kill_half"])
+    ap.add_argument("--particles", type=int, default=64 * 1024 * 1024, help="instances per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    from renderer_amd import abi, scripts
+    from renderer_amd.runtime import VectorVMState, global_offsets
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if distributed else 0)
+    be = abi.load_hip_backend()
+    be._check(be.lib.vvm_set_device(dev.index), "vvm_set_device")
+
+    n = args.particles
+    kill = args.workload == "fountain_kill_half"
+    first = rank * n                       # this rank's first global instance
+    w = scripts.fountain()
+    ins = scripts.fountain_streams_torch(first, n, dev, kill_half=kill, pad=PAD)
+    outs = [torch.zeros(n + PAD, dtype=torch.float32, device=dev) for _ in range(8)]
+    torch.cuda.synchronize()
+
+    state = VectorVMState(w.script.blob)
+    ds = abi.DataSet([t.data_ptr() for t in ins], [t.data_ptr() for t in outs], 0)
+    frame = state.frame([ds], n, [w.constants])
+    stream = torch.cuda.current_stream().cuda_stream
+    opt = abi.ExecOptions(0, first if first < 2 ** 31 else 0, first if first < 2 ** 31 else 0, stream, 0)
+    counts_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+    gathered = torch.zeros(world, dtype=torch.int32, device=dev)
+
+    def step():
+        state.exec_async(frame, opt)
+        if distributed:
+            # the path's one exchange: every rank's survivor count, for the global acquireindex offsets
+            state.copy_counts(counts_dev.data_ptr(), stream)
+            dist.all_gather_into_tensor(gathered, counts_dev)
+
+    for _ in range(args.warmup):
+        step()
+    survivors = state.finish(frame)
+    torch.cuda.synchronize()
+
+    state.enable_timing(True)
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    survivors = state.finish(frame)
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms_sum, launches = state.collect_kernel_ms()
+    state.enable_timing(False)
+
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        offs = global_offsets(gathered.tolist())
+        assert int(gathered[rank].item()) == survivors
+        assert offs[rank] == sum(gathered.tolist()[:rank])
+
+    if rank == 0:
+        info = state.info()
+        total_updates = float(n) * world * args.steps
+        value = total_updates / elapsed
+        alg_bytes = float(info.BytesInPerInstance) * n + float(info.BytesOutPerInstance) * survivors
+        kernel_ms = kernel_ms_sum / max(launches, 1)
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        line = {
+            "metric": "particle updates/sec", "value": value, "unit": "particle updates/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s script (8 f32 streams in, 8 out, kill via acquireindex), %d particles per GPU, "
+                                   "%.1f%% survive" % (args.workload, n, 100.0 * survivors / max(n, 1)),
+                       "particles_per_gpu": n, "survivors_rank0": survivors, "instances_per_lane": int(info.InstancesPerLane),
+                       "parallelism": "instance ranges sharded over %d GPU(s); all-gather of survivor counts" % world if distributed
+                       else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": None, "kernel": "vvm_exec_kernel", "kernel_ms": kernel_ms, "launches": launches,
+                         "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
+        elif world == 1:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+
+    state.close()
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -252,6 +252,11 @@ VVM_API int vvm_state_info(const vvm_state* state, vvm_program_info* out);
  * Lets host-side tooling validate a script on a machine with no GPU. */
 VVM_API int vvm_inspect_blob(const uint8_t* blob, size_t num_bytes, vvm_program_info* out);
 
+/* Thaw and link a blob without touching a device and copy out the linked device program: 4 dwords per instruction
+ * (renderer_amd/csrc/vvm_device.h gives the encoding), at most `capacity_instructions` of them.  Returns the number of
+ * instructions of the program (negative status code on failure).  narrow != 0 links for the 1-instance-per-lane kernel. */
+VVM_API int vvm_inspect_code(const uint8_t* blob, size_t num_bytes, int narrow, uint32_t* out_words, int32_t capacity_instructions);
+
 /* Thread-local text of the last failure in this library. */
 VVM_API const char* vvm_last_error(void);
 

@@ -265,6 +265,8 @@ class HipBackend(Backend):
         L.vvm_state_info.argtypes = [C.c_void_p, C.POINTER(ProgramInfo)]
         L.vvm_inspect_blob.restype = C.c_int
         L.vvm_inspect_blob.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(ProgramInfo)]
+        L.vvm_inspect_code.restype = C.c_int
+        L.vvm_inspect_code.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_uint32), C.c_int32]
         L.vvm_device_alloc.restype = C.c_void_p
         L.vvm_device_alloc.argtypes = [C.c_size_t]
         L.vvm_device_free.restype = None
@@ -313,6 +315,15 @@ class HipBackend(Backend):
         pi = ProgramInfo()
         self._check(self.lib.vvm_inspect_blob(blob, len(blob), C.byref(pi)), "vvm_inspect_blob")
         return pi
+
+    def inspect_code(self, blob: bytes, narrow: bool = False):
+        """Linked device program of a blob as a list of (w0, w1, w2, w3) tuples (no device needed)."""
+        n = self.lib.vvm_inspect_code(blob, len(blob), 1 if narrow else 0, None, 0)
+        if n < 0:
+            self._check(-n, "vvm_inspect_code")
+        buf = (C.c_uint32 * (4 * n))()
+        self.lib.vvm_inspect_code(blob, len(blob), 1 if narrow else 0, buf, n)
+        return [tuple(buf[4 * i:4 * i + 4]) for i in range(n)]
 
     def info(self, state: int) -> ProgramInfo:
         pi = ProgramInfo()

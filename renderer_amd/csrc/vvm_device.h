@@ -13,21 +13,24 @@
 // ---- operand = class (3 bits) | index (13 bits) ----
 enum : uint32_t {
 	VVM_OPC_VREG  = 0,   // per-lane virtual register: index < resident count -> VGPR, else LDS slot
-	VVM_OPC_CONST = 1,   // remapped constant (uniform)
-	VVM_OPC_INPUT = 2,   // advancing 32-bit input stream, read at the instance index
-	VVM_OPC_NOADV = 3,   // no-advance input: element [InstanceOffset] of the stream, uniform (VectorVMRuntime.cpp:381-401)
-	VVM_OPC_HALF  = 4,   // advancing 16-bit input stream (only half_to_float / *_from_half read it)
-	VVM_OPC_NOADV_HALF = 5,
+	VVM_OPC_UNIF  = 1,   // uniform register: one of the first VVM_MAX_UNIFORMS remapped constants, held in a VGPR vector
+	VVM_OPC_CONST = 2,   // remapped constant read from the constant table (the ones past the uniform registers)
+	VVM_OPC_INPUT = 3,   // advancing 32-bit input stream, read at the instance index
+	VVM_OPC_NOADV = 4,   // no-advance input: element [InstanceOffset] of the stream, uniform (VectorVMRuntime.cpp:381-401)
+	VVM_OPC_HALF  = 5,   // advancing 16-bit input stream (only half_to_float / *_from_half read it)
+	VVM_OPC_NOADV_HALF = 6,
 	VVM_OPC_NONE  = 7    // 0xFFFF in the bytecode: external-function dummy register
 };
 #define VVM_OPND(cls, idx) ((uint32_t)(((cls) << 13) | ((idx) & 0x1FFFu)))
 #define VVM_OPND_CLS(o)    (((o) >> 13) & 7u)
 #define VVM_OPND_IDX(o)    ((o) & 0x1FFFu)
 #define VVM_MAX_OPND_INDEX 0x1FFFu
+#define VVM_MAX_UNIFORMS   32u
 
 // ---- device-only opcodes (the reference's opcodes keep their numbers 0..178) ----
 enum : uint32_t {
-	VVM_DOP_LOADN  = 192,  // prefetch up to 8 input streams into consecutive virtual registers
+	VVM_DOP_LOADN  = 191,  // prefetch up to 8 input streams into consecutive virtual registers (program prologue only)
+	VVM_DOP_ACQUIRE = 192, // acquireindex; every opcode from here on produces no register result
 	VVM_DOP_OUTPUT32 = 193, // up to 3 (src,dst) pairs of outputdata_float / outputdata_int32
 	VVM_DOP_OUTPUT16 = 194, // up to 3 pairs of outputdata_half (float register -> half stream)
 	VVM_DOP_OUTPUT16_FROM16 = 195,
@@ -37,7 +40,7 @@ enum : uint32_t {
 // Device instruction, 16 bytes:
 //   w0: op[0:8) nin[8:11) nout[11:13) aux[16:24) aux2[24:32)
 //   w1: o0 | o1 << 16      w2: o2 | o3 << 16      w3: o4 | o5 << 16
-// For ordinary ops the inputs are o0.. in order and the outputs are o5 (first) and o4 (second).
+// Ordinary ops have exactly one destination: the inputs are o0.. in order and the destination is o5.
 struct VvmIns {
 	uint32_t w0, w1, w2, w3;
 };
@@ -60,7 +63,8 @@ struct VvmExecDesc {
 	uint32_t rand_seed_lo, rand_seed_hi;
 	int32_t  rand_instance_base;
 	uint32_t flags;
-	uint32_t pad[2];
+	uint32_t num_unif;             // constants copied into uniform registers, a multiple of 4 (the table is padded)
+	uint32_t pad[1];
 };
 
 enum : uint32_t {

@@ -261,8 +261,10 @@ int fill_params(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* op
 	d->rand_seed_hi = opt ? (uint32_t)(opt->RandSeed >> 32) : 0;
 	d->rand_instance_base = opt ? opt->RandInstanceBase : 0;
 	d->flags = lp.uses_perlin ? VVM_DESC_USES_PERLIN : 0;
+	d->num_unif = std::min<uint32_t>((s.num_consts + 3u) & ~3u, VVM_MAX_UNIFORMS);   // off_in is 16-aligned, so the table is padded
 
 	uint32_t* consts = (uint32_t*)(host + pe.off_consts);                                               // RT.cpp:2204-2207
+	memset(consts, 0, pe.off_in - pe.off_consts);
 	for (uint32_t i = 0; i < s.num_consts; ++i) {
 		const uint8_t* table = ctx->ConstantTableData[st->const_table[i]];
 		memcpy(&consts[i], table + 4u * (size_t)st->const_dword[i], 4);
@@ -603,6 +605,20 @@ VVM_API int vvm_inspect_blob(const uint8_t* blob, size_t num_bytes, vvm_program_
 	if (rc != VVM_OK) return fail(rc, err);
 	fill_info(s, lp, out);
 	return VVM_OK;
+}
+
+VVM_API int vvm_inspect_code(const uint8_t* blob, size_t num_bytes, int narrow, uint32_t* out_words, int32_t capacity_instructions)
+{
+	vvm::ThawedScript s;
+	vvm::LinkedProgram lp;
+	std::string err;
+	int rc = vvm::thaw_blob(blob, num_bytes, s, err);
+	if (rc == VVM_OK) rc = vvm::link_program(s, narrow != 0, lp, err);
+	if (rc != VVM_OK) { fail(rc, err); return -rc; }
+	const int32_t n = (int32_t)lp.code.size();
+	if (out_words && capacity_instructions > 0)
+		memcpy(out_words, lp.code.data(), sizeof(VvmIns) * (size_t)std::min(n, capacity_instructions));
+	return n;
 }
 
 VVM_API void* vvm_device_alloc(size_t num_bytes)

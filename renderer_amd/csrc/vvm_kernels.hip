@@ -359,6 +359,26 @@ __device__ __noinline__ void curl_noise3(const uint8_t* P, float x, float y, flo
 	oz = (p1_dx - p0_dy) * inv2e;
 }
 
+// one component of curl_noise3 (0 = x, 1 = y, 2 = z): four Perlin evaluations, same arithmetic as the full form
+__device__ __noinline__ float curl_noise3_component(const uint8_t* P, float x, float y, float z, uint32_t which)
+{
+	const float e = 0.015625f, inv2e = 32.0f;
+	const float o1x = 31.416f, o1y = -47.853f, o1z = 12.793f;
+	const float o2x = -233.145f, o2y = -113.408f, o2z = -185.31f;
+	if (which == 0) {
+		const float p2_dy = perlin3(P, x + o2x, (y + e) + o2y, z + o2z) - perlin3(P, x + o2x, (y - e) + o2y, z + o2z);
+		const float p1_dz = perlin3(P, x + o1x, y + o1y, (z + e) + o1z) - perlin3(P, x + o1x, y + o1y, (z - e) + o1z);
+		return (p2_dy - p1_dz) * inv2e;
+	} else if (which == 1) {
+		const float p0_dz = perlin3(P, x, y, z + e) - perlin3(P, x, y, z - e);
+		const float p2_dx = perlin3(P, (x + e) + o2x, y + o2y, z + o2z) - perlin3(P, (x - e) + o2x, y + o2y, z + o2z);
+		return (p0_dz - p2_dx) * inv2e;
+	}
+	const float p1_dx = perlin3(P, (x + e) + o1x, y + o1y, z + o1z) - perlin3(P, (x - e) + o1x, y + o1y, z + o1z);
+	const float p0_dy = perlin3(P, x, y + e, z) - perlin3(P, x, y - e, z);
+	return (p1_dx - p0_dy) * inv2e;
+}
+
 // ---- wave helpers --------------------------------------------------------------------------------------
 DEV uint32_t lanes_below(u64 m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 DEV uint32_t wave_sum(uint32_t v)
@@ -461,13 +481,13 @@ template <int V> DEV void load_stream16(const Ctx& c, uint64_t base, uint32_t (&
 	}
 }
 
-// operand fetch; the class and index are wave-uniform, so every branch below is a scalar branch
-template <int V, bool SPILL> DEV void fetch(CREGS, const Ctx& c, uint32_t o, float (&out)[V])
+// Operand fetch.  The class and the index are wave-uniform, so every branch below is a scalar branch.  Two classes cover
+// almost every operand of a linked program and are tested first: a per-lane register (GPR-index read) and a uniform register
+// (constants, copied once per tile into the vector U: one VGPR each, read by GPR index, no memory access).
+template <int V> DEV void fetch_slow(const Ctx& c, uint32_t o, float (&out)[V])
 {
 	const uint32_t cls = VVM_OPND_CLS(o), idx = VVM_OPND_IDX(o);
-	if (cls == VVM_OPC_VREG) {
-		reg_read<V, SPILL>(RARGS, c, idx, out);
-	} else if (cls == VVM_OPC_CONST) {
+	if (cls == VVM_OPC_CONST) {
 		const float v = bitsf(sload32(c.consts, idx));
 #pragma unroll
 		for (int k = 0; k < V; ++k) out[k] = v;
@@ -489,6 +509,18 @@ template <int V, bool SPILL> DEV void fetch(CREGS, const Ctx& c, uint32_t o, flo
 	} else {
 #pragma unroll
 		for (int k = 0; k < V; ++k) out[k] = 0.0f;
+	}
+}
+template <int V, bool SPILL> DEV void fetch(CREGS, vec32f U, const Ctx& c, uint32_t o, float (&out)[V])
+{
+	if (o < (1u << 13)) {                       // VVM_OPC_VREG
+		reg_read<V, SPILL>(RARGS, c, o, out);
+	} else if (o < (2u << 13)) {                // VVM_OPC_UNIF
+		const float v = vget(U, o & 31u);
+#pragma unroll
+		for (int k = 0; k < V; ++k) out[k] = v;
+	} else {
+		fetch_slow<V>(c, o, out);
 	}
 }
 
@@ -535,7 +567,7 @@ struct KernelEnv {
 	uint32_t total_tiles;
 	VvmLaunchState* ls;
 	uint32_t lds_spill_slots;
-	uint32_t debug_skip;     // bring-up aid (VVM_DEBUG_SKIP): bit 0 tiles, 1 stream loads, 2 look-back words, 3 stream stores, 4 counts
+	uint32_t debug_skip;     // bring-up aid (VVM_DEBUG_SKIP): bit 0 tiles, 1 stream loads, 2 look-back words, 3 stream stores, 4 counts, 5 look-back (assume no deaths)
 };
 
 // ------------------------------------------------------------------------------------------------------
@@ -547,6 +579,13 @@ DEV void run_tile(const VvmExecDesc& d, const Ctx& c, uint32_t* lds_ctrl, uint32
 	t.keep = 0; t.rank = 0; t.block_total = 0; t.out_base = 0; t.acquired_ds = ~0u;
 	const uint32_t lane = c.tid & 63u, wave = c.tid >> 6;
 	const VvmIns* prog = d.prog;
+
+	// Uniform registers: the first constants of the script, one VGPR each (the table is padded to a multiple of four).
+	vec32f U = 0.0f;
+	for (uint32_t i = 0; i < d.num_unif; i += 4) {
+		const uint32_t c0 = sload32(c.consts, i), c1 = sload32(c.consts, i + 1), c2 = sload32(c.consts, i + 2), c3 = sload32(c.consts, i + 3);
+		U = vset(U, i, bitsf(c0)); U = vset(U, i + 1, bitsf(c1)); U = vset(U, i + 2, bitsf(c2)); U = vset(U, i + 3, bitsf(c3));
+	}
 
 	// Prologue: the program starts with its VVM_DOP_LOADN instructions.  They run in a loop of their own so that the main
 	// loop below has exactly one place that inserts into the register vectors (with two, the compiler keeps a second copy
@@ -579,26 +618,30 @@ DEV void run_tile(const VvmExecDesc& d, const Ctx& c, uint32_t* lds_ctrl, uint32
 
 	}
 
-	for (uint32_t pc = pc0;; ++pc) {
-		VvmIns ins;
-		ins.w0 = sload32(prog, pc * 4 + 0); ins.w1 = sload32(prog, pc * 4 + 1);
-		ins.w2 = sload32(prog, pc * 4 + 2); ins.w3 = sload32(prog, pc * 4 + 3);
+	// Main loop.  The next instruction is fetched while the current one executes.  Every instruction, whatever its kind, ends
+	// at the single register write below: each device instruction has exactly one destination register (the linker splits the
+	// reference's two-output ops and the three-output noise built-in), and an instruction without a result writes register 0
+	// back to itself.  With one insert site per loop the register vectors stay in place; a second one makes the compiler keep
+	// a copy of the whole register file.
+	VvmIns nxt;
+	nxt.w0 = sload32(prog, pc0 * 4 + 0); nxt.w1 = sload32(prog, pc0 * 4 + 1);
+	nxt.w2 = sload32(prog, pc0 * 4 + 2); nxt.w3 = sload32(prog, pc0 * 4 + 3);
+	for (uint32_t pc = pc0 + 1;; ++pc) {
+		const VvmIns ins = nxt;
+		nxt.w0 = sload32(prog, pc * 4 + 0); nxt.w1 = sload32(prog, pc * 4 + 1);
+		nxt.w2 = sload32(prog, pc * 4 + 2); nxt.w3 = sload32(prog, pc * 4 + 3);
 		const uint32_t w0 = ins.w0;
-		const uint32_t op = w0 & 0xFFu, nin = (w0 >> 8) & 7u, nout = (w0 >> 11) & 3u, aux = (w0 >> 16) & 0xFFu, aux2 = w0 >> 24;
+		const uint32_t op = w0 & 0xFFu, nin = (w0 >> 8) & 7u, aux = (w0 >> 16) & 0xFFu, aux2 = w0 >> 24;
 		const uint32_t o0 = ins.w1 & 0xFFFFu, o1 = ins.w1 >> 16, o2 = ins.w2 & 0xFFFFu, o3 = ins.w2 >> 16, o4 = ins.w3 & 0xFFFFu, o5 = ins.w3 >> 16;
 		if (op == VVM_OP_done) break;
 
-		// results of this instruction, written to registers at the single write site at the end of the loop body; instructions
-		// that produce none leave the enables false (the write site then re-inserts the old element values)
-		float r[V], r2[V], r3[V];
-		bool w1 = false, w2 = false, w3 = false;
-		uint32_t d1 = 0, d2 = 0, d3 = 0;
-#pragma unroll
-		for (int k = 0; k < V; ++k) { r[k] = 0.0f; r2[k] = 0.0f; r3[k] = 0.0f; }
-		if (op == VVM_OP_acquireindex) {
+		float r[V];
+		uint32_t dst = 0;
+		if (op >= VVM_DOP_ACQUIRE) reg_read<V, SPILL>(RARGS, c, 0, r);
+		if (op == VVM_DOP_ACQUIRE) {
 			// sign bit of the predicate = keep (VectorVMRuntime.cpp:838-841); instances past the end never survive (:846-857)
 			float p[V];
-			fetch<V, SPILL>(RARGS, c, o0, p);
+			fetch<V, SPILL>(RARGS, U, c, o0, p);
 			uint32_t kb = 0;
 #pragma unroll
 			for (int k = 0; k < V; ++k)
@@ -630,7 +673,7 @@ DEV void run_tile(const VvmExecDesc& d, const Ctx& c, uint32_t* lds_ctrl, uint32
 			} else {
 				if (c.tid == 0) __hip_atomic_store(status + tile_local, ((u64)tag << 34) | (VVM_LB_AGGREGATE << 32) | total, RLX_AGENT);
 				if (wave == 0) {
-					const uint32_t ex = look_back(status, tile_local, tag, lane, error_word);
+					const uint32_t ex = (dbg & 32u) ? tile_local * (VVM_BLOCK_THREADS * V) : look_back(status, tile_local, tag, lane, error_word);
 					if (lane == 0) {
 						lds_ctrl[9] = ex;
 						__hip_atomic_store(status + tile_local, ((u64)tag << 34) | (VVM_LB_INCLUSIVE << 32) | (ex + total), RLX_AGENT);
@@ -657,7 +700,7 @@ DEV void run_tile(const VvmExecDesc& d, const Ctx& c, uint32_t* lds_ctrl, uint32
 				const uint64_t base = sload64(c.out_ptrs, dst);
 				if (base == 0 || total == 0 || (dbg & 8u)) continue;
 				float v[V];
-				fetch<V, SPILL>(RARGS, c, src, v);
+				fetch<V, SPILL>(RARGS, U, c, src, v);
 				if (op == VVM_DOP_OUTPUT32) {
 					float* p = (float*)base + t.out_base;
 					if (all_alive) {
@@ -690,20 +733,22 @@ DEV void run_tile(const VvmExecDesc& d, const Ctx& c, uint32_t* lds_ctrl, uint32
 		}
 
 		else {
-		// ---- ordinary ops: fetch nin operands, compute, write nout registers ----
+		// ---- ordinary ops: fetch nin operands, compute one result ----
 		// The instance index is made opaque once per instruction: otherwise everything the index-dependent cases derive from it
 		// (hash rounds of the random ops, int->float conversions of exec_index) is hoisted out of the interpreter loop and
 		// held in registers for the whole tile by every script, whether it has such an op or not.
 		uint32_t inst_i = c.inst0;
 		asm volatile("" : "+v"(inst_i));
+		// operands an instruction does not have hold an arbitrary value; saying so explicitly keeps them from becoming values
+		// carried around the interpreter loop
 		float a[V], b[V], cc[V], dd[V], ee[V];
-		w1 = true; w2 = (nout == 2);
-		d1 = VVM_OPND_IDX(o5); d2 = VVM_OPND_IDX(o4);
-		if (nin > 0) fetch<V, SPILL>(RARGS, c, o0, a);
-		if (nin > 1) fetch<V, SPILL>(RARGS, c, o1, b);
-		if (nin > 2) fetch<V, SPILL>(RARGS, c, o2, cc);
-		if (nin > 3) fetch<V, SPILL>(RARGS, c, o3, dd);
-		if (nin > 4) fetch<V, SPILL>(RARGS, c, o4, ee);
+#pragma unroll
+		for (int k = 0; k < V; ++k) { a[k] = __builtin_nondeterministic_value(0.0f); b[k] = a[k]; cc[k] = a[k]; dd[k] = a[k]; ee[k] = a[k]; }
+		dst = o5;
+		if (nin > 0) fetch<V, SPILL>(RARGS, U, c, o0, a);
+		if (nin > 1) fetch<V, SPILL>(RARGS, U, c, o1, b);
+		if (nin > 2) fetch<V, SPILL>(RARGS, U, c, o2, cc);
+		if (nin > 3) { fetch<V, SPILL>(RARGS, U, c, o3, dd); if (nin > 4) fetch<V, SPILL>(RARGS, U, c, o4, ee); }
 
 #define LANES for (int k = 0; k < V; ++k)
 #define A a[k]
@@ -789,8 +834,7 @@ DEV void run_tile(const VvmExecDesc& d, const Ctx& c, uint32_t* lds_ctrl, uint32
 		case VVM_OP_f2b: SETM(A > 0.0f);
 		case VVM_OP_b2f: SETF(f_sel(A, 1.0f, 0.0f));
 		case VVM_OP_i2b: SETM(IA > 0);
-		case VVM_OP_b2i: case VVM_OP_b2i_2x: SETI(UA & 1u);
-		case VVM_OP_mul_2x: SETF(A * B);
+		case VVM_OP_b2i: SETI(UA & 1u);
 		// merged ops, VectorVMRuntime.cpp:1999-2074
 		case VVM_OP_cmplt_select: SETF(f_sel(mask(A < B), C, D));
 		case VVM_OP_cmple_select: SETF(f_sel(mask(A <= B), C, D));
@@ -864,7 +908,7 @@ DEV void run_tile(const VvmExecDesc& d, const Ctx& c, uint32_t* lds_ctrl, uint32
 		case VVM_OP_max_f2i: SETI(cvtt(f_max(A, B)));
 		case VVM_OP_select_mul: SETF(f_sel(A, B, C) * D);
 		case VVM_OP_select_add: SETF(f_sel(A, B, C) + D);
-		case VVM_OP_sin_cos: if constexpr (FULL) { _Pragma("unroll") LANES f_sincos(A, r[k], r2[k]); } break;
+		case VVM_OP_sin_cos: if constexpr (FULL) { _Pragma("unroll") LANES { float sn, cs; f_sincos(A, sn, cs); r[k] = aux ? cs : sn; } } break;   // aux: 0 sine, 1 cosine
 		case VVM_OP_half_to_float: SETF(load_half(UA));             // RT.cpp:1113-1127
 		case VVM_OP_exec_index: SETI((uint32_t)d.exec_index_base + inst_i + k);                       // RT.cpp:880-900
 		case VVM_OP_exec_indexf: SETF(i2f((int32_t)((uint32_t)d.exec_index_base + inst_i + k)));      // RT.cpp:902-923
@@ -873,22 +917,12 @@ DEV void run_tile(const VvmExecDesc& d, const Ctx& c, uint32_t* lds_ctrl, uint32
 		case VVM_OP_random: SETF(rand01(rand_u32(d.rand_seed_lo, d.rand_seed_hi, (uint32_t)d.rand_instance_base + inst_i + k, aux2)) * A);
 		case VVM_OP_randomi: SETI(cvtt(rand01(rand_u32(d.rand_seed_lo, d.rand_seed_hi, (uint32_t)d.rand_instance_base + inst_i + k, aux2)) * i2f(IA)));
 		case VVM_OP_random_add: SETF(rand01(rand_u32(d.rand_seed_lo, d.rand_seed_hi, (uint32_t)d.rand_instance_base + inst_i + k, aux2)) * A + B);
-		case VVM_OP_random_2x: { _Pragma("unroll") LANES {
-			r[k] = rand01(rand_u32(d.rand_seed_lo, d.rand_seed_hi, (uint32_t)d.rand_instance_base + inst_i + k, aux2)) * A;
-			r2[k] = rand01(rand_u32(d.rand_seed_lo, d.rand_seed_hi, (uint32_t)d.rand_instance_base + inst_i + k, aux2 + 1u)) * A; } } break;
 		case VVM_OP_external_func_call:
-			// aux = built-in id; operands in order: inputs o0..o2, then outputs o3, o4, o5 (VectorVMRuntime.cpp:1450-1464);
-			// an output the script does not use is the dummy register class
+			// aux = built-in id, aux2 = which output this device instruction produces (VectorVMRuntime.cpp:1450-1464 lists the
+			// operands as inputs then outputs; the linker emits one instruction per output in use)
 			if constexpr (FULL) {
-				if (aux == VVM_EXTFN_PERLIN3) {
-					_Pragma("unroll") LANES r[k] = perlin3(c.perlin_lds, A, B, C);
-					w1 = VVM_OPND_CLS(o3) == VVM_OPC_VREG; d1 = VVM_OPND_IDX(o3); w2 = false;
-				} else if (aux == VVM_EXTFN_CURL_NOISE3) {
-					_Pragma("unroll") LANES curl_noise3(c.perlin_lds, A, B, C, r[k], r2[k], r3[k]);
-					w1 = VVM_OPND_CLS(o3) == VVM_OPC_VREG; d1 = VVM_OPND_IDX(o3);
-					w2 = VVM_OPND_CLS(o4) == VVM_OPC_VREG; d2 = VVM_OPND_IDX(o4);
-					w3 = VVM_OPND_CLS(o5) == VVM_OPC_VREG; d3 = VVM_OPND_IDX(o5);
-				} else { w1 = false; w2 = false; }
+				if (aux == VVM_EXTFN_PERLIN3) { _Pragma("unroll") LANES r[k] = perlin3(c.perlin_lds, A, B, C); }
+				else { _Pragma("unroll") LANES r[k] = curl_noise3_component(c.perlin_lds, A, B, C, aux2); }
 			}
 			break;
 		default: { _Pragma("unroll") LANES r[k] = 0.0f; } break;
@@ -908,17 +942,9 @@ DEV void run_tile(const VvmExecDesc& d, const Ctx& c, uint32_t* lds_ctrl, uint32
 #undef SETF
 #undef SETI
 #undef SETM
-		if (nout == 2) {
-			if (op == VVM_OP_mul_2x || op == VVM_OP_b2i_2x) {
-#pragma unroll
-				for (int k = 0; k < V; ++k) r2[k] = r[k];
-			}
-		}
 		}
 		// the one place where the main loop writes registers
-		if constexpr (FULL) REG_WRITE_IF(w3, d3, r3);
-		REG_WRITE_IF(w2, d2, r2);
-		REG_WRITE_IF(w1, d1, r);
+		REG_WRITE(VVM_OPND_IDX(dst), r);
 	}
 }
 
@@ -970,6 +996,7 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (FULL ? 2 : (V == 4 ? 3 : 8
 			d.rand_seed_hi = sload32(dp, offsetof(VvmExecDesc, rand_seed_hi) / 4);
 			d.rand_instance_base = (int32_t)sload32(dp, offsetof(VvmExecDesc, rand_instance_base) / 4);
 			d.flags = sload32(dp, offsetof(VvmExecDesc, flags) / 4);
+			d.num_unif = sload32(dp, offsetof(VvmExecDesc, num_unif) / 4);
 		}
 		const uint32_t tile_local = ticket - d.first_tile;
 		const uint32_t tile_first = tile_local * (VVM_BLOCK_THREADS * V);

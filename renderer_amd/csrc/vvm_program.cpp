@@ -284,6 +284,24 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 			touch(r);
 		}
 	}
+	// A device instruction has one destination, so the reference's multi-output instructions are split.  The reference reads
+	// all inputs before it writes any output (per 4 lanes); when more than one destination is also an input of the same
+	// instruction, all but the last of those are computed into scratch registers and copied afterwards.
+	uint32_t max_scratch = 0;
+	for (const Decoded& d : ins) {
+		if (d.out.size() < 2 || (d.kind != K_ORD && d.kind != K_EXTFN)) continue;
+		uint32_t aliasing = 0;
+		for (size_t i = 0; i < d.out.size(); ++i) {
+			if (d.out[i] == VVM_INVALID_REG) continue;
+			bool later_same = false;
+			for (size_t j = i + 1; j < d.out.size(); ++j) later_same |= d.out[j] == d.out[i];
+			if (later_same) continue;
+			if (std::find(d.in.begin(), d.in.end(), d.out[i]) != d.in.end()) ++aliasing;
+		}
+		if (aliasing > 1) max_scratch = std::max(max_scratch, aliasing - 1);
+	}
+	const uint32_t scratch0 = nv;
+	for (uint32_t i = 0; i < max_scratch; ++i) { ++nv; vreg_uses.push_back(1); }
 	if (lp.uses_ids) { err = "update_id / acquire_id are not implemented by the GPU executor yet"; return VVM_E_UNSUPPORTED_OP; }
 	uint32_t acquired = 0;
 	for (uint8_t a : lp.acquires_dataset) acquired += a;
@@ -336,7 +354,7 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 	auto operand = [&](uint16_t r) -> uint32_t {
 		if (r == VVM_INVALID_REG) return VVM_OPND(VVM_OPC_NONE, 0);
 		if (r < T) return VVM_OPND(VVM_OPC_VREG, place[r]);
-		if (r < T + C) return VVM_OPND(VVM_OPC_CONST, r - T);
+		if (r < T + C) return (r - T < VVM_MAX_UNIFORMS) ? VVM_OPND(VVM_OPC_UNIF, r - T) : VVM_OPND(VVM_OPC_CONST, r - T);
 		if (r < T + C + I) {
 			const uint32_t i = r - (T + C);
 			if (input_vreg[i] >= 0) return VVM_OPND(VVM_OPC_VREG, (uint32_t)input_vreg[i]);
@@ -350,6 +368,34 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 
 	// ---- emit ----
 	lp.code.clear();
+	struct SplitOut { uint16_t reg; uint32_t w0; };
+	// Emits one device instruction per destination of `d` (all share the input operands o[0..4]) in an order that gives the
+	// reference's result: all inputs are read before any output is written, and of two writes to one register the later wins.
+	auto emit_split = [&](const Decoded& d, std::vector<SplitOut>& outs, const uint32_t* o) {
+		std::vector<SplitOut> plain, aliasing;
+		for (size_t i = 0; i < outs.size(); ++i) {
+			bool later_same = false;
+			for (size_t j = i + 1; j < outs.size(); ++j) later_same |= outs[j].reg == outs[i].reg;
+			if (later_same) continue;
+			const bool is_input = std::find(d.in.begin(), d.in.end(), outs[i].reg) != d.in.end();
+			(is_input ? aliasing : plain).push_back(outs[i]);
+		}
+		auto put = [&](uint32_t w0, uint32_t dst) {
+			VvmIns k;
+			k.w0 = w0; k.w1 = o[0] | (o[1] << 16); k.w2 = o[2] | (o[3] << 16); k.w3 = o[4] | (dst << 16);
+			lp.code.push_back(k);
+		};
+		for (const SplitOut& so : plain) put(so.w0, operand(so.reg));
+		for (size_t i = 0; i + 1 < aliasing.size(); ++i) put(aliasing[i].w0, VVM_OPND(VVM_OPC_VREG, place[scratch0 + i]));
+		if (!aliasing.empty()) put(aliasing.back().w0, operand(aliasing.back().reg));
+		for (size_t i = 0; i + 1 < aliasing.size(); ++i) {   // copy: x | x
+			const uint32_t src = VVM_OPND(VVM_OPC_VREG, place[scratch0 + i]);
+			VvmIns k;
+			k.w0 = VVM_INS_W0(VVM_OP_bit_or, 2, 1, 0, 0);
+			k.w1 = src | (src << 16); k.w2 = 0; k.w3 = operand(aliasing[i].reg) << 16;
+			lp.code.push_back(k);
+		}
+	};
 	for (size_t i = 0; i < prefetch.size(); i += 8) {
 		const size_t n = std::min<size_t>(8, prefetch.size() - i);
 		uint64_t lo = 0; uint32_t hi = 0;     // eight 12-bit stream indices in 96 bits
@@ -371,21 +417,23 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 		case K_ORD: case K_DST_ONLY: {
 			uint32_t o[6] = {0, 0, 0, 0, 0, 0};
 			for (size_t i = 0; i < d.in.size(); ++i) o[i] = operand(d.in[i]);
-			if (d.out.size() >= 1) o[5] = operand(d.out[0]);
-			if (d.out.size() >= 2) o[4] = operand(d.out[1]);
 			for (size_t i = 0; i < d.out.size(); ++i)
 				if (VVM_OPND_CLS(operand(d.out[i])) != VVM_OPC_VREG) { err = "an op destination is not a temp or output register"; return VVM_E_BAD_BLOB; }
-			uint32_t aux2 = 0;
-			if (d.op == VVM_OP_random || d.op == VVM_OP_randomi || d.op == VVM_OP_random_add) aux2 = rand_ordinal++;
-			else if (d.op == VVM_OP_random_2x) { aux2 = rand_ordinal; rand_ordinal += 2; }
+			// per destination: the single-output device op and its aux / aux2
+			uint32_t op1 = d.op, aux[2] = {0, 0}, aux2[2] = {0, 0};
+			if (d.op == VVM_OP_random || d.op == VVM_OP_randomi || d.op == VVM_OP_random_add) aux2[0] = rand_ordinal++;
+			else if (d.op == VVM_OP_random_2x) { op1 = VVM_OP_random; aux2[0] = rand_ordinal; aux2[1] = rand_ordinal + 1; rand_ordinal += 2; }   // RT.cpp:1079-1111
+			else if (d.op == VVM_OP_mul_2x) op1 = VVM_OP_mul;                                     // RT.cpp:1743-1777
+			else if (d.op == VVM_OP_b2i_2x) op1 = VVM_OP_b2i;                                     // RT.cpp:1875-1904
+			else if (d.op == VVM_OP_sin_cos) aux[1] = 1;                                          // RT.cpp:1491-1516: sine first, cosine second
 			if (rand_ordinal > 255) { err = "more than 255 random draws in one script"; return VVM_E_TOO_LARGE; }
-			k.w0 = VVM_INS_W0(d.op, d.in.size(), d.out.size(), 0, aux2);
-			k.w1 = o[0] | (o[1] << 16); k.w2 = o[2] | (o[3] << 16); k.w3 = o[4] | (o[5] << 16);
-			lp.code.push_back(k);
+			std::vector<SplitOut> outs;
+			for (size_t i = 0; i < d.out.size(); ++i) outs.push_back(SplitOut{d.out[i], VVM_INS_W0(op1, d.in.size(), 1, aux[i], aux2[i])});
+			emit_split(d, outs, o);
 			break;
 		}
 		case K_ACQUIRE:
-			k.w0 = VVM_INS_W0(VVM_OP_acquireindex, 1, 0, d.dataset, 0);
+			k.w0 = VVM_INS_W0(VVM_DOP_ACQUIRE, 1, 0, d.dataset, 0);
 			k.w1 = operand(d.in[0]);
 			lp.code.push_back(k);
 			break;
@@ -415,20 +463,24 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 				err = msg;
 				return VVM_E_UNSUPPORTED_OP;
 			}
+			// one device instruction per output in use; aux = built-in, aux2 = output number (the operands are the inputs followed
+			// by the outputs, RT.cpp:1450-1464; an unused output is the dummy register 0xFFFF)
 			uint32_t o[6] = {0, 0, 0, 0, 0, 0};
 			for (int i = 0; i < 3; ++i) o[i] = operand(d.in[(size_t)i]);
-			for (int i = 0; i < no; ++i) o[3 + i] = operand(d.out[(size_t)i]);
-			for (int i = no; i < 3; ++i) o[3 + i] = VVM_OPND(VVM_OPC_NONE, 0);
-			// aux is patched per Exec with the built-in id; aux2 carries the function index
-			k.w0 = VVM_INS_W0(VVM_OP_external_func_call, 3, 0, no == 1 ? VVM_EXTFN_PERLIN3 : VVM_EXTFN_CURL_NOISE3, d.fn);
-			k.w1 = o[0] | (o[1] << 16); k.w2 = o[2] | (o[3] << 16); k.w3 = o[4] | (o[5] << 16);
-			lp.code.push_back(k);
+			std::vector<SplitOut> outs;
+			for (int i = 0; i < no; ++i) {
+				if (d.out[(size_t)i] == VVM_INVALID_REG) continue;
+				if (VVM_OPND_CLS(operand(d.out[(size_t)i])) != VVM_OPC_VREG) { err = "an external function output is not a temp or output register"; return VVM_E_BAD_BLOB; }
+				outs.push_back(SplitOut{d.out[(size_t)i], VVM_INS_W0(VVM_OP_external_func_call, 3, 1, no == 1 ? VVM_EXTFN_PERLIN3 : VVM_EXTFN_CURL_NOISE3, i)});
+			}
+			emit_split(d, outs, o);
 			break;
 		}
 		default: break;
 		}
 	}
 	lp.code.push_back(VvmIns{VVM_INS_W0(VVM_OP_done, 0, 0, 0, 0), 0, 0, 0});
+	lp.code.push_back(VvmIns{VVM_INS_W0(VVM_OP_done, 0, 0, 0, 0), 0, 0, 0});   // the kernel fetches one instruction ahead
 
 	for (const InputInfo& in : lp.inputs) if (!in.noadvance) lp.bytes_in_per_instance += (in.type == 2) ? 2 : 4;
 	for (uint32_t i = 0; i < s.num_outputs_remapped; ++i) if (s.out_dst[i] != 0xFFFF) lp.bytes_out_per_instance += (s.out_type[i] == 2) ? 2 : 4;
