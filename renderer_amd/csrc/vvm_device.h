@@ -13,7 +13,7 @@
 // ---- operand = class (3 bits) | index (13 bits) ----
 enum : uint32_t {
 	VVM_OPC_VREG  = 0,   // per-lane virtual register: index < resident count -> VGPR, else LDS slot
-	VVM_OPC_UNIF  = 1,   // uniform register: one of the first VVM_MAX_UNIFORMS remapped constants, held in a VGPR vector
+	VVM_OPC_UNIF  = 1,   // uniform register: one of the first VVM_MAX_UNIFORMS remapped constants (lane i of one VGPR holds constant i)
 	VVM_OPC_CONST = 2,   // remapped constant read from the constant table (the ones past the uniform registers)
 	VVM_OPC_INPUT = 3,   // advancing 32-bit input stream, read at the instance index
 	VVM_OPC_NOADV = 4,   // no-advance input: element [InstanceOffset] of the stream, uniform (VectorVMRuntime.cpp:381-401)
@@ -25,7 +25,7 @@ enum : uint32_t {
 #define VVM_OPND_CLS(o)    (((o) >> 13) & 7u)
 #define VVM_OPND_IDX(o)    ((o) & 0x1FFFu)
 #define VVM_MAX_OPND_INDEX 0x1FFFu
-#define VVM_MAX_UNIFORMS   32u
+#define VVM_MAX_UNIFORMS   64u
 
 // ---- device-only opcodes (the reference's opcodes keep their numbers 0..178) ----
 enum : uint32_t {
@@ -50,7 +50,7 @@ struct VvmIns {
 // One Exec (one emitter) as the kernel sees it.  Lives in device memory.
 struct VvmExecDesc {
 	const VvmIns*   prog;
-	const uint32_t* consts;        // NumConstBuffers dwords, remapped order
+	const uint32_t* consts;        // NumConstBuffers dwords, remapped order, zero-padded to at least VVM_MAX_UNIFORMS dwords
 	const uint64_t* in_ptrs;       // byte address of element [InstanceOffset] of every remapped input stream
 	const uint64_t* out_ptrs;      // byte address of element [InstanceOffset] of every output, by output serial index (0 = none)
 	unsigned long long* status;    // one look-back word per tile of this Exec
@@ -63,8 +63,7 @@ struct VvmExecDesc {
 	uint32_t rand_seed_lo, rand_seed_hi;
 	int32_t  rand_instance_base;
 	uint32_t flags;
-	uint32_t num_unif;             // constants copied into uniform registers, a multiple of 4 (the table is padded)
-	uint32_t pad[1];
+	uint32_t pad[2];
 };
 
 enum : uint32_t {
@@ -72,11 +71,22 @@ enum : uint32_t {
 };
 
 // Launch-wide words in device memory; the last block to leave a launch re-arms them for the next one.
+//
+// Tiles are handed out in index order by ticket counters.  A device-scope atomic on ONE address completes about every 13 ns
+// on MI355X (65536 tiles would take 0.85 ms for the tickets alone), so there are VVM_TICKET_CLASSES counters, each on a cache
+// line of its own: workgroup b draws from counter b % classes, and draw c of counter x is tile c * classes + x.  Tiles still
+// start in (nearly) index order, which the look-back relies on, and every tile is claimed by a running workgroup.
+#define VVM_TICKET_CLASSES      16u
+#define VVM_TICKET_STRIDE_BYTES 256u
 struct VvmLaunchState {
-	uint32_t ticket;     // next tile to hand out
+	uint32_t unused;
 	uint32_t done;       // blocks that have left
 	uint32_t epoch;      // tag that makes a look-back word valid for this launch (never 0)
-	uint32_t pad;
+	uint32_t pad;        // error word: set when a look-back gave up
+	// profiling aid, filled only when the launcher's debug bit 7 is set: look-backs, rounds, polls, clocks spent in them
+	unsigned long long stats[6];
+	uint32_t reserved[(VVM_TICKET_STRIDE_BYTES - 64u) / 4u];
+	uint32_t tickets[VVM_TICKET_CLASSES * VVM_TICKET_STRIDE_BYTES / 4u];   // counter x at tickets[x * VVM_TICKET_STRIDE_BYTES / 4]
 };
 
 // look-back word: tag[34:64) | flag[32:34) | value[0:32)

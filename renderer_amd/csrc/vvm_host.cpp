@@ -232,7 +232,7 @@ int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, P
 	pe.tiles = ((uint32_t)ctx->NumInstances + tile - 1) / tile;
 	const uint32_t O = std::max<uint32_t>(s.num_outputs_remapped, s.num_output_instructions);
 	pe.off_consts = align_up(sizeof(VvmExecDesc), 16);
-	pe.off_in = align_up(pe.off_consts + 4u * (size_t)s.num_consts, 16);
+	pe.off_in = align_up(pe.off_consts + 4u * (size_t)std::max<uint32_t>(s.num_consts, VVM_MAX_UNIFORMS), 16);   // the kernel loads VVM_MAX_UNIFORMS dwords unconditionally
 	pe.off_out = align_up(pe.off_in + 8u * (size_t)s.num_inputs, 16);
 	pe.bytes = align_up(pe.off_out + 8u * (size_t)O, 256);
 	return VVM_OK;
@@ -261,7 +261,6 @@ int fill_params(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* op
 	d->rand_seed_hi = opt ? (uint32_t)(opt->RandSeed >> 32) : 0;
 	d->rand_instance_base = opt ? opt->RandInstanceBase : 0;
 	d->flags = lp.uses_perlin ? VVM_DESC_USES_PERLIN : 0;
-	d->num_unif = std::min<uint32_t>((s.num_consts + 3u) & ~3u, VVM_MAX_UNIFORMS);   // off_in is 16-aligned, so the table is padded
 
 	uint32_t* consts = (uint32_t*)(host + pe.off_consts);                                               // RT.cpp:2204-2207
 	memset(consts, 0, pe.off_in - pe.off_consts);
@@ -299,6 +298,15 @@ int fill_params(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* op
 	ctx->Internal.MaxChunksPerBatch = 1;
 	ctx->Internal.MaxInstancesPerChunk = ((uint32_t)ctx->NumInstances + 3u) & ~3u;
 	return VVM_OK;
+}
+
+// fresh launch words: everything zero, epoch 1
+hipError_t reset_launch_state(VvmLaunchState* d)
+{
+	hipError_t e = hipMemset(d, 0, sizeof(VvmLaunchState));
+	if (e != hipSuccess) return e;
+	const uint32_t one = 1;
+	return hipMemcpy(&d->epoch, &one, 4, hipMemcpyHostToDevice);
 }
 
 uint32_t grid_for(uint32_t tiles)
@@ -340,9 +348,8 @@ VVM_API vvm_state* vvm_alloc_state(const uint8_t* blob, size_t num_bytes)
 		if ((e = hipMalloc((void**)&st->d_perlin, 512)) != hipSuccess) return bail(e, "hipMalloc(perlin)");
 		if ((e = hipMemcpy(st->d_perlin, k_perlin_perm_host, 512, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(perlin)");
 	}
-	const VvmLaunchState init{0, 0, 1, 0};
 	if ((e = hipMalloc((void**)&st->d_launch, sizeof(VvmLaunchState))) != hipSuccess) return bail(e, "hipMalloc(launch state)");
-	if ((e = hipMemcpy(st->d_launch, &init, sizeof(init), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(launch state)");
+	if ((e = reset_launch_state(st->d_launch)) != hipSuccess) return bail(e, "reset(launch state)");
 	const size_t ncounts = std::max<uint32_t>(st->script.max_output_dataset, 1) + 4;
 	if ((e = hipMalloc((void**)&st->d_counts, ncounts * 4)) != hipSuccess) return bail(e, "hipMalloc(counts)");
 	if ((e = hipMemset(st->d_counts, 0, ncounts * 4)) != hipSuccess) return bail(e, "hipMemset(counts)");
@@ -414,7 +421,7 @@ VVM_API int vvm_exec_async(vvm_exec_context* ctx, const vvm_exec_options* opt)
 	st->ring.pending[slot] = true;
 	const size_t ncounts = std::max<uint32_t>(st->script.max_output_dataset, 1);
 	HIP_TRY(hipMemcpyAsync(st->h_counts, st->d_counts, ncounts * 4, hipMemcpyDeviceToHost, stream));
-	HIP_TRY(hipMemcpyAsync(st->h_counts + ncounts + 4, st->d_launch, sizeof(VvmLaunchState), hipMemcpyDeviceToHost, stream));
+	HIP_TRY(hipMemcpyAsync(st->h_counts + ncounts + 4, st->d_launch, 64, hipMemcpyDeviceToHost, stream));     // the words up to stats[]
 	return VVM_OK;
 }
 
@@ -427,9 +434,10 @@ VVM_API int vvm_exec_finish(vvm_exec_context* ctx)
 	if (ran) {
 		const size_t ncounts = std::max<uint32_t>(st->script.max_output_dataset, 1);
 		const VvmLaunchState* ls = (const VvmLaunchState*)(st->h_counts + ncounts + 4);
+		if (getenv("VVM_DEBUG_STATS"))
+			fprintf(stderr, "vvm stats (cumulative): lookbacks %llu rounds %llu polls %llu clocks %llu\n", ls->stats[0], ls->stats[1], ls->stats[2], ls->stats[3]);
 		if (ls->pad != 0) {
-			const VvmLaunchState init{0, 0, 1, 0};
-			(void)hipMemcpy(st->d_launch, &init, sizeof(init), hipMemcpyHostToDevice);
+			(void)reset_launch_state(st->d_launch);
 			if (st->d_status) (void)hipMemset(st->d_status, 0, (size_t)st->status_capacity * 8);
 			return fail(VVM_E_HIP, "look-back timed out inside the kernel (a tile never published its count)");
 		}
@@ -500,9 +508,8 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 	if (!g_batch.h_launch) HIP_TRY(hipHostMalloc((void**)&g_batch.h_launch, 8 * sizeof(VvmLaunchState), hipHostMallocDefault));
 	for (size_t g = 0; g < groups.size(); ++g)
 		if (!g_batch.d_launch[g]) {
-			const VvmLaunchState init{0, 0, 1, 0};
 			HIP_TRY(hipMalloc((void**)&g_batch.d_launch[g], sizeof(VvmLaunchState)));
-			HIP_TRY(hipMemcpy(g_batch.d_launch[g], &init, sizeof(init), hipMemcpyHostToDevice));
+			HIP_TRY(reset_launch_state(g_batch.d_launch[g]));
 		}
 
 	// Descriptors of one group are contiguous (the kernel indexes them); their tables follow all descriptors.
@@ -549,7 +556,7 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 		                                       (uint32_t)groups[g].members.size(), groups[g].tiles, g_batch.d_launch[g], groups[g].spill,
 		                                       lp.full_kernel ? 1 : 0, grid_for(groups[g].tiles), g_batch.stream);
 		if (lrc != 0) return hip_fail((hipError_t)lrc, "batched kernel launch");
-		HIP_TRY(hipMemcpyAsync(&g_batch.h_launch[g], g_batch.d_launch[g], sizeof(VvmLaunchState), hipMemcpyDeviceToHost, g_batch.stream));
+		HIP_TRY(hipMemcpyAsync(&g_batch.h_launch[g], g_batch.d_launch[g], 64, hipMemcpyDeviceToHost, g_batch.stream));
 	}
 	for (int i = 0; i < n; ++i) {
 		vvm_state* st = ctxs[i].VVMState;
@@ -559,8 +566,7 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 	HIP_TRY(hipStreamSynchronize(g_batch.stream));
 	for (size_t g = 0; g < groups.size(); ++g)
 		if (groups[g].tiles && g_batch.h_launch[g].pad != 0) {
-			const VvmLaunchState init{0, 0, 1, 0};
-			(void)hipMemcpy(g_batch.d_launch[g], &init, sizeof(init), hipMemcpyHostToDevice);
+			(void)reset_launch_state(g_batch.d_launch[g]);
 			(void)hipMemset(g_batch.d_status, 0, (size_t)g_batch.status_capacity * 8);
 			return fail(VVM_E_HIP, "look-back timed out inside the batched kernel");
 		}

@@ -62,7 +62,7 @@ template <typename VEC> __device__ __forceinline__ float vget(VEC v, uint32_t i)
 template <typename VEC> __device__ __forceinline__ VEC vset(VEC v, uint32_t i, float x) { v[i] = x; return v; }
 
 // LDS carve (dynamic region only, every offset a multiple of 16)
-#define LDS_CTRL_WORDS   32        // uint32: [0..3] wave totals, [8] ticket, [9] prefix, [10] flag
+#define LDS_CTRL_WORDS   32        // uint32: [0..3] wave totals, [9] prefix, [10] ticket
 #define LDS_PERLIN_OFF   128       // 512 bytes
 #define LDS_SPILL_OFF    640
 
@@ -77,10 +77,13 @@ DEV float f_max(float a, float b) { return (a > b) ? a : b; }                  /
 DEV float f_abs(float a) { return bitsf(fbits(a) & 0x7FFFFFFFu); }             // SSE.h:1287-1290
 DEV float f_neg(float a) { return 0.0f - a; }                                  // SSE.h:1311-1314
 DEV float f_mad(float a, float b, float c) { return (a * b) + c; }             // SSE.h:1411-1418 with FMA3 off
-DEV float f_div(float a, float b) { return (f_abs(b) > 1.e-8f) ? (a / b) : 0.0f; }            // RT.cpp:1909
-DEV float f_sqrtg(float a) { return (a > 1.e-8f) ? __fsqrt_rn(a) : 0.0f; }                    // RT.cpp:1914
-DEV float f_rsq(float a) { return (a > 1.e-8f) ? (1.0f / __fsqrt_rn(a)) : 0.0f; }             // RT.cpp:1913, SSE.h:2014-2022
-DEV float f_rcp(float a) { return (f_abs(a) > 1.e-8f) ? __builtin_amdgcn_rcpf(a) : 0.0f; }    // RT.cpp:1912 (hardware estimate, SSE.h:2121-2125)
+// Every helper below computes its value unconditionally and then selects: a lazily evaluated `cond ? f(x) : 0` leaves a
+// per-lane branch in the interpreter loop, and one per-lane branch anywhere in that loop makes the compiler rewrite all of
+// its (wave-uniform) control flow into flag-guarded if-chains.
+DEV float f_div(float a, float b) { const float q = a / b; return (f_abs(b) > 1.e-8f) ? q : 0.0f; }                     // RT.cpp:1909
+DEV float f_sqrtg(float a) { const float q = __fsqrt_rn(a); return (a > 1.e-8f) ? q : 0.0f; }                           // RT.cpp:1914
+DEV float f_rsq(float a) { const float q = 1.0f / __fsqrt_rn(a); return (a > 1.e-8f) ? q : 0.0f; }                      // RT.cpp:1913, SSE.h:2014-2022
+DEV float f_rcp(float a) { const float q = __builtin_amdgcn_rcpf(a); return (f_abs(a) > 1.e-8f) ? q : 0.0f; }           // RT.cpp:1912 (hardware estimate, SSE.h:2121-2125)
 DEV float f_lerp(float a, float b, float c) { return f_mad(b, c, a * (1.0f - c)); }           // VCOMMON.inl:532-536
 DEV float f_clamp(float a, float b, float c) { return f_min(f_max(a, b), c); }                // VCOMMON.inl:495-498
 DEV float f_sign(float a) { return (a >= 0.0f) ? 1.0f : -1.0f; }                              // SSE.h:2911-2915
@@ -93,10 +96,10 @@ __device__ __noinline__ float lib_exp2(float a) { return powf(2.0f, a); }       
 __device__ __noinline__ float lib_log2(float a) { return logf(a) * 1.4426950f; }                // SSE.h:3015-3027, GPM.h:502
 __device__ __noinline__ float lib_tan(float a) { return tanf(a); }                              // SSE.h:3188-3201
 __device__ __noinline__ float lib_atan(float a) { return atanf(a); }                            // SSE.h:3279-3292
-DEV float f_fmod(float a, float b) { return (f_abs(b) <= 1.e-8f) ? 0.0f : lib_fmod(a, b); }   // SSE.h:2867-2886
+DEV float f_fmod(float a, float b) { const float q = lib_fmod(a, b); return (f_abs(b) <= 1.e-8f) ? 0.0f : q; }   // SSE.h:2867-2886
 // _mm_cvttps_epi32 / _mm_cvtps_epi32: 0x80000000 for NaN and out-of-range (SSE.h:3409-3412)
-DEV int32_t cvtt(float a) { return (a >= -2147483648.0f && a < 2147483648.0f) ? (int32_t)a : (int32_t)0x80000000; }
-DEV int32_t cvtr(float a) { return (a >= -2147483648.0f && a < 2147483648.0f) ? __float2int_rn(a) : (int32_t)0x80000000; }
+DEV int32_t cvtt(float a) { const int32_t q = (int32_t)a; return (a >= -2147483648.0f && a < 2147483648.0f) ? q : (int32_t)0x80000000; }
+DEV int32_t cvtr(float a) { const int32_t q = __float2int_rn(a); return (a >= -2147483648.0f && a < 2147483648.0f) ? q : (int32_t)0x80000000; }
 DEV float   i2f(int32_t a) { return (float)a; }                                               // SSE.h:3407
 
 DEV float ue_atan2(float Y, float X)                                                          // GenericPlatformMath.cpp:33-76
@@ -105,7 +108,7 @@ DEV float ue_atan2(float Y, float X)                                            
 	const float ax = f_abs(X), ay = f_abs(Y);
 	const bool ybig = ay > ax;
 	float t0 = ybig ? ay : ax, t1 = ybig ? ax : ay;
-	if (t0 == 0.f) return 0.f;
+	const bool zero = (t0 == 0.f);
 	float t3 = t1 / t0, t4 = t3 * t3;
 	t0 = +7.2128853633444123e-03f;
 	t0 = t0 * t4 + -3.5059680836411644e-02f;
@@ -118,7 +121,7 @@ DEV float ue_atan2(float Y, float X)                                            
 	t3 = ybig ? (0.5f * PI) - t3 : t3;
 	t3 = (X < 0.0f) ? PI - t3 : t3;
 	t3 = (Y < 0.0f) ? -t3 : t3;
-	return t3;
+	return zero ? 0.f : t3;
 }
 DEV float f_acos(float a) { return ue_atan2(f_sqrtg((1.0f - a) * (1.0f + a)), a); }           // RT.cpp:1924
 DEV float f_asin(float a) { return (3.14159265359f * 0.25f) - f_acos(a); }                    // RT.cpp:1925 with :111
@@ -231,8 +234,8 @@ DEV float mf_cos(float x)
 	float y = ((j & 2) == 0) ? (0.0f + ys) : (yc + 0.0f);
 	return bitsf(fbits(y) ^ sign);
 }
-DEV float f_log(float a) { return (a > 0.0f) ? mf_log(a) : 0.0f; }                            // RT.cpp:1919
-DEV float f_pow(float a, float b) { return (a > 1.e-8f) ? mf_exp(mf_log(a) * b) : 0.0f; }     // RT.cpp:1936, SSE.h:1941-1948
+DEV float f_log(float a) { const float q = mf_log(a); return (a > 0.0f) ? q : 0.0f; }                            // RT.cpp:1919
+DEV float f_pow(float a, float b) { const float q = mf_exp(mf_log(a) * b); return (a > 1.e-8f) ? q : 0.0f; }     // RT.cpp:1936, SSE.h:1941-1948
 
 DEV void f_sincos(float a, float& s_out, float& c_out)                                        // SSE.h:3118-3172
 {
@@ -265,9 +268,9 @@ DEV void f_sincos(float a, float& s_out, float& c_out)                          
 
 DEV int32_t i_div(int32_t n, int32_t d)                                                        // RT.cpp:958-973
 {
-	if (d == 0) return 0;
-	if (d == -1 && n == (int32_t)0x80000000) return 0x7FFFFFFF;
-	return n / d;
+	const bool zero = (d == 0), wrap = (d == -1 && n == (int32_t)0x80000000);
+	const int32_t q = n / ((zero || wrap) ? 1 : d);
+	return zero ? 0 : (wrap ? 0x7FFFFFFF : q);
 }
 DEV int32_t i_min(int32_t a, int32_t b) { return a < b ? a : b; }
 DEV int32_t i_max(int32_t a, int32_t b) { return a > b ? a : b; }
@@ -282,8 +285,9 @@ DEV float load_half(uint32_t h)
 	uint32_t u = (h & 0x7fffu) << 13;
 	const uint32_t e = shifted_exp & u;
 	u += (127u - 15u) << 23;
-	if (e == shifted_exp) u += (128u - 16u) << 23;
-	else if (e == 0) { u += 1u << 23; u = fbits(bitsf(u) - bitsf(113u << 23)); }
+	const uint32_t inf_nan = u + ((128u - 16u) << 23);
+	const uint32_t denorm = fbits(bitsf(u + (1u << 23)) - bitsf(113u << 23));
+	u = (e == shifted_exp) ? inf_nan : ((e == 0) ? denorm : u);
 	u |= (h & 0x8000u) << 16;
 	return bitsf(u);
 }
@@ -292,11 +296,11 @@ DEV uint32_t store_half(float x)
 	uint32_t u = fbits(x);
 	const uint32_t f32infty = 255u << 23, f16max = (127u + 16u) << 23, dm = ((127u - 15u) + (23u - 10u) + 1u) << 23;
 	const uint32_t sign = u & 0x80000000u;
-	uint32_t o;
 	u ^= sign;
-	if (u >= f16max) o = (u > f32infty) ? 0x7e00u : 0x7c00u;
-	else if (u < (113u << 23)) { o = (fbits(bitsf(u) + bitsf(dm)) - dm) & 0xFFFFu; }
-	else { const uint32_t odd = (u >> 13) & 1u; u += ((uint32_t)(15 - 127) << 23) + 0xfffu; u += odd; o = (u >> 13) & 0xFFFFu; }
+	const uint32_t o_big = (u > f32infty) ? 0x7e00u : 0x7c00u;
+	const uint32_t o_small = (fbits(bitsf(u) + bitsf(dm)) - dm) & 0xFFFFu;
+	const uint32_t o_norm = ((u + ((uint32_t)(15 - 127) << 23) + 0xfffu + ((u >> 13) & 1u)) >> 13) & 0xFFFFu;
+	const uint32_t o = (u >= f16max) ? o_big : ((u < (113u << 23)) ? o_small : o_norm);
 	return o | (sign >> 16);
 }
 
@@ -392,14 +396,6 @@ DEV uint32_t wave_sum(uint32_t v)
 #define RVEC typename RegTraits<V>::vec
 #define CREGS RVEC R0, RVEC R1, RVEC R2, RVEC R3
 #define RARGS R0, R1, R2, R3
-template <int V>
-struct Tile {
-	uint32_t keep;          // bit k: instance k of this lane survives
-	uint32_t rank;          // tile-local output rank of the lane's first survivor
-	uint32_t block_total;   // survivors in the tile
-	uint32_t out_base;      // exclusive prefix over the Exec's previous tiles
-	uint32_t acquired_ds;   // dataset the acquireindex named, or ~0u
-};
 
 struct Ctx {
 	const uint32_t* consts;
@@ -458,106 +454,207 @@ template <int V, bool SPILL> DEV void reg_spill(const Ctx& c, bool enable, uint3
 	} while (0)
 #define REG_WRITE(idx, arr) REG_WRITE_IF(true, idx, arr)
 
+// ---- stream access ------------------------------------------------------------------------------------
+// The loop that interprets ordinary instructions must not contain a single per-lane branch (see the note at f_div), and an
+// operand fetch can be a stream load.  In the last, partial tile of an Exec the loads therefore clamp the element index to
+// the last instance (num_instances >= 1 whenever a tile exists) and select zero for the instances past the end.
 template <int V> DEV void load_stream32(const Ctx& c, uint64_t base, float (&out)[V])
 {
-	const float* p = (const float*)base + c.inst0;
 	if (c.full) {
+		const float* p = (const float*)base + c.inst0;
 		if constexpr (V == 4) { const f4u v = *(const f4u*)p; out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w; }
 		else out[0] = p[0];
 	} else {
 #pragma unroll
-		for (int k = 0; k < V; ++k) out[k] = (c.inst0 + k < c.num_instances) ? p[k] : 0.0f;
+		for (int k = 0; k < V; ++k) {
+			const uint32_t i = c.inst0 + k;
+			const float x = ((const float*)base)[min(i, c.num_instances - 1u)];
+			out[k] = (i < c.num_instances) ? x : 0.0f;
+		}
 	}
 }
-template <int V> DEV void load_stream16(const Ctx& c, uint64_t base, uint32_t (&out)[V])
+template <int V> DEV void load_stream16(const Ctx& c, uint64_t base, float (&out)[V])    // raw half bits, zero-extended
 {
-	const uint16_t* p = (const uint16_t*)base + c.inst0;
 	if (c.full) {
-		if constexpr (V == 4) { const h4u v = *(const h4u*)p; out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w; }
-		else out[0] = p[0];
+		const uint16_t* p = (const uint16_t*)base + c.inst0;
+		if constexpr (V == 4) { const h4u v = *(const h4u*)p; out[0] = bitsf(v.x); out[1] = bitsf(v.y); out[2] = bitsf(v.z); out[3] = bitsf(v.w); }
+		else out[0] = bitsf(p[0]);
 	} else {
 #pragma unroll
-		for (int k = 0; k < V; ++k) out[k] = (c.inst0 + k < c.num_instances) ? p[k] : 0u;
+		for (int k = 0; k < V; ++k) {
+			const uint32_t i = c.inst0 + k;
+			const uint32_t x = ((const uint16_t*)base)[min(i, c.num_instances - 1u)];
+			out[k] = bitsf((i < c.num_instances) ? x : 0u);
+		}
 	}
+}
+
+// Compacting store of a lane's surviving values: survivor j of the lane goes to element first + j.
+// Out of line on purpose: inlined into the code between the runs of ordinary instructions, its per-lane branches make the
+// compiler treat the interpreter loop as part of one large divergent region and rewrite that loop's branches as well.
+//   kind 0: 32-bit value   1: float -> half   2: low 16 bits as they are   3: half bits -> float
+// (kind 3 is outputdata_float_from_half, whose handler in the reference is an empty stub, VectorVMRuntime.cpp:573-577)
+__device__ __noinline__ void store_compact(uint32_t kind, uint64_t base, uint32_t first, uint32_t keep, float v0, float v1, float v2, float v3)
+{
+	const float v[4] = {v0, v1, v2, v3};
+	uint32_t r = first;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		if ((keep >> k) & 1u) {
+			if (kind == 0) ((float*)base)[r] = v[k];
+			else if (kind == 3) ((float*)base)[r] = load_half(fbits(v[k]));
+			else ((uint16_t*)base)[r] = (uint16_t)((kind == 1) ? store_half(v[k]) : fbits(v[k]));
+			++r;
+		}
+	}
+}
+
+// Decoupled look-back over the Exec's tile words; called by wave 0 only.  Returns the exclusive prefix of `tile`.
+// Each round reads the VVM_LB_WINDOW tiles before `first` (VVM_LB_WINDOW / 64 words per lane, all loads in flight together),
+// waits until every one of them carries this launch's tag, and sums the counts back to the nearest tile whose word already
+// holds an inclusive prefix.  The window is sized to the number of tiles that are typically between a tile and the nearest
+// resolved predecessor (tiles start at ~65 per microsecond on a full device and a round trip takes a few microseconds),
+// so that one round is the common case.
+#define VVM_LB_WINDOW 256
+DEV uint32_t look_back(gu64* status, uint32_t tile, uint32_t tag, uint32_t lane, gu32* error_word, uint32_t& rounds, uint32_t& polls)
+{
+	constexpr int WPL = VVM_LB_WINDOW / 64;
+	uint32_t sum = 0;
+	int32_t first = (int32_t)tile - 1;
+	for (;;) {
+		u64 w[WPL];
+		uint32_t spins = 0;
+		++rounds;
+		for (;;) {
+			bool ok = true;
+			++polls;
+#pragma unroll
+			for (int j = 0; j < WPL; ++j) {
+				const int32_t mine = first - (int32_t)lane - 64 * j;
+				const u64 x = __hip_atomic_load(status + max(mine, 0), RLX_AGENT);
+				w[j] = (mine >= 0) ? x : (((u64)tag << 34) | (VVM_LB_INCLUSIVE << 32));     // before the first tile: prefix 0
+				ok = ok && ((uint32_t)(w[j] >> 34) == tag);
+			}
+			if (__all(ok)) break;
+			if (++spins > (1u << 22)) {     // a predecessor never published: give up rather than hang the device
+				__hip_atomic_store(error_word, 1u, RLX_AGENT);
+				return sum;
+			}
+			__builtin_amdgcn_s_sleep(1);
+		}
+		uint32_t acc = 0;
+		bool found = false;
+#pragma unroll
+		for (int j = 0; j < WPL; ++j) {
+			const u64 inc_mask = __ballot(((w[j] >> 32) & 3ull) == VVM_LB_INCLUSIVE);
+			const uint32_t nearest = inc_mask ? (uint32_t)__builtin_ctzll(inc_mask) : 63u;
+			acc += (!found && lane <= nearest) ? (uint32_t)w[j] : 0u;
+			found = found || (inc_mask != 0);
+		}
+		sum += wave_sum(acc);
+		if (found) return sum;
+		first -= VVM_LB_WINDOW;
+	}
+}
+
+// acquireindex, first half: rank the tile's survivors and publish the tile's count.
+// keep_bits: bit k = instance k of the lane survives.  Returns (rank of the lane's first survivor within the tile, survivors
+// in the tile).  Survivors keep instance order (VectorVMRuntime.cpp:786-804, 824-878): a lane's instances are consecutive,
+// lanes are in instance order, so the rank is the number of surviving instances of all lower lanes and waves.
+DEV uint2 acquire_rank_and_publish(uint32_t keep_bits, uint32_t tid, uint32_t* lds_ctrl, gu64* status, uint32_t tile_local,
+                                                       uint32_t tag, uint32_t dbg)
+{
+	const uint32_t lane = tid & 63u, wave = tid >> 6;
+	uint32_t below = 0, wave_total = 0;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		const u64 b = __ballot((keep_bits >> k) & 1u);
+		below += lanes_below(b);
+		wave_total += (uint32_t)__popcll(b);
+	}
+	__syncthreads();
+	if (lane == 0) lds_ctrl[wave] = wave_total;
+	__syncthreads();
+	uint32_t wave_off = 0, total = 0;
+#pragma unroll
+	for (uint32_t w = 0; w < VVM_BLOCK_THREADS / 64; ++w) {
+		const uint32_t x = lds_ctrl[w];
+		wave_off += (w < wave) ? x : 0u;
+		total += x;
+	}
+	if (tid == 0) {
+		// the first tile's count is its inclusive prefix already
+		const u64 flag = (tile_local == 0) ? VVM_LB_INCLUSIVE : VVM_LB_AGGREGATE;
+		if (!(tile_local == 0 && (dbg & 4u))) __hip_atomic_store(status + tile_local, ((u64)tag << 34) | (flag << 32) | total, RLX_AGENT);
+	}
+	return make_uint2(wave_off + below, total);
+}
+
+// acquireindex, second half: the exclusive prefix over the Exec's previous tiles.  Runs when the first output instruction
+// needs it (or at the end of the program), so that the instructions between the acquireindex and the outputs cover the
+// latency of the look-back.  The Exec's last tile also writes the dataset's survivor count.
+DEV uint32_t acquire_resolve_prefix(uint32_t total, uint32_t tid, uint32_t* lds_ctrl, gu64* status, uint32_t tile_local,
+                                                        uint32_t num_tiles, uint32_t tile_instances, uint32_t tag, gu32* error_word,
+                                                        int32_t* count_out, uint32_t dbg)
+{
+	uint32_t base = 0;
+	if (tile_local != 0) {
+		if ((tid >> 6) == 0) {
+			uint32_t rounds = 0, polls = 0;
+			const u64 t0 = (dbg & 128u) ? __builtin_amdgcn_s_memtime() : 0;
+			const uint32_t ex = (dbg & 32u) ? tile_local * tile_instances : look_back(status, tile_local, tag, tid & 63u, error_word, rounds, polls);
+			if (tid == 0) {
+				lds_ctrl[9] = ex;
+				__hip_atomic_store(status + tile_local, ((u64)tag << 34) | (VVM_LB_INCLUSIVE << 32) | (ex + total), RLX_AGENT);
+				if (dbg & 128u) {
+					gu64* st = (gu64*)((char*)error_word + 4);      // VvmLaunchState::stats follows the error word
+					__hip_atomic_fetch_add(st + 0, 1ull, RLX_AGENT);
+					__hip_atomic_fetch_add(st + 1, (u64)rounds, RLX_AGENT);
+					__hip_atomic_fetch_add(st + 2, (u64)polls, RLX_AGENT);
+					__hip_atomic_fetch_add(st + 3, __builtin_amdgcn_s_memtime() - t0, RLX_AGENT);
+				}
+			}
+		}
+		__syncthreads();
+		base = lds_ctrl[9];
+	}
+	if (tile_local + 1 == num_tiles && tid == 0 && !(dbg & 16u)) *count_out = (int32_t)(base + total);
+	return base;
 }
 
 // Operand fetch.  The class and the index are wave-uniform, so every branch below is a scalar branch.  Two classes cover
 // almost every operand of a linked program and are tested first: a per-lane register (GPR-index read) and a uniform register
-// (constants, copied once per tile into the vector U: one VGPR each, read by GPR index, no memory access).
+// (lane i of `uni` holds constant i of the script; a lane read with a uniform index yields it as a scalar).
 template <int V> DEV void fetch_slow(const Ctx& c, uint32_t o, float (&out)[V])
 {
 	const uint32_t cls = VVM_OPND_CLS(o), idx = VVM_OPND_IDX(o);
-	if (cls == VVM_OPC_CONST) {
-		const float v = bitsf(sload32(c.consts, idx));
-#pragma unroll
-		for (int k = 0; k < V; ++k) out[k] = v;
-	} else if (cls == VVM_OPC_INPUT) {
+	if (cls == VVM_OPC_INPUT) {
 		load_stream32<V>(c, sload64(c.in_ptrs, idx), out);
-	} else if (cls == VVM_OPC_NOADV) {
-		const float v = bitsf(sload32((const void*)sload64(c.in_ptrs, idx), 0));
-#pragma unroll
-		for (int k = 0; k < V; ++k) out[k] = v;
-	} else if (cls == VVM_OPC_HALF) {   // raw half bits, zero-extended
-		uint32_t h[V];
-		load_stream16<V>(c, sload64(c.in_ptrs, idx), h);
-#pragma unroll
-		for (int k = 0; k < V; ++k) out[k] = bitsf(h[k]);
-	} else if (cls == VVM_OPC_NOADV_HALF) {   // converted once, like VectorVMRuntime.cpp:388-394
-		const float v = load_half(*(const uint16_t*)sload64(c.in_ptrs, idx));
-#pragma unroll
-		for (int k = 0; k < V; ++k) out[k] = v;
+	} else if (cls == VVM_OPC_HALF) {
+		load_stream16<V>(c, sload64(c.in_ptrs, idx), out);
 	} else {
+		uint32_t u = 0;
+		if (cls == VVM_OPC_CONST) u = sload32(c.consts, idx);
+		else if (cls == VVM_OPC_NOADV) u = sload32((const void*)sload64(c.in_ptrs, idx), 0);      // element [InstanceOffset], VectorVMRuntime.cpp:381-401
+		else if (cls == VVM_OPC_NOADV_HALF) {                                                     // converted once, like VectorVMRuntime.cpp:388-394
+			const uint64_t a = sload64(c.in_ptrs, idx);
+			const uint32_t w = sload32((const void*)(a & ~3ull), 0);
+			u = fbits(load_half((a & 2ull) ? (w >> 16) : (w & 0xFFFFu)));
+		}
 #pragma unroll
-		for (int k = 0; k < V; ++k) out[k] = 0.0f;
+		for (int k = 0; k < V; ++k) out[k] = bitsf(u);
 	}
 }
-template <int V, bool SPILL> DEV void fetch(CREGS, vec32f U, const Ctx& c, uint32_t o, float (&out)[V])
+template <int V, bool SPILL> DEV void fetch(CREGS, uint32_t uni, const Ctx& c, uint32_t o, float (&out)[V])
 {
 	if (o < (1u << 13)) {                       // VVM_OPC_VREG
 		reg_read<V, SPILL>(RARGS, c, o, out);
 	} else if (o < (2u << 13)) {                // VVM_OPC_UNIF
-		const float v = vget(U, o & 31u);
+		const float v = bitsf((uint32_t)__builtin_amdgcn_readlane((int)uni, (int)(o & 63u)));
 #pragma unroll
 		for (int k = 0; k < V; ++k) out[k] = v;
 	} else {
 		fetch_slow<V>(c, o, out);
-	}
-}
-
-// decoupled look-back over the Exec's tile words; called by wave 0 only.  Returns the exclusive prefix.
-DEV uint32_t look_back(gu64* status, uint32_t tile, uint32_t tag, uint32_t lane, gu32* error_word)
-{
-	uint32_t sum = 0;
-	int32_t first = (int32_t)tile - 1;
-	for (;;) {
-		const int32_t mine = first - (int32_t)lane;
-		u64 w = 0;
-		uint32_t spins = 0;
-		for (;;) {
-			bool ok = true;
-			if (mine >= 0) {
-				w = __hip_atomic_load(status + mine, RLX_AGENT);
-				ok = (uint32_t)(w >> 34) == tag;
-			} else {
-				w = ((u64)tag << 34) | (VVM_LB_INCLUSIVE << 32);
-			}
-			if (__all(ok)) break;
-			if (++spins > (1u << 22)) {     // a predecessor never published: give up rather than hang the device
-				if (lane == 0) __hip_atomic_store(error_word, 1u, RLX_AGENT);
-				return sum;
-			}
-			__builtin_amdgcn_s_sleep(2);
-		}
-		const uint32_t val = (uint32_t)w;
-		const bool inclusive = ((w >> 32) & 3ull) == VVM_LB_INCLUSIVE;
-		const u64 inc_mask = __ballot(inclusive);
-		if (inc_mask != 0) {
-			const uint32_t nearest = (uint32_t)__builtin_ctzll(inc_mask);
-			sum += wave_sum(lane <= nearest ? val : 0u);
-			return sum;
-		}
-		sum += wave_sum(val);
-		first -= 64;
 	}
 }
 
@@ -567,25 +664,23 @@ struct KernelEnv {
 	uint32_t total_tiles;
 	VvmLaunchState* ls;
 	uint32_t lds_spill_slots;
-	uint32_t debug_skip;     // bring-up aid (VVM_DEBUG_SKIP): bit 0 tiles, 1 stream loads, 2 look-back words, 3 stream stores, 4 counts, 5 look-back (assume no deaths)
+	uint32_t debug_skip;     // bring-up aid (VVM_DEBUG_SKIP): bit 0 tiles, 1 stream loads, 2 tile-0 look-back word, 3 stream stores, 4 counts, 5 look-back (assume no deaths)
 };
 
 // ------------------------------------------------------------------------------------------------------
 template <int V, bool SPILL, bool FULL>
 DEV void run_tile(const VvmExecDesc& d, const Ctx& c, uint32_t* lds_ctrl, uint32_t tile_local, uint32_t tag, gu32* error_word, uint32_t dbg)
 {
-	Tile<V> t;
 	RVEC R0 = 0.0f, R1 = 0.0f, R2 = 0.0f, R3 = 0.0f;
-	t.keep = 0; t.rank = 0; t.block_total = 0; t.out_base = 0; t.acquired_ds = ~0u;
-	const uint32_t lane = c.tid & 63u, wave = c.tid >> 6;
+	// acquireindex state of the tile: all wave-uniform except keep and rank
+	uint32_t t_keep = 0, t_rank = 0;
+	uint32_t t_total = 0, t_base = 0, t_dataset = ~0u;
+	bool t_pending = false;          // the tile's count is published, its prefix not yet resolved
 	const VvmIns* prog = d.prog;
+	gu64* status = (gu64*)d.status;
 
-	// Uniform registers: the first constants of the script, one VGPR each (the table is padded to a multiple of four).
-	vec32f U = 0.0f;
-	for (uint32_t i = 0; i < d.num_unif; i += 4) {
-		const uint32_t c0 = sload32(c.consts, i), c1 = sload32(c.consts, i + 1), c2 = sload32(c.consts, i + 2), c3 = sload32(c.consts, i + 3);
-		U = vset(U, i, bitsf(c0)); U = vset(U, i + 1, bitsf(c1)); U = vset(U, i + 2, bitsf(c2)); U = vset(U, i + 3, bitsf(c3));
-	}
+	// Uniform registers: lane i holds constant i (the host pads the table to 64 dwords, so the load needs no bound).
+	const uint32_t uni = ((const uint32_t*)c.consts)[c.tid & 63u];
 
 	// Prologue: the program starts with its VVM_DOP_LOADN instructions.  They run in a loop of their own so that the main
 	// loop below has exactly one place that inserts into the register vectors (with two, the compiler keeps a second copy
@@ -597,158 +692,65 @@ DEV void run_tile(const VvmExecDesc& d, const Ctx& c, uint32_t* lds_ctrl, uint32
 		if ((ins.w0 & 0xFFu) != VVM_DOP_LOADN) break;
 		ins.w1 = sload32(prog, pc0 * 4 + 1); ins.w2 = sload32(prog, pc0 * 4 + 2); ins.w3 = sload32(prog, pc0 * 4 + 3);
 		const uint32_t aux = (ins.w0 >> 16) & 0xFFu, aux2 = ins.w0 >> 24;
-		{
-			// aux = count (1..8), aux2 = first destination register; eight 12-bit stream indices in w1..w3
-			float st[8][V];
-			const u64 lo = (u64)ins.w1 | ((u64)ins.w2 << 32);
+		// aux = count (1..8), aux2 = first destination register; eight 12-bit stream indices in w1..w3
+		float st[8][V];
+		const u64 lo = (u64)ins.w1 | ((u64)ins.w2 << 32);
 #pragma unroll
-			for (int j = 0; j < 8; ++j) {
-				if ((uint32_t)j < aux) {
-					const uint32_t idx = (j < 5) ? (uint32_t)(lo >> (12 * j)) & 0xFFFu
-					                    : (j == 5) ? (uint32_t)((lo >> 60) | ((u64)(ins.w3 & 0xFFu) << 4)) & 0xFFFu
-					                               : (ins.w3 >> (8 + 12 * (j - 6))) & 0xFFFu;
-					if (!(dbg & 2u)) load_stream32<V>(c, sload64(c.in_ptrs, idx), st[j]);
-					else { _Pragma("unroll") for (int k = 0; k < V; ++k) st[j][k] = 0.0f; }
-				}
+		for (int j = 0; j < 8; ++j) {
+#pragma unroll
+			for (int k = 0; k < V; ++k) st[j][k] = 0.0f;
+			if ((uint32_t)j < aux && !(dbg & 2u)) {
+				const uint32_t idx = (j < 5) ? (uint32_t)(lo >> (12 * j)) & 0xFFFu
+				                    : (j == 5) ? (uint32_t)((lo >> 60) | ((u64)(ins.w3 & 0xFFu) << 4)) & 0xFFFu
+				                               : (ins.w3 >> (8 + 12 * (j - 6))) & 0xFFFu;
+				load_stream32<V>(c, sload64(c.in_ptrs, idx), st[j]);
 			}
-#pragma unroll
-			for (int j = 0; j < 8; ++j)
-				REG_WRITE_IF((uint32_t)j < aux, aux2 + j, st[j]);
 		}
-
+#pragma unroll
+		for (int j = 0; j < 8; ++j)
+			REG_WRITE_IF((uint32_t)j < aux, aux2 + j, st[j]);
 	}
 
-	// Main loop.  The next instruction is fetched while the current one executes.  Every instruction, whatever its kind, ends
-	// at the single register write below: each device instruction has exactly one destination register (the linker splits the
-	// reference's two-output ops and the three-output noise built-in), and an instruction without a result writes register 0
-	// back to itself.  With one insert site per loop the register vectors stay in place; a second one makes the compiler keep
-	// a copy of the whole register file.
+	// The program is a sequence of runs of ordinary instructions separated by the few special ones (acquireindex, outputs,
+	// the end).  The inner loop interprets one run; all of its control flow is wave-uniform, which the kernel is compiled to
+	// keep as direct scalar branches.  The special instructions, which need per-lane branches (single-lane publishes,
+	// compacting stores), are handled between runs, outside that loop.  The next instruction is always fetched while the
+	// current one executes.
+	//
+	// Every ordinary instruction ends at the single register write at the bottom of the inner loop: each device instruction has
+	// exactly one destination register (the linker splits the reference's two-output ops and the three-output noise
+	// built-in).  With one insert site the register vectors stay in place; a second one makes the compiler keep a copy of the
+	// whole register file.
 	VvmIns nxt;
 	nxt.w0 = sload32(prog, pc0 * 4 + 0); nxt.w1 = sload32(prog, pc0 * 4 + 1);
 	nxt.w2 = sload32(prog, pc0 * 4 + 2); nxt.w3 = sload32(prog, pc0 * 4 + 3);
-	for (uint32_t pc = pc0 + 1;; ++pc) {
-		const VvmIns ins = nxt;
-		nxt.w0 = sload32(prog, pc * 4 + 0); nxt.w1 = sload32(prog, pc * 4 + 1);
-		nxt.w2 = sload32(prog, pc * 4 + 2); nxt.w3 = sload32(prog, pc * 4 + 3);
-		const uint32_t w0 = ins.w0;
-		const uint32_t op = w0 & 0xFFu, nin = (w0 >> 8) & 7u, aux = (w0 >> 16) & 0xFFu, aux2 = w0 >> 24;
-		const uint32_t o0 = ins.w1 & 0xFFFFu, o1 = ins.w1 >> 16, o2 = ins.w2 & 0xFFFFu, o3 = ins.w2 >> 16, o4 = ins.w3 & 0xFFFFu, o5 = ins.w3 >> 16;
-		if (op == VVM_OP_done) break;
+	uint32_t pc = pc0 + 1;
+	for (;;) {
+		uint32_t op, aux, aux2, o0, o1, o2, o3, o4, o5;
+		for (;;) {
+			const VvmIns ins = nxt;
+			nxt.w0 = sload32(prog, pc * 4 + 0); nxt.w1 = sload32(prog, pc * 4 + 1);
+			nxt.w2 = sload32(prog, pc * 4 + 2); nxt.w3 = sload32(prog, pc * 4 + 3);
+			++pc;
+			const uint32_t w0 = ins.w0;
+			op = w0 & 0xFFu; aux = (w0 >> 16) & 0xFFu; aux2 = w0 >> 24;
+			const uint32_t nin = (w0 >> 8) & 7u;
+			o0 = ins.w1 & 0xFFFFu; o1 = ins.w1 >> 16; o2 = ins.w2 & 0xFFFFu; o3 = ins.w2 >> 16; o4 = ins.w3 & 0xFFFFu; o5 = ins.w3 >> 16;
+			if (op - 1u >= VVM_DOP_LOADN - 1u) break;          // done (0) or a special instruction
 
-		float r[V];
-		uint32_t dst = 0;
-		if (op >= VVM_DOP_ACQUIRE) reg_read<V, SPILL>(RARGS, c, 0, r);
-		if (op == VVM_DOP_ACQUIRE) {
-			// sign bit of the predicate = keep (VectorVMRuntime.cpp:838-841); instances past the end never survive (:846-857)
-			float p[V];
-			fetch<V, SPILL>(RARGS, U, c, o0, p);
-			uint32_t kb = 0;
+			float r[V];
+			const uint32_t dst = o5;
+			uint32_t inst_i = c.inst0;
+			asm volatile("" : "+v"(inst_i));
+			// operands an instruction does not have hold an arbitrary value; saying so explicitly keeps them from becoming values
+			// carried around the interpreter loop
+			float a[V], b[V], cc[V], dd[V], ee[V];
 #pragma unroll
-			for (int k = 0; k < V; ++k)
-				if ((fbits(p[k]) >> 31) && (c.inst0 + k < c.num_instances)) kb |= 1u << k;
-			uint32_t below = 0, wave_total = 0;
-#pragma unroll
-			for (int k = 0; k < V; ++k) {
-				const u64 b = __ballot((kb >> k) & 1u);
-				below += lanes_below(b);
-				wave_total += (uint32_t)__popcll(b);
-			}
-			__syncthreads();
-			if (lane == 0) lds_ctrl[wave] = wave_total;
-			__syncthreads();
-			uint32_t wave_off = 0, total = 0;
-#pragma unroll
-			for (uint32_t w = 0; w < VVM_BLOCK_THREADS / 64; ++w) {
-				const uint32_t x = lds_ctrl[w];
-				wave_off += (w < wave) ? x : 0u;
-				total += x;
-			}
-			total = __builtin_amdgcn_readfirstlane(total);
-			t.keep = kb; t.rank = wave_off + below; t.block_total = total; t.acquired_ds = aux;
-			// publish this tile's count, then resolve the prefix over the previous tiles
-			gu64* status = (gu64*)d.status;
-			uint32_t base = 0;
-			if (tile_local == 0) {
-				if (c.tid == 0 && !(dbg & 4u)) __hip_atomic_store(status, ((u64)tag << 34) | (VVM_LB_INCLUSIVE << 32) | total, RLX_AGENT);
-			} else {
-				if (c.tid == 0) __hip_atomic_store(status + tile_local, ((u64)tag << 34) | (VVM_LB_AGGREGATE << 32) | total, RLX_AGENT);
-				if (wave == 0) {
-					const uint32_t ex = (dbg & 32u) ? tile_local * (VVM_BLOCK_THREADS * V) : look_back(status, tile_local, tag, lane, error_word);
-					if (lane == 0) {
-						lds_ctrl[9] = ex;
-						__hip_atomic_store(status + tile_local, ((u64)tag << 34) | (VVM_LB_INCLUSIVE << 32) | (ex + total), RLX_AGENT);
-					}
-				}
-				__syncthreads();
-				base = __builtin_amdgcn_readfirstlane(lds_ctrl[9]);
-			}
-			t.out_base = base;
-			if (tile_local + 1 == d.num_tiles && c.tid == 0 && !(dbg & 16u)) d.counts[aux] = (int32_t)(base + total);
-		}
-
-		else if (op >= VVM_DOP_OUTPUT32 && op <= VVM_DOP_OUTPUT32_FROM16) {
-			// aux = pair count (1..3), aux2 = dataset; pairs (o0,o1) (o2,o3) (o4,o5) = (source, output serial index)
-			const bool mine = (aux2 == t.acquired_ds);
-			const uint32_t total = mine ? t.block_total : 0u;    // no acquireindex for this dataset: nothing is written (VectorVMRuntime.cpp:565, 769)
-			const uint32_t valid = min(c.num_instances - (c.inst0 - c.tid * V), (uint32_t)(VVM_BLOCK_THREADS * V));
-			const bool all_alive = (total == valid) && c.full;
-#pragma unroll
-			for (int j = 0; j < 3; ++j) {
-				if ((uint32_t)j >= aux) break;
-				const uint32_t src = (j == 0) ? o0 : (j == 1) ? o2 : o4;
-				const uint32_t dst = (j == 0) ? o1 : (j == 1) ? o3 : o5;
-				const uint64_t base = sload64(c.out_ptrs, dst);
-				if (base == 0 || total == 0 || (dbg & 8u)) continue;
-				float v[V];
-				fetch<V, SPILL>(RARGS, U, c, src, v);
-				if (op == VVM_DOP_OUTPUT32) {
-					float* p = (float*)base + t.out_base;
-					if (all_alive) {
-						if constexpr (V == 4) { f4u q; q.x = v[0]; q.y = v[1]; q.z = v[2]; q.w = v[3]; *(f4u*)(p + c.tid * 4) = q; }
-						else p[c.tid] = v[0];
-					} else {
-						uint32_t r = t.rank;
-#pragma unroll
-						for (int k = 0; k < V; ++k)
-							if ((t.keep >> k) & 1u) { p[r] = v[k]; ++r; }
-					}
-				} else {
-					uint32_t r = t.rank;
-					if (op == VVM_DOP_OUTPUT32_FROM16) {          // half bits -> float stream (the reference's handler is an empty stub, :573-577)
-						float* p = (float*)base + t.out_base;
-#pragma unroll
-						for (int k = 0; k < V; ++k)
-							if ((t.keep >> k) & 1u) { p[r] = load_half(fbits(v[k])); ++r; }
-					} else {
-						uint16_t* p = (uint16_t*)base + t.out_base;
-#pragma unroll
-						for (int k = 0; k < V; ++k)
-							if ((t.keep >> k) & 1u) {
-								p[r] = (uint16_t)((op == VVM_DOP_OUTPUT16) ? store_half(v[k]) : fbits(v[k]));
-								++r;
-							}
-					}
-				}
-			}
-		}
-
-		else {
-		// ---- ordinary ops: fetch nin operands, compute one result ----
-		// The instance index is made opaque once per instruction: otherwise everything the index-dependent cases derive from it
-		// (hash rounds of the random ops, int->float conversions of exec_index) is hoisted out of the interpreter loop and
-		// held in registers for the whole tile by every script, whether it has such an op or not.
-		uint32_t inst_i = c.inst0;
-		asm volatile("" : "+v"(inst_i));
-		// operands an instruction does not have hold an arbitrary value; saying so explicitly keeps them from becoming values
-		// carried around the interpreter loop
-		float a[V], b[V], cc[V], dd[V], ee[V];
-#pragma unroll
-		for (int k = 0; k < V; ++k) { a[k] = __builtin_nondeterministic_value(0.0f); b[k] = a[k]; cc[k] = a[k]; dd[k] = a[k]; ee[k] = a[k]; }
-		dst = o5;
-		if (nin > 0) fetch<V, SPILL>(RARGS, U, c, o0, a);
-		if (nin > 1) fetch<V, SPILL>(RARGS, U, c, o1, b);
-		if (nin > 2) fetch<V, SPILL>(RARGS, U, c, o2, cc);
-		if (nin > 3) { fetch<V, SPILL>(RARGS, U, c, o3, dd); if (nin > 4) fetch<V, SPILL>(RARGS, U, c, o4, ee); }
+			for (int k = 0; k < V; ++k) { a[k] = __builtin_nondeterministic_value(0.0f); b[k] = a[k]; cc[k] = a[k]; dd[k] = a[k]; ee[k] = a[k]; }
+			if (nin > 0) fetch<V, SPILL>(RARGS, uni, c, o0, a);
+			if (nin > 1) fetch<V, SPILL>(RARGS, uni, c, o1, b);
+			if (nin > 2) fetch<V, SPILL>(RARGS, uni, c, o2, cc);
+			if (nin > 3) { fetch<V, SPILL>(RARGS, uni, c, o3, dd); if (nin > 4) fetch<V, SPILL>(RARGS, uni, c, o4, ee); }
 
 #define LANES for (int k = 0; k < V; ++k)
 #define A a[k]
@@ -765,168 +767,168 @@ DEV void run_tile(const VvmExecDesc& d, const Ctx& c, uint32_t* lds_ctrl, uint32
 #define SETF(expr) { _Pragma("unroll") LANES r[k] = (expr); } break
 #define SETI(expr) { _Pragma("unroll") LANES r[k] = bitsf((uint32_t)(expr)); } break
 #define SETM(expr) { _Pragma("unroll") LANES r[k] = mask(expr); } break
-		switch (op) {
-		case VVM_OP_add: SETF(A + B);
-		case VVM_OP_sub: SETF(A - B);
-		case VVM_OP_mul: SETF(A * B);
-		case VVM_OP_div: SETF(f_div(A, B));
-		case VVM_OP_mad: SETF(f_mad(A, B, C));
-		case VVM_OP_lerp: SETF(f_lerp(A, B, C));
-		case VVM_OP_rcp: SETF(f_rcp(A));
-		case VVM_OP_rsq: SETF(f_rsq(A));
-		case VVM_OP_sqrt: SETF(f_sqrtg(A));
-		case VVM_OP_neg: SETF(f_neg(A));
-		case VVM_OP_abs: SETF(f_abs(A));
-		case VVM_OP_exp: if constexpr (FULL) SETF(mf_exp(A));
-		case VVM_OP_exp2: if constexpr (FULL) SETF(lib_exp2(A));
-		case VVM_OP_log: if constexpr (FULL) SETF(f_log(A));
-		case VVM_OP_log2: if constexpr (FULL) SETF(lib_log2(A));
-		case VVM_OP_sin: if constexpr (FULL) SETF(mf_sin(A));
-		case VVM_OP_cos: if constexpr (FULL) SETF(mf_cos(A));
-		case VVM_OP_tan: if constexpr (FULL) SETF(lib_tan(A));
-		case VVM_OP_asin: if constexpr (FULL) SETF(f_asin(A));
-		case VVM_OP_acos: if constexpr (FULL) SETF(f_acos(A));
-		case VVM_OP_atan: if constexpr (FULL) SETF(lib_atan(A));
-		case VVM_OP_atan2: if constexpr (FULL) SETF(ue_atan2(A, B));
-		case VVM_OP_ceil: SETF(ceilf(A));
-		case VVM_OP_floor: SETF(floorf(A));
-		case VVM_OP_fmod: if constexpr (FULL) SETF(f_fmod(A, B));
-		case VVM_OP_frac: SETF(f_frac(A));
-		case VVM_OP_trunc: SETF(truncf(A));
-		case VVM_OP_clamp: SETF(f_clamp(A, B, C));
-		case VVM_OP_min: SETF(f_min(A, B));
-		case VVM_OP_max: SETF(f_max(A, B));
-		case VVM_OP_pow: if constexpr (FULL) SETF(f_pow(A, B));
-		case VVM_OP_round: SETF(rintf(A));                         // SSE.h:2819-2822 (nearest even)
-		case VVM_OP_sign: SETF(f_sign(A));
-		case VVM_OP_step: SETF(f_step(B - A));                     // RT.cpp:1939
-		case VVM_OP_cmplt: SETM(A < B);
-		case VVM_OP_cmple: SETM(A <= B);
-		case VVM_OP_cmpgt: SETM(A > B);
-		case VVM_OP_cmpge: SETM(A >= B);
-		case VVM_OP_cmpeq: SETM(A == B);
-		case VVM_OP_cmpneq: SETM(A != B);
-		case VVM_OP_select: SETF(f_sel(A, B, C));
-		case VVM_OP_addi: SETI(UA + UB);
-		case VVM_OP_subi: SETI(UA - UB);
-		case VVM_OP_muli: SETI(UA * UB);
-		case VVM_OP_divi: SETI(i_div(IA, IB));
-		case VVM_OP_clampi: SETI(i_min(i_max(IA, IB), IC));
-		case VVM_OP_mini: SETI(i_min(IA, IB));
-		case VVM_OP_maxi: SETI(i_max(IA, IB));
-		case VVM_OP_absi: SETI(i_abs(IA));
-		case VVM_OP_negi: SETI(0u - UA);
-		case VVM_OP_signi: SETI(IA >= 0 ? 1 : -1);
-		case VVM_OP_cmplti: SETM(IA < IB);
-		case VVM_OP_cmplei: SETM(IA <= IB);
-		case VVM_OP_cmpgti: SETM(IA > IB);
-		case VVM_OP_cmpgei: SETM(IA >= IB);
-		case VVM_OP_cmpeqi: SETM(IA == IB);
-		case VVM_OP_cmpneqi: SETM(IA != IB);
-		case VVM_OP_bit_and: case VVM_OP_logic_and: SETI(UA & UB);
-		case VVM_OP_bit_or: case VVM_OP_logic_or: SETI(UA | UB);
-		case VVM_OP_bit_xor: case VVM_OP_logic_xor: SETI(UA ^ UB);
-		case VVM_OP_bit_not: case VVM_OP_logic_not: SETI(~UA);
-		case VVM_OP_bit_lshift: SETI(i_shl(UA, UB));
-		case VVM_OP_bit_rshift: SETI(i_shr(UA, UB));
-		case VVM_OP_f2i: SETI(cvtt(A));
-		case VVM_OP_i2f: SETF(i2f(IA));
-		case VVM_OP_f2b: SETM(A > 0.0f);
-		case VVM_OP_b2f: SETF(f_sel(A, 1.0f, 0.0f));
-		case VVM_OP_i2b: SETM(IA > 0);
-		case VVM_OP_b2i: SETI(UA & 1u);
-		// merged ops, VectorVMRuntime.cpp:1999-2074
-		case VVM_OP_cmplt_select: SETF(f_sel(mask(A < B), C, D));
-		case VVM_OP_cmple_select: SETF(f_sel(mask(A <= B), C, D));
-		case VVM_OP_cmpeq_select: SETF(f_sel(mask(A == B), C, D));
-		case VVM_OP_cmplti_select: SETF(f_sel(mask(IA < IB), C, D));
-		case VVM_OP_cmplei_select: SETF(f_sel(mask(IA <= IB), C, D));
-		case VVM_OP_cmpeqi_select: SETF(f_sel(mask(IA == IB), C, D));
-		case VVM_OP_cmplt_logic_and: SETI((A < B ? ~0u : 0u) & UC);
-		case VVM_OP_cmple_logic_and: SETI((A <= B ? ~0u : 0u) & UC);
-		case VVM_OP_cmpgt_logic_and: SETI((A > B ? ~0u : 0u) & UC);
-		case VVM_OP_cmpge_logic_and: SETI((A >= B ? ~0u : 0u) & UC);
-		case VVM_OP_cmpeq_logic_and: SETI((A == B ? ~0u : 0u) & UC);
-		case VVM_OP_cmpne_logic_and: SETI((A != B ? ~0u : 0u) & UC);
-		case VVM_OP_cmplti_logic_and: SETI((IA < IB ? ~0u : 0u) & UC);
-		case VVM_OP_cmplei_logic_and: SETI((IA <= IB ? ~0u : 0u) & UC);
-		case VVM_OP_cmpgti_logic_and: SETI((IA > IB ? ~0u : 0u) & UC);
-		case VVM_OP_cmpgei_logic_and: SETI((IA >= IB ? ~0u : 0u) & UC);
-		case VVM_OP_cmpeqi_logic_and: SETI((IA == IB ? ~0u : 0u) & UC);
-		case VVM_OP_cmpnei_logic_and: SETI((IA != IB ? ~0u : 0u) & UC);
-		case VVM_OP_cmplt_logic_or: SETI((A < B ? ~0u : 0u) | UC);
-		case VVM_OP_cmple_logic_or: SETI((A <= B ? ~0u : 0u) | UC);
-		case VVM_OP_cmpgt_logic_or: SETI((A > B ? ~0u : 0u) | UC);
-		case VVM_OP_cmpge_logic_or: SETI((A >= B ? ~0u : 0u) | UC);
-		case VVM_OP_cmpeq_logic_or: SETI((A == B ? ~0u : 0u) | UC);
-		case VVM_OP_cmpne_logic_or: SETI((A != B ? ~0u : 0u) | UC);
-		case VVM_OP_cmplti_logic_or: SETI((IA < IB ? ~0u : 0u) | UC);
-		case VVM_OP_cmplei_logic_or: SETI((IA <= IB ? ~0u : 0u) | UC);
-		case VVM_OP_cmpgti_logic_or: SETI((IA > IB ? ~0u : 0u) | UC);
-		case VVM_OP_cmpgei_logic_or: SETI((IA >= IB ? ~0u : 0u) | UC);
-		case VVM_OP_cmpeqi_logic_or: SETI((IA == IB ? ~0u : 0u) | UC);
-		case VVM_OP_cmpnei_logic_or: SETI((IA != IB ? ~0u : 0u) | UC);
-		case VVM_OP_mad_add: SETF(f_mad(A, B, C) + D);
-		case VVM_OP_mad_sub0: SETF(f_mad(A, B, C) - D);
-		case VVM_OP_mad_sub1: SETF(D - f_mad(A, B, C));
-		case VVM_OP_mad_mul: SETF(f_mad(A, B, C) * D);
-		case VVM_OP_mad_sqrt: SETF(__fsqrt_rn(f_mad(A, B, C)));      // unguarded, RT.cpp:2033
-		case VVM_OP_mad_mad0: SETF(f_mad(D, E, f_mad(A, B, C)));
-		case VVM_OP_mad_mad1: SETF(f_mad(f_mad(A, B, C), D, E));
-		case VVM_OP_mul_mad0: SETF(f_mad(A * B, C, D));
-		case VVM_OP_mul_mad1: SETF(f_mad(C, D, A * B));
-		case VVM_OP_mul_add: SETF((A * B) + C);
-		case VVM_OP_mul_sub0: SETF((A * B) - C);
-		case VVM_OP_mul_sub1: SETF(C - (A * B));
-		case VVM_OP_mul_mul: SETF((A * B) * C);
-		case VVM_OP_mul_max: SETF(f_max(A * B, C));
-		case VVM_OP_add_mad1: SETF(f_mad(C, D, A + B));
-		case VVM_OP_add_add: SETF((A + B) + C);
-		case VVM_OP_sub_cmplt1: SETM(C < (A - B));
-		case VVM_OP_sub_neg: SETF(f_neg(A - B));
-		case VVM_OP_sub_mul: SETF((A - B) * C);
-		case VVM_OP_div_mad0: SETF(f_mad(f_div(A, B), C, D));
-		case VVM_OP_div_f2i: SETI(cvtt(f_div(A, B)));
-		case VVM_OP_div_mul: SETF(f_div(A, B) * C);
-		case VVM_OP_muli_addi: SETI(UA * UB + UC);
-		case VVM_OP_addi_bit_rshift: SETI(i_shr(UA + UB, UC));
-		case VVM_OP_addi_muli: SETI((UA + UB) * UC);
-		case VVM_OP_i2f_div0: SETF(f_div(i2f(IA), B));
-		case VVM_OP_i2f_div1: SETF(f_div(B, i2f(IA)));
-		case VVM_OP_i2f_mul: SETF(i2f(IA) * B);
-		case VVM_OP_i2f_mad0: SETF(f_mad(i2f(IA), B, C));
-		case VVM_OP_i2f_mad1: SETF(f_mad(A, B, i2f(IC)));
-		case VVM_OP_f2i_select1: SETI((UA & (uint32_t)cvtt(B)) | (~UA & UC));
-		case VVM_OP_f2i_maxi: SETI(i_max(cvtt(A), IB));
-		case VVM_OP_f2i_addi: SETI((uint32_t)cvtt(A) + UB);
-		case VVM_OP_fmod_add: if constexpr (FULL) SETF(f_fmod(A, B) + C);
-		case VVM_OP_bit_and_i2f: SETF(i2f((int32_t)(UA & UB)));
-		case VVM_OP_bit_rshift_bit_and: SETI(i_shr(UA, UB) & UC);
-		case VVM_OP_neg_cmplt: SETM(f_neg(A) < B);
-		case VVM_OP_bit_or_muli: SETI((UA | UB) * UC);
-		case VVM_OP_bit_lshift_bit_or: SETI(i_shl(UA, UB) | UC);
-		case VVM_OP_max_f2i: SETI(cvtt(f_max(A, B)));
-		case VVM_OP_select_mul: SETF(f_sel(A, B, C) * D);
-		case VVM_OP_select_add: SETF(f_sel(A, B, C) + D);
-		case VVM_OP_sin_cos: if constexpr (FULL) { _Pragma("unroll") LANES { float sn, cs; f_sincos(A, sn, cs); r[k] = aux ? cs : sn; } } break;   // aux: 0 sine, 1 cosine
-		case VVM_OP_half_to_float: SETF(load_half(UA));             // RT.cpp:1113-1127
-		case VVM_OP_exec_index: SETI((uint32_t)d.exec_index_base + inst_i + k);                       // RT.cpp:880-900
-		case VVM_OP_exec_indexf: SETF(i2f((int32_t)((uint32_t)d.exec_index_base + inst_i + k)));      // RT.cpp:902-923
-		case VVM_OP_exec_index_addi: SETI((uint32_t)d.exec_index_base + inst_i + k + UA);             // RT.cpp:925-951
-		// aux2 = ordinal of the random op within the script
-		case VVM_OP_random: SETF(rand01(rand_u32(d.rand_seed_lo, d.rand_seed_hi, (uint32_t)d.rand_instance_base + inst_i + k, aux2)) * A);
-		case VVM_OP_randomi: SETI(cvtt(rand01(rand_u32(d.rand_seed_lo, d.rand_seed_hi, (uint32_t)d.rand_instance_base + inst_i + k, aux2)) * i2f(IA)));
-		case VVM_OP_random_add: SETF(rand01(rand_u32(d.rand_seed_lo, d.rand_seed_hi, (uint32_t)d.rand_instance_base + inst_i + k, aux2)) * A + B);
-		case VVM_OP_external_func_call:
-			// aux = built-in id, aux2 = which output this device instruction produces (VectorVMRuntime.cpp:1450-1464 lists the
-			// operands as inputs then outputs; the linker emits one instruction per output in use)
-			if constexpr (FULL) {
-				if (aux == VVM_EXTFN_PERLIN3) { _Pragma("unroll") LANES r[k] = perlin3(c.perlin_lds, A, B, C); }
-				else { _Pragma("unroll") LANES r[k] = curl_noise3_component(c.perlin_lds, A, B, C, aux2); }
+			switch (op) {
+			case VVM_OP_add: SETF(A + B);
+			case VVM_OP_sub: SETF(A - B);
+			case VVM_OP_mul: SETF(A * B);
+			case VVM_OP_div: SETF(f_div(A, B));
+			case VVM_OP_mad: SETF(f_mad(A, B, C));
+			case VVM_OP_lerp: SETF(f_lerp(A, B, C));
+			case VVM_OP_rcp: SETF(f_rcp(A));
+			case VVM_OP_rsq: SETF(f_rsq(A));
+			case VVM_OP_sqrt: SETF(f_sqrtg(A));
+			case VVM_OP_neg: SETF(f_neg(A));
+			case VVM_OP_abs: SETF(f_abs(A));
+			case VVM_OP_exp: if constexpr (FULL) SETF(mf_exp(A));
+			case VVM_OP_exp2: if constexpr (FULL) SETF(lib_exp2(A));
+			case VVM_OP_log: if constexpr (FULL) SETF(f_log(A));
+			case VVM_OP_log2: if constexpr (FULL) SETF(lib_log2(A));
+			case VVM_OP_sin: if constexpr (FULL) SETF(mf_sin(A));
+			case VVM_OP_cos: if constexpr (FULL) SETF(mf_cos(A));
+			case VVM_OP_tan: if constexpr (FULL) SETF(lib_tan(A));
+			case VVM_OP_asin: if constexpr (FULL) SETF(f_asin(A));
+			case VVM_OP_acos: if constexpr (FULL) SETF(f_acos(A));
+			case VVM_OP_atan: if constexpr (FULL) SETF(lib_atan(A));
+			case VVM_OP_atan2: if constexpr (FULL) SETF(ue_atan2(A, B));
+			case VVM_OP_ceil: SETF(ceilf(A));
+			case VVM_OP_floor: SETF(floorf(A));
+			case VVM_OP_fmod: if constexpr (FULL) SETF(f_fmod(A, B));
+			case VVM_OP_frac: SETF(f_frac(A));
+			case VVM_OP_trunc: SETF(truncf(A));
+			case VVM_OP_clamp: SETF(f_clamp(A, B, C));
+			case VVM_OP_min: SETF(f_min(A, B));
+			case VVM_OP_max: SETF(f_max(A, B));
+			case VVM_OP_pow: if constexpr (FULL) SETF(f_pow(A, B));
+			case VVM_OP_round: SETF(rintf(A));                         // SSE.h:2819-2822 (nearest even)
+			case VVM_OP_sign: SETF(f_sign(A));
+			case VVM_OP_step: SETF(f_step(B - A));                     // RT.cpp:1939
+			case VVM_OP_cmplt: SETM(A < B);
+			case VVM_OP_cmple: SETM(A <= B);
+			case VVM_OP_cmpgt: SETM(A > B);
+			case VVM_OP_cmpge: SETM(A >= B);
+			case VVM_OP_cmpeq: SETM(A == B);
+			case VVM_OP_cmpneq: SETM(A != B);
+			case VVM_OP_select: SETF(f_sel(A, B, C));
+			case VVM_OP_addi: SETI(UA + UB);
+			case VVM_OP_subi: SETI(UA - UB);
+			case VVM_OP_muli: SETI(UA * UB);
+			case VVM_OP_divi: SETI(i_div(IA, IB));
+			case VVM_OP_clampi: SETI(i_min(i_max(IA, IB), IC));
+			case VVM_OP_mini: SETI(i_min(IA, IB));
+			case VVM_OP_maxi: SETI(i_max(IA, IB));
+			case VVM_OP_absi: SETI(i_abs(IA));
+			case VVM_OP_negi: SETI(0u - UA);
+			case VVM_OP_signi: SETI(IA >= 0 ? 1 : -1);
+			case VVM_OP_cmplti: SETM(IA < IB);
+			case VVM_OP_cmplei: SETM(IA <= IB);
+			case VVM_OP_cmpgti: SETM(IA > IB);
+			case VVM_OP_cmpgei: SETM(IA >= IB);
+			case VVM_OP_cmpeqi: SETM(IA == IB);
+			case VVM_OP_cmpneqi: SETM(IA != IB);
+			case VVM_OP_bit_and: case VVM_OP_logic_and: SETI(UA & UB);
+			case VVM_OP_bit_or: case VVM_OP_logic_or: SETI(UA | UB);
+			case VVM_OP_bit_xor: case VVM_OP_logic_xor: SETI(UA ^ UB);
+			case VVM_OP_bit_not: case VVM_OP_logic_not: SETI(~UA);
+			case VVM_OP_bit_lshift: SETI(i_shl(UA, UB));
+			case VVM_OP_bit_rshift: SETI(i_shr(UA, UB));
+			case VVM_OP_f2i: SETI(cvtt(A));
+			case VVM_OP_i2f: SETF(i2f(IA));
+			case VVM_OP_f2b: SETM(A > 0.0f);
+			case VVM_OP_b2f: SETF(f_sel(A, 1.0f, 0.0f));
+			case VVM_OP_i2b: SETM(IA > 0);
+			case VVM_OP_b2i: SETI(UA & 1u);
+			// merged ops, VectorVMRuntime.cpp:1999-2074
+			case VVM_OP_cmplt_select: SETF(f_sel(mask(A < B), C, D));
+			case VVM_OP_cmple_select: SETF(f_sel(mask(A <= B), C, D));
+			case VVM_OP_cmpeq_select: SETF(f_sel(mask(A == B), C, D));
+			case VVM_OP_cmplti_select: SETF(f_sel(mask(IA < IB), C, D));
+			case VVM_OP_cmplei_select: SETF(f_sel(mask(IA <= IB), C, D));
+			case VVM_OP_cmpeqi_select: SETF(f_sel(mask(IA == IB), C, D));
+			case VVM_OP_cmplt_logic_and: SETI((A < B ? ~0u : 0u) & UC);
+			case VVM_OP_cmple_logic_and: SETI((A <= B ? ~0u : 0u) & UC);
+			case VVM_OP_cmpgt_logic_and: SETI((A > B ? ~0u : 0u) & UC);
+			case VVM_OP_cmpge_logic_and: SETI((A >= B ? ~0u : 0u) & UC);
+			case VVM_OP_cmpeq_logic_and: SETI((A == B ? ~0u : 0u) & UC);
+			case VVM_OP_cmpne_logic_and: SETI((A != B ? ~0u : 0u) & UC);
+			case VVM_OP_cmplti_logic_and: SETI((IA < IB ? ~0u : 0u) & UC);
+			case VVM_OP_cmplei_logic_and: SETI((IA <= IB ? ~0u : 0u) & UC);
+			case VVM_OP_cmpgti_logic_and: SETI((IA > IB ? ~0u : 0u) & UC);
+			case VVM_OP_cmpgei_logic_and: SETI((IA >= IB ? ~0u : 0u) & UC);
+			case VVM_OP_cmpeqi_logic_and: SETI((IA == IB ? ~0u : 0u) & UC);
+			case VVM_OP_cmpnei_logic_and: SETI((IA != IB ? ~0u : 0u) & UC);
+			case VVM_OP_cmplt_logic_or: SETI((A < B ? ~0u : 0u) | UC);
+			case VVM_OP_cmple_logic_or: SETI((A <= B ? ~0u : 0u) | UC);
+			case VVM_OP_cmpgt_logic_or: SETI((A > B ? ~0u : 0u) | UC);
+			case VVM_OP_cmpge_logic_or: SETI((A >= B ? ~0u : 0u) | UC);
+			case VVM_OP_cmpeq_logic_or: SETI((A == B ? ~0u : 0u) | UC);
+			case VVM_OP_cmpne_logic_or: SETI((A != B ? ~0u : 0u) | UC);
+			case VVM_OP_cmplti_logic_or: SETI((IA < IB ? ~0u : 0u) | UC);
+			case VVM_OP_cmplei_logic_or: SETI((IA <= IB ? ~0u : 0u) | UC);
+			case VVM_OP_cmpgti_logic_or: SETI((IA > IB ? ~0u : 0u) | UC);
+			case VVM_OP_cmpgei_logic_or: SETI((IA >= IB ? ~0u : 0u) | UC);
+			case VVM_OP_cmpeqi_logic_or: SETI((IA == IB ? ~0u : 0u) | UC);
+			case VVM_OP_cmpnei_logic_or: SETI((IA != IB ? ~0u : 0u) | UC);
+			case VVM_OP_mad_add: SETF(f_mad(A, B, C) + D);
+			case VVM_OP_mad_sub0: SETF(f_mad(A, B, C) - D);
+			case VVM_OP_mad_sub1: SETF(D - f_mad(A, B, C));
+			case VVM_OP_mad_mul: SETF(f_mad(A, B, C) * D);
+			case VVM_OP_mad_sqrt: SETF(__fsqrt_rn(f_mad(A, B, C)));      // unguarded, RT.cpp:2033
+			case VVM_OP_mad_mad0: SETF(f_mad(D, E, f_mad(A, B, C)));
+			case VVM_OP_mad_mad1: SETF(f_mad(f_mad(A, B, C), D, E));
+			case VVM_OP_mul_mad0: SETF(f_mad(A * B, C, D));
+			case VVM_OP_mul_mad1: SETF(f_mad(C, D, A * B));
+			case VVM_OP_mul_add: SETF((A * B) + C);
+			case VVM_OP_mul_sub0: SETF((A * B) - C);
+			case VVM_OP_mul_sub1: SETF(C - (A * B));
+			case VVM_OP_mul_mul: SETF((A * B) * C);
+			case VVM_OP_mul_max: SETF(f_max(A * B, C));
+			case VVM_OP_add_mad1: SETF(f_mad(C, D, A + B));
+			case VVM_OP_add_add: SETF((A + B) + C);
+			case VVM_OP_sub_cmplt1: SETM(C < (A - B));
+			case VVM_OP_sub_neg: SETF(f_neg(A - B));
+			case VVM_OP_sub_mul: SETF((A - B) * C);
+			case VVM_OP_div_mad0: SETF(f_mad(f_div(A, B), C, D));
+			case VVM_OP_div_f2i: SETI(cvtt(f_div(A, B)));
+			case VVM_OP_div_mul: SETF(f_div(A, B) * C);
+			case VVM_OP_muli_addi: SETI(UA * UB + UC);
+			case VVM_OP_addi_bit_rshift: SETI(i_shr(UA + UB, UC));
+			case VVM_OP_addi_muli: SETI((UA + UB) * UC);
+			case VVM_OP_i2f_div0: SETF(f_div(i2f(IA), B));
+			case VVM_OP_i2f_div1: SETF(f_div(B, i2f(IA)));
+			case VVM_OP_i2f_mul: SETF(i2f(IA) * B);
+			case VVM_OP_i2f_mad0: SETF(f_mad(i2f(IA), B, C));
+			case VVM_OP_i2f_mad1: SETF(f_mad(A, B, i2f(IC)));
+			case VVM_OP_f2i_select1: SETI((UA & (uint32_t)cvtt(B)) | (~UA & UC));
+			case VVM_OP_f2i_maxi: SETI(i_max(cvtt(A), IB));
+			case VVM_OP_f2i_addi: SETI((uint32_t)cvtt(A) + UB);
+			case VVM_OP_fmod_add: if constexpr (FULL) SETF(f_fmod(A, B) + C);
+			case VVM_OP_bit_and_i2f: SETF(i2f((int32_t)(UA & UB)));
+			case VVM_OP_bit_rshift_bit_and: SETI(i_shr(UA, UB) & UC);
+			case VVM_OP_neg_cmplt: SETM(f_neg(A) < B);
+			case VVM_OP_bit_or_muli: SETI((UA | UB) * UC);
+			case VVM_OP_bit_lshift_bit_or: SETI(i_shl(UA, UB) | UC);
+			case VVM_OP_max_f2i: SETI(cvtt(f_max(A, B)));
+			case VVM_OP_select_mul: SETF(f_sel(A, B, C) * D);
+			case VVM_OP_select_add: SETF(f_sel(A, B, C) + D);
+			case VVM_OP_sin_cos: if constexpr (FULL) { _Pragma("unroll") LANES { float sn, cs; f_sincos(A, sn, cs); r[k] = aux ? cs : sn; } } break;   // aux: 0 sine, 1 cosine
+			case VVM_OP_half_to_float: SETF(load_half(UA));             // RT.cpp:1113-1127
+			case VVM_OP_exec_index: SETI((uint32_t)d.exec_index_base + inst_i + k);                       // RT.cpp:880-900
+			case VVM_OP_exec_indexf: SETF(i2f((int32_t)((uint32_t)d.exec_index_base + inst_i + k)));      // RT.cpp:902-923
+			case VVM_OP_exec_index_addi: SETI((uint32_t)d.exec_index_base + inst_i + k + UA);             // RT.cpp:925-951
+			// aux2 = ordinal of the random op within the script
+			case VVM_OP_random: SETF(rand01(rand_u32(d.rand_seed_lo, d.rand_seed_hi, (uint32_t)d.rand_instance_base + inst_i + k, aux2)) * A);
+			case VVM_OP_randomi: SETI(cvtt(rand01(rand_u32(d.rand_seed_lo, d.rand_seed_hi, (uint32_t)d.rand_instance_base + inst_i + k, aux2)) * i2f(IA)));
+			case VVM_OP_random_add: SETF(rand01(rand_u32(d.rand_seed_lo, d.rand_seed_hi, (uint32_t)d.rand_instance_base + inst_i + k, aux2)) * A + B);
+			case VVM_OP_external_func_call:
+				// aux = built-in id, aux2 = which output this device instruction produces (VectorVMRuntime.cpp:1450-1464 lists the
+				// operands as inputs then outputs; the linker emits one instruction per output in use)
+				if constexpr (FULL) {
+					if (aux == VVM_EXTFN_PERLIN3) { _Pragma("unroll") LANES r[k] = perlin3(c.perlin_lds, A, B, C); }
+					else { _Pragma("unroll") LANES r[k] = curl_noise3_component(c.perlin_lds, A, B, C, aux2); }
+				}
+				break;
+			default: { _Pragma("unroll") LANES r[k] = 0.0f; } break;
 			}
-			break;
-		default: { _Pragma("unroll") LANES r[k] = 0.0f; } break;
-		}
 #undef LANES
 #undef A
 #undef B
@@ -942,31 +944,82 @@ DEV void run_tile(const VvmExecDesc& d, const Ctx& c, uint32_t* lds_ctrl, uint32
 #undef SETF
 #undef SETI
 #undef SETM
+			// the one place where the interpreter writes registers
+			REG_WRITE(VVM_OPND_IDX(dst), r);
 		}
-		// the one place where the main loop writes registers
-		REG_WRITE(VVM_OPND_IDX(dst), r);
+
+		if (op == VVM_DOP_ACQUIRE) {
+			// sign bit of the predicate = keep (VectorVMRuntime.cpp:838-841); instances past the end never survive (:846-857)
+			float p[V];
+			fetch<V, SPILL>(RARGS, uni, c, o0, p);
+			uint32_t kb = 0;
+#pragma unroll
+			for (int k = 0; k < V; ++k)
+				kb |= ((fbits(p[k]) >> 31) & ((c.inst0 + k < c.num_instances) ? 1u : 0u)) << k;
+			const uint2 rt = acquire_rank_and_publish(kb, c.tid, lds_ctrl, status, tile_local, tag, dbg);
+			t_keep = kb; t_rank = rt.x; t_total = SCALAR(rt.y); t_dataset = aux; t_pending = true;
+			if (dbg & 64u) continue;      // experiment: resolve the prefix at the first output instead
+		}
+		// the exclusive prefix over the previous tiles
+		if (t_pending) {
+			t_base = SCALAR(acquire_resolve_prefix(t_total, c.tid, lds_ctrl, status, tile_local, d.num_tiles, VVM_BLOCK_THREADS * V, tag,
+			                                       error_word, d.counts + t_dataset, dbg));
+			t_pending = false;
+		}
+		if (op == VVM_OP_done) break;
+		if (op == VVM_DOP_ACQUIRE) continue;
+		// aux = pair count (1..3), aux2 = dataset; pairs (o0,o1) (o2,o3) (o4,o5) = (source, output serial index)
+		const uint32_t total = (aux2 == t_dataset) ? t_total : 0u;    // no acquireindex for this dataset: nothing is written (VectorVMRuntime.cpp:565, 769)
+		const uint32_t valid = min(c.num_instances - (c.inst0 - c.tid * V), (uint32_t)(VVM_BLOCK_THREADS * V));
+		const bool all_alive = (total == valid) && c.full;
+		const uint32_t kind = op - VVM_DOP_OUTPUT32;          // the four output opcodes in the order of store_compact's kinds
+#pragma unroll
+		for (int j = 0; j < 3; ++j) {
+			if ((uint32_t)j >= aux) break;
+			const uint32_t src = (j == 0) ? o0 : (j == 1) ? o2 : o4;
+			const uint32_t out_idx = (j == 0) ? o1 : (j == 1) ? o3 : o5;
+			const uint64_t base = sload64(c.out_ptrs, out_idx);
+			if (base == 0 || total == 0 || (dbg & 8u)) continue;
+			float v[V];
+			fetch<V, SPILL>(RARGS, uni, c, src, v);
+			if (kind == 0 && all_alive) {
+				float* q = (float*)base + t_base;
+				if constexpr (V == 4) { f4u x; x.x = v[0]; x.y = v[1]; x.z = v[2]; x.w = v[3]; *(f4u*)(q + c.tid * 4) = x; }
+				else q[c.tid] = v[0];
+			} else {
+				if constexpr (V == 4) store_compact(kind, base, t_base + t_rank, t_keep, v[0], v[1], v[2], v[3]);
+				else store_compact(kind, base, t_base + t_rank, t_keep, v[0], 0.0f, 0.0f, 0.0f);
+			}
+		}
 	}
 }
 
 template <int V, bool SPILL, bool FULL>
-__global__ void __launch_bounds__(VVM_BLOCK_THREADS, (FULL ? 2 : (V == 4 ? 3 : 8))) vvm_exec_kernel(KernelEnv env)
+__global__ void __launch_bounds__(VVM_BLOCK_THREADS, (FULL ? 2 : (V == 4 ? 4 : 8))) vvm_exec_kernel(KernelEnv env)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	uint32_t* lds_ctrl = (uint32_t*)lds;
 	uint8_t* lds_perlin = lds + LDS_PERLIN_OFF;
 	float* lds_spill = (float*)(lds + LDS_SPILL_OFF);
 	const uint32_t tid = threadIdx.x;
-	gu32* ticket_word = (gu32*)&env.ls->ticket;
+	// ticket counter of this workgroup's class (see VvmLaunchState); with fewer workgroups than classes only the first
+	// gridDim.x counters are in use
+	const uint32_t classes = min(gridDim.x, VVM_TICKET_CLASSES);
+	const uint32_t cls = blockIdx.x % classes;
+	gu32* ticket_word = (gu32*)&env.ls->tickets[cls * (VVM_TICKET_STRIDE_BYTES / 4u)];
 	gu32* error_word = (gu32*)&env.ls->pad;
 	const uint32_t tag = SCALAR(__hip_atomic_load((gu32*)&env.ls->epoch, RLX_AGENT)) & 0x3FFFFFFFu;
 	bool perlin_ready = false;
 
+	// A tile is claimed when the workgroup is ready to start it, never ahead of time: the look-back of a tile waits for the
+	// counts of all earlier tiles, so a tile that is claimed but not yet running stalls every later one.
 	for (;;) {
 		__syncthreads();
-		if (tid == 0) lds_ctrl[8] = __hip_atomic_fetch_add(ticket_word, 1u, RLX_AGENT);
+		if (tid == 0) lds_ctrl[10] = __hip_atomic_fetch_add(ticket_word, 1u, RLX_AGENT);
 		__syncthreads();
-		const uint32_t ticket = __builtin_amdgcn_readfirstlane(lds_ctrl[8]);
-		if (ticket >= env.total_tiles) break;
+		const uint32_t draw = SCALAR(lds_ctrl[10]);
+		if (draw >= (env.total_tiles + classes - 1u - cls) / classes) break;      // this class has that many tiles
+		const uint32_t ticket = draw * classes + cls;
 
 		// which Exec owns this ticket: the last descriptor with first_tile <= ticket
 		uint32_t e = 0;
@@ -996,7 +1049,6 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (FULL ? 2 : (V == 4 ? 3 : 8
 			d.rand_seed_hi = sload32(dp, offsetof(VvmExecDesc, rand_seed_hi) / 4);
 			d.rand_instance_base = (int32_t)sload32(dp, offsetof(VvmExecDesc, rand_instance_base) / 4);
 			d.flags = sload32(dp, offsetof(VvmExecDesc, flags) / 4);
-			d.num_unif = sload32(dp, offsetof(VvmExecDesc, num_unif) / 4);
 		}
 		const uint32_t tile_local = ticket - d.first_tile;
 		const uint32_t tile_first = tile_local * (VVM_BLOCK_THREADS * V);
@@ -1025,7 +1077,8 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (FULL ? 2 : (V == 4 ? 3 : 8
 			if (next == 0) next = 1;
 			__hip_atomic_store((gu32*)&env.ls->epoch, next, RLX_AGENT);
 			__hip_atomic_store((gu32*)&env.ls->done, 0u, RLX_AGENT);
-			__hip_atomic_store(ticket_word, 0u, RLX_AGENT);
+			for (uint32_t x = 0; x < VVM_TICKET_CLASSES; ++x)
+				__hip_atomic_store((gu32*)&env.ls->tickets[x * (VVM_TICKET_STRIDE_BYTES / 4u)], 0u, RLX_AGENT);
 		}
 	}
 }
