@@ -15,10 +15,9 @@ enum : uint32_t {
 	VVM_OPC_VREG  = 0,   // per-lane virtual register: index < resident count -> VGPR, else LDS slot
 	VVM_OPC_UNIF  = 1,   // uniform register: one of the first VVM_MAX_UNIFORMS remapped constants (lane i of one VGPR holds constant i)
 	VVM_OPC_CONST = 2,   // remapped constant read from the constant table (the ones past the uniform registers)
-	VVM_OPC_INPUT = 3,   // advancing 32-bit input stream, read at the instance index
 	VVM_OPC_NOADV = 4,   // no-advance input: element [InstanceOffset] of the stream, uniform (VectorVMRuntime.cpp:381-401)
-	VVM_OPC_HALF  = 5,   // advancing 16-bit input stream (only half_to_float / *_from_half read it)
-	VVM_OPC_NOADV_HALF = 6,
+	VVM_OPC_NOADV_HALF = 6,   // the same for a 16-bit stream, converted to float
+	                          // (advancing input streams are loaded into per-lane registers by VVM_DOP_LOADN / VVM_DOP_LOADN16)
 	VVM_OPC_NONE  = 7    // 0xFFFF in the bytecode: external-function dummy register
 };
 #define VVM_OPND(cls, idx) ((uint32_t)(((cls) << 13) | ((idx) & 0x1FFFu)))
@@ -29,7 +28,8 @@ enum : uint32_t {
 
 // ---- device-only opcodes (the reference's opcodes keep their numbers 0..178) ----
 enum : uint32_t {
-	VVM_DOP_LOADN  = 191,  // prefetch up to 8 input streams into consecutive virtual registers (program prologue only)
+	VVM_DOP_LOADN16 = 190, // the same for 16-bit streams: the raw bits, zero-extended
+	VVM_DOP_LOADN  = 191,  // load up to 8 32-bit input streams into consecutive virtual registers (program prologue only)
 	VVM_DOP_ACQUIRE = 192, // acquireindex; every opcode from here on produces no register result
 	VVM_DOP_OUTPUT32 = 193, // up to 3 (src,dst) pairs of outputdata_float / outputdata_int32
 	VVM_DOP_OUTPUT16 = 194, // up to 3 pairs of outputdata_half (float register -> half stream)
@@ -50,7 +50,7 @@ struct VvmIns {
 // One Exec (one emitter) as the kernel sees it.  Lives in device memory.
 struct VvmExecDesc {
 	const VvmIns*   prog;
-	const uint32_t* consts;        // NumConstBuffers dwords, remapped order, zero-padded to at least VVM_MAX_UNIFORMS dwords
+	const uint32_t* consts;        // NumConstBuffers dwords, remapped order, zero-padded to a multiple of 4 dwords
 	const uint64_t* in_ptrs;       // byte address of element [InstanceOffset] of every remapped input stream
 	const uint64_t* out_ptrs;      // byte address of element [InstanceOffset] of every output, by output serial index (0 = none)
 	unsigned long long* status;    // one look-back word per tile of this Exec
@@ -63,7 +63,8 @@ struct VvmExecDesc {
 	uint32_t rand_seed_lo, rand_seed_hi;
 	int32_t  rand_instance_base;
 	uint32_t flags;
-	uint32_t pad[2];
+	uint32_t num_unif;             // constants copied into the uniform register, a multiple of 4, at most VVM_MAX_UNIFORMS
+	uint32_t pad[1];
 };
 
 enum : uint32_t {
@@ -83,9 +84,10 @@ struct VvmLaunchState {
 	uint32_t done;       // blocks that have left
 	uint32_t epoch;      // tag that makes a look-back word valid for this launch (never 0)
 	uint32_t pad;        // error word: set when a look-back gave up
-	// profiling aid, filled only when the launcher's debug bit 7 is set: look-backs, rounds, polls, clocks spent in them
-	unsigned long long stats[6];
-	uint32_t reserved[(VVM_TICKET_STRIDE_BYTES - 64u) / 4u];
+	// profiling aid, filled only when the launcher's debug bit 7 is set: look-backs, rounds, polls, clocks/16 spent in them,
+	// clocks/16 waiting for tickets, in the load phase, in the interpreter, tiles
+	unsigned long long stats[8];
+	uint32_t reserved[(VVM_TICKET_STRIDE_BYTES - 80u) / 4u];
 	uint32_t tickets[VVM_TICKET_CLASSES * VVM_TICKET_STRIDE_BYTES / 4u];   // counter x at tickets[x * VVM_TICKET_STRIDE_BYTES / 4]
 };
 

@@ -232,7 +232,7 @@ int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, P
 	pe.tiles = ((uint32_t)ctx->NumInstances + tile - 1) / tile;
 	const uint32_t O = std::max<uint32_t>(s.num_outputs_remapped, s.num_output_instructions);
 	pe.off_consts = align_up(sizeof(VvmExecDesc), 16);
-	pe.off_in = align_up(pe.off_consts + 4u * (size_t)std::max<uint32_t>(s.num_consts, VVM_MAX_UNIFORMS), 16);   // the kernel loads VVM_MAX_UNIFORMS dwords unconditionally
+	pe.off_in = align_up(pe.off_consts + 4u * (size_t)s.num_consts, 16);     // (so the table is padded to a multiple of 4 dwords)
 	pe.off_out = align_up(pe.off_in + 8u * (size_t)s.num_inputs, 16);
 	pe.bytes = align_up(pe.off_out + 8u * (size_t)O, 256);
 	return VVM_OK;
@@ -261,6 +261,7 @@ int fill_params(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* op
 	d->rand_seed_hi = opt ? (uint32_t)(opt->RandSeed >> 32) : 0;
 	d->rand_instance_base = opt ? opt->RandInstanceBase : 0;
 	d->flags = lp.uses_perlin ? VVM_DESC_USES_PERLIN : 0;
+	d->num_unif = std::min<uint32_t>((s.num_consts + 3u) & ~3u, VVM_MAX_UNIFORMS);
 
 	uint32_t* consts = (uint32_t*)(host + pe.off_consts);                                               // RT.cpp:2204-2207
 	memset(consts, 0, pe.off_in - pe.off_consts);
@@ -421,7 +422,7 @@ VVM_API int vvm_exec_async(vvm_exec_context* ctx, const vvm_exec_options* opt)
 	st->ring.pending[slot] = true;
 	const size_t ncounts = std::max<uint32_t>(st->script.max_output_dataset, 1);
 	HIP_TRY(hipMemcpyAsync(st->h_counts, st->d_counts, ncounts * 4, hipMemcpyDeviceToHost, stream));
-	HIP_TRY(hipMemcpyAsync(st->h_counts + ncounts + 4, st->d_launch, 64, hipMemcpyDeviceToHost, stream));     // the words up to stats[]
+	HIP_TRY(hipMemcpyAsync(st->h_counts + ncounts + 4, st->d_launch, 80, hipMemcpyDeviceToHost, stream));     // the words up to and including stats[]
 	return VVM_OK;
 }
 
@@ -435,7 +436,7 @@ VVM_API int vvm_exec_finish(vvm_exec_context* ctx)
 		const size_t ncounts = std::max<uint32_t>(st->script.max_output_dataset, 1);
 		const VvmLaunchState* ls = (const VvmLaunchState*)(st->h_counts + ncounts + 4);
 		if (getenv("VVM_DEBUG_STATS"))
-			fprintf(stderr, "vvm stats (cumulative): lookbacks %llu rounds %llu polls %llu clocks %llu\n", ls->stats[0], ls->stats[1], ls->stats[2], ls->stats[3]);
+			fprintf(stderr, "vvm stats (cumulative): lookbacks %llu rounds %llu polls %llu clocks/16 %llu | ticket %llu load %llu interp %llu tiles %llu\n", ls->stats[0], ls->stats[1], ls->stats[2], ls->stats[3], ls->stats[4], ls->stats[5], ls->stats[6], ls->stats[7]);
 		if (ls->pad != 0) {
 			(void)reset_launch_state(st->d_launch);
 			if (st->d_status) (void)hipMemset(st->d_status, 0, (size_t)st->status_capacity * 8);
@@ -556,7 +557,7 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 		                                       (uint32_t)groups[g].members.size(), groups[g].tiles, g_batch.d_launch[g], groups[g].spill,
 		                                       lp.full_kernel ? 1 : 0, grid_for(groups[g].tiles), g_batch.stream);
 		if (lrc != 0) return hip_fail((hipError_t)lrc, "batched kernel launch");
-		HIP_TRY(hipMemcpyAsync(&g_batch.h_launch[g], g_batch.d_launch[g], 64, hipMemcpyDeviceToHost, g_batch.stream));
+		HIP_TRY(hipMemcpyAsync(&g_batch.h_launch[g], g_batch.d_launch[g], 80, hipMemcpyDeviceToHost, g_batch.stream));
 	}
 	for (int i = 0; i < n; ++i) {
 		vvm_state* st = ctxs[i].VVMState;

@@ -11,5 +11,5 @@ int vvm_launch_exec_kernel(int instances_per_lane, const VvmExecDesc* descs, uin
                            VvmLaunchState* ls, uint32_t lds_spill_slots, int full, uint32_t grid, hipStream_t stream);
 int vvm_kernel_max_dynamic_lds(void);
 uint32_t vvm_kernel_resident_registers(int instances_per_lane);
-uint32_t vvm_kernel_lds_fixed_bytes(void);
+uint32_t vvm_kernel_lds_fixed_bytes(int instances_per_lane);
 }

@@ -62,9 +62,17 @@ template <typename VEC> __device__ __forceinline__ float vget(VEC v, uint32_t i)
 template <typename VEC> __device__ __forceinline__ VEC vset(VEC v, uint32_t i, float x) { v[i] = x; return v; }
 
 // LDS carve (dynamic region only, every offset a multiple of 16)
-#define LDS_CTRL_WORDS   32        // uint32: [0..3] wave totals, [9] prefix, [10] ticket
-#define LDS_PERLIN_OFF   128       // 512 bytes
-#define LDS_SPILL_OFF    640
+//   [0, 256)      control words (uint32): [0..3] wave totals, [9] prefix, [10] ticket, [16..19] look-back statistics
+//   [256, 768)    Perlin permutation table
+//   [768, 896)    staged outputs: destination address (uint64 x VVM_STAGE_SLOTS) then kind (uint32 x VVM_STAGE_SLOTS)
+//   [896, ...)    output staging: VVM_STAGE_SLOTS slots of one tile's worth of 32-bit values, then one sink dword per thread
+//   then          register spill slots
+#define VVM_STAGE_SLOTS     8u
+#define LDS_PERLIN_OFF      256
+#define LDS_STAGE_META_OFF  768
+#define LDS_STAGE_OFF       896
+#define LDS_STAGE_BYTES(V)  (VVM_STAGE_SLOTS * VVM_BLOCK_THREADS * (V) * 4u + VVM_BLOCK_THREADS * 4u)
+#define LDS_SPILL_OFF(V)    (LDS_STAGE_OFF + LDS_STAGE_BYTES(V))
 
 DEV uint32_t fbits(float f) { return __float_as_uint(f); }
 DEV float    bitsf(uint32_t u) { return __uint_as_float(u); }
@@ -384,6 +392,26 @@ __device__ __noinline__ float curl_noise3_component(const uint8_t* P, float x, f
 }
 
 // ---- wave helpers --------------------------------------------------------------------------------------
+// lane LANE of v := x (wave-uniform); the other lanes keep their value.  The lane number is an immediate: a VALU
+// instruction of this target reads at most one scalar register.
+template <int LANE> DEV uint32_t write_lane(uint32_t v, uint32_t x)
+{
+	asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(x), "n"(LANE));
+	return v;
+}
+template <int G> DEV uint32_t fill_uniforms(uint32_t uni, const void* consts, uint32_t count)
+{
+	if constexpr (G < (int)VVM_MAX_UNIFORMS / 4) {
+		if ((uint32_t)(4 * G) < count) {
+			uni = write_lane<4 * G + 0>(uni, sload32(consts, 4 * G + 0));
+			uni = write_lane<4 * G + 1>(uni, sload32(consts, 4 * G + 1));
+			uni = write_lane<4 * G + 2>(uni, sload32(consts, 4 * G + 2));
+			uni = write_lane<4 * G + 3>(uni, sload32(consts, 4 * G + 3));
+			uni = fill_uniforms<G + 1>(uni, consts, count);
+		}
+	}
+	return uni;
+}
 DEV uint32_t lanes_below(u64 m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 DEV uint32_t wave_sum(uint32_t v)
 {
@@ -489,26 +517,6 @@ template <int V> DEV void load_stream16(const Ctx& c, uint64_t base, float (&out
 	}
 }
 
-// Compacting store of a lane's surviving values: survivor j of the lane goes to element first + j.
-// Out of line on purpose: inlined into the code between the runs of ordinary instructions, its per-lane branches make the
-// compiler treat the interpreter loop as part of one large divergent region and rewrite that loop's branches as well.
-//   kind 0: 32-bit value   1: float -> half   2: low 16 bits as they are   3: half bits -> float
-// (kind 3 is outputdata_float_from_half, whose handler in the reference is an empty stub, VectorVMRuntime.cpp:573-577)
-__device__ __noinline__ void store_compact(uint32_t kind, uint64_t base, uint32_t first, uint32_t keep, float v0, float v1, float v2, float v3)
-{
-	const float v[4] = {v0, v1, v2, v3};
-	uint32_t r = first;
-#pragma unroll
-	for (int k = 0; k < 4; ++k) {
-		if ((keep >> k) & 1u) {
-			if (kind == 0) ((float*)base)[r] = v[k];
-			else if (kind == 3) ((float*)base)[r] = load_half(fbits(v[k]));
-			else ((uint16_t*)base)[r] = (uint16_t)((kind == 1) ? store_half(v[k]) : fbits(v[k]));
-			++r;
-		}
-	}
-}
-
 // Decoupled look-back over the Exec's tile words; called by wave 0 only.  Returns the exclusive prefix of `tile`.
 // Each round reads the VVM_LB_WINDOW tiles before `first` (VVM_LB_WINDOW / 64 words per lane, all loads in flight together),
 // waits until every one of them carries this launch's tag, and sums the counts back to the nearest tile whose word already
@@ -598,7 +606,9 @@ DEV uint32_t acquire_resolve_prefix(uint32_t total, uint32_t tid, uint32_t* lds_
                                                         int32_t* count_out, uint32_t dbg)
 {
 	uint32_t base = 0;
-	if (tile_local != 0) {
+	if (tile_local == 0) {
+		__syncthreads();      // callers rely on one barrier in here (see resolve_tile)
+	} else {
 		if ((tid >> 6) == 0) {
 			uint32_t rounds = 0, polls = 0;
 			const u64 t0 = (dbg & 128u) ? __builtin_amdgcn_s_memtime() : 0;
@@ -606,12 +616,9 @@ DEV uint32_t acquire_resolve_prefix(uint32_t total, uint32_t tid, uint32_t* lds_
 			if (tid == 0) {
 				lds_ctrl[9] = ex;
 				__hip_atomic_store(status + tile_local, ((u64)tag << 34) | (VVM_LB_INCLUSIVE << 32) | (ex + total), RLX_AGENT);
-				if (dbg & 128u) {
-					gu64* st = (gu64*)((char*)error_word + 4);      // VvmLaunchState::stats follows the error word
-					__hip_atomic_fetch_add(st + 0, 1ull, RLX_AGENT);
-					__hip_atomic_fetch_add(st + 1, (u64)rounds, RLX_AGENT);
-					__hip_atomic_fetch_add(st + 2, (u64)polls, RLX_AGENT);
-					__hip_atomic_fetch_add(st + 3, __builtin_amdgcn_s_memtime() - t0, RLX_AGENT);
+				if (dbg & 128u) {      // per-workgroup sums, added to VvmLaunchState::stats when the workgroup leaves
+					lds_ctrl[16] += 1u; lds_ctrl[17] += rounds; lds_ctrl[18] += polls;
+					lds_ctrl[19] += (uint32_t)((__builtin_amdgcn_s_memtime() - t0) >> 4);
 				}
 			}
 		}
@@ -622,28 +629,85 @@ DEV uint32_t acquire_resolve_prefix(uint32_t total, uint32_t tid, uint32_t* lds_
 	return base;
 }
 
+// What is left to do for a tile whose program has run: its outputs sit compacted in the LDS staging slots, and its prefix
+// may still be unresolved.  All fields are wave-uniform.
+struct Pending {
+	bool     active;
+	bool     unresolved;   // the tile's count is published, its exclusive prefix not yet known
+	uint32_t total;        // survivors in the tile
+	uint32_t base;         // exclusive prefix (valid once resolved)
+	uint32_t n_staged;     // staging slots in use
+	uint32_t tile_local, num_tiles;
+	gu64*    status;
+	int32_t* count_out;
+};
+
+// Finishing a tile takes two steps, both run by the NEXT tile while its input loads are in flight (also when the staging
+// slots run out, and after the last tile):
+//   resolve_tile  the look-back for the tile's exclusive prefix.  Its polls queue behind the input loads, so the two latencies
+//                 overlap instead of adding up.
+//   store_tile    survivor i of the tile (the survivors were compacted when they were staged) goes to element base + i of
+//                 each staged output.  A thread moves V consecutive values, so every tile without a partial tail stores
+//                 128 bits per lane whatever its death rate.  Issued after the next tile's loads have arrived: stores and
+//                 loads share one completion counter, and a wait for loads would otherwise also wait for these stores.
+template <int V> DEV void resolve_tile(Pending& p, uint32_t tid, uint32_t* lds_ctrl, uint32_t tag, gu32* error_word, uint32_t dbg)
+{
+	if (p.unresolved) {
+		p.base = SCALAR(acquire_resolve_prefix(p.total, tid, lds_ctrl, p.status, p.tile_local, p.num_tiles, VVM_BLOCK_THREADS * V, tag,
+		                                       error_word, p.count_out, dbg));
+		p.unresolved = false;
+	} else {
+		__syncthreads();      // (acquire_resolve_prefix has one) every thread's staged values are in LDS
+	}
+}
+template <int V> DEV void store_tile(Pending& p, uint32_t tid, unsigned char* lds, uint32_t dbg)
+{
+	const uint32_t* meta = (const uint32_t*)(lds + LDS_STAGE_META_OFF);
+	const float* stage = (const float*)(lds + LDS_STAGE_OFF);
+	const uint32_t i0 = tid * V;
+	for (uint32_t s = 0; s < p.n_staged; ++s) {
+		const uint64_t ptr = ((uint64_t)SCALAR(meta[2 * s + 1]) << 32) | (uint64_t)SCALAR(meta[2 * s]);
+		const uint32_t kind = SCALAR(meta[2 * VVM_STAGE_SLOTS + s]);
+		const float* src = stage + s * (VVM_BLOCK_THREADS * V) + i0;
+		if (dbg & 8u) continue;
+		if (kind == 0 || kind == 3) {          // 32-bit destination
+			float* dst = (float*)ptr + p.base + i0;
+			if constexpr (V == 4) {
+				if (i0 + 4 <= p.total) { const f4a x = *(const f4a*)src; f4u y; y.x = x.x; y.y = x.y; y.z = x.z; y.w = x.w; *(f4u*)dst = y; }
+				else {
+#pragma unroll
+					for (int k = 0; k < 4; ++k) if (i0 + k < p.total) dst[k] = src[k];
+				}
+			} else if (i0 < p.total) dst[0] = src[0];
+		} else {                               // 16-bit destination, the staged value holds the bits
+			uint16_t* dst = (uint16_t*)ptr + p.base + i0;
+#pragma unroll
+			for (int k = 0; k < V; ++k) if (i0 + k < p.total) dst[k] = (uint16_t)fbits(src[k]);
+		}
+	}
+	p.n_staged = 0;
+	p.active = false;
+}
+
 // Operand fetch.  The class and the index are wave-uniform, so every branch below is a scalar branch.  Two classes cover
 // almost every operand of a linked program and are tested first: a per-lane register (GPR-index read) and a uniform register
 // (lane i of `uni` holds constant i of the script; a lane read with a uniform index yields it as a scalar).
 template <int V> DEV void fetch_slow(const Ctx& c, uint32_t o, float (&out)[V])
 {
+	// only uniform values are left here (scalar loads): advancing streams are in registers before the interpreter loop starts,
+	// so the loop issues no vector memory instruction and never has to wait for one (a wait would also cover the output
+	// stores of the previous tile, which are still draining)
 	const uint32_t cls = VVM_OPND_CLS(o), idx = VVM_OPND_IDX(o);
-	if (cls == VVM_OPC_INPUT) {
-		load_stream32<V>(c, sload64(c.in_ptrs, idx), out);
-	} else if (cls == VVM_OPC_HALF) {
-		load_stream16<V>(c, sload64(c.in_ptrs, idx), out);
-	} else {
-		uint32_t u = 0;
-		if (cls == VVM_OPC_CONST) u = sload32(c.consts, idx);
-		else if (cls == VVM_OPC_NOADV) u = sload32((const void*)sload64(c.in_ptrs, idx), 0);      // element [InstanceOffset], VectorVMRuntime.cpp:381-401
-		else if (cls == VVM_OPC_NOADV_HALF) {                                                     // converted once, like VectorVMRuntime.cpp:388-394
-			const uint64_t a = sload64(c.in_ptrs, idx);
-			const uint32_t w = sload32((const void*)(a & ~3ull), 0);
-			u = fbits(load_half((a & 2ull) ? (w >> 16) : (w & 0xFFFFu)));
-		}
-#pragma unroll
-		for (int k = 0; k < V; ++k) out[k] = bitsf(u);
+	uint32_t u = 0;
+	if (cls == VVM_OPC_CONST) u = sload32(c.consts, idx);
+	else if (cls == VVM_OPC_NOADV) u = sload32((const void*)sload64(c.in_ptrs, idx), 0);      // element [InstanceOffset], VectorVMRuntime.cpp:381-401
+	else if (cls == VVM_OPC_NOADV_HALF) {                                                     // converted once, like VectorVMRuntime.cpp:388-394
+		const uint64_t a = sload64(c.in_ptrs, idx);
+		const uint32_t w = sload32((const void*)(a & ~3ull), 0);
+		u = fbits(load_half((a & 2ull) ? (w >> 16) : (w & 0xFFFFu)));
 	}
+#pragma unroll
+	for (int k = 0; k < V; ++k) out[k] = bitsf(u);
 }
 template <int V, bool SPILL> DEV void fetch(CREGS, uint32_t uni, const Ctx& c, uint32_t o, float (&out)[V])
 {
@@ -669,27 +733,34 @@ struct KernelEnv {
 
 // ------------------------------------------------------------------------------------------------------
 template <int V, bool SPILL, bool FULL>
-DEV void run_tile(const VvmExecDesc& d, const Ctx& c, uint32_t* lds_ctrl, uint32_t tile_local, uint32_t tag, gu32* error_word, uint32_t dbg)
+DEV void run_tile(const VvmExecDesc& d, const Ctx& c, unsigned char* lds, uint32_t tile_local, uint32_t tag, gu32* error_word, uint32_t dbg, Pending& pend,
+                  gu32* ticket_word, uint32_t& claimed, bool& have_claim)
 {
 	RVEC R0 = 0.0f, R1 = 0.0f, R2 = 0.0f, R3 = 0.0f;
+	uint32_t* lds_ctrl = (uint32_t*)lds;
 	// acquireindex state of the tile: all wave-uniform except keep and rank
 	uint32_t t_keep = 0, t_rank = 0;
 	uint32_t t_total = 0, t_base = 0, t_dataset = ~0u;
 	bool t_pending = false;          // the tile's count is published, its prefix not yet resolved
+	uint32_t n_staged = 0;           // staging slots this tile has filled
 	const VvmIns* prog = d.prog;
 	gu64* status = (gu64*)d.status;
 
-	// Uniform registers: lane i holds constant i (the host pads the table to 64 dwords, so the load needs no bound).
-	const uint32_t uni = ((const uint32_t*)c.consts)[c.tid & 63u];
+	// Uniform registers: lane i of `uni` holds constant i.  Filled by scalar loads and lane writes (the table is padded to a
+	// multiple of four dwords): a vector load would leave a pending-load wait on every later read of `uni`, and that wait
+	// would also cover the previous tile's output stores.
+	const uint32_t uni = fill_uniforms<0>(0u, c.consts, d.num_unif);
+	const u64 tl0 = (dbg & 128u) ? __builtin_amdgcn_s_memtime() : 0;
 
-	// Prologue: the program starts with its VVM_DOP_LOADN instructions.  They run in a loop of their own so that the main
+	// Prologue: the program starts with its VVM_DOP_LOADN / VVM_DOP_LOADN16 instructions.  They run in a loop of their own so that the main
 	// loop below has exactly one place that inserts into the register vectors (with two, the compiler keeps a second copy
 	// of the whole register file alive across the loop).
 	uint32_t pc0 = 0;
 	for (;; ++pc0) {
 		VvmIns ins;
 		ins.w0 = sload32(prog, pc0 * 4 + 0);
-		if ((ins.w0 & 0xFFu) != VVM_DOP_LOADN) break;
+		const uint32_t lop = ins.w0 & 0xFFu;
+		if (lop != VVM_DOP_LOADN && lop != VVM_DOP_LOADN16) break;
 		ins.w1 = sload32(prog, pc0 * 4 + 1); ins.w2 = sload32(prog, pc0 * 4 + 2); ins.w3 = sload32(prog, pc0 * 4 + 3);
 		const uint32_t aux = (ins.w0 >> 16) & 0xFFu, aux2 = ins.w0 >> 24;
 		// aux = count (1..8), aux2 = first destination register; eight 12-bit stream indices in w1..w3
@@ -703,12 +774,21 @@ DEV void run_tile(const VvmExecDesc& d, const Ctx& c, uint32_t* lds_ctrl, uint32
 				const uint32_t idx = (j < 5) ? (uint32_t)(lo >> (12 * j)) & 0xFFFu
 				                    : (j == 5) ? (uint32_t)((lo >> 60) | ((u64)(ins.w3 & 0xFFu) << 4)) & 0xFFFu
 				                               : (ins.w3 >> (8 + 12 * (j - 6))) & 0xFFFu;
-				load_stream32<V>(c, sload64(c.in_ptrs, idx), st[j]);
+				if (lop == VVM_DOP_LOADN) load_stream32<V>(c, sload64(c.in_ptrs, idx), st[j]);
+				else load_stream16<V>(c, sload64(c.in_ptrs, idx), st[j]);
 			}
 		}
+		// the previous tile's look-back runs while these loads are in flight, its stores are issued once they have arrived
+		const bool finish_previous = pend.active;
+		if (finish_previous) resolve_tile<V>(pend, c.tid, lds_ctrl, tag, error_word, dbg);
 #pragma unroll
 		for (int j = 0; j < 8; ++j)
 			REG_WRITE_IF((uint32_t)j < aux, aux2 + j, st[j]);
+		if (finish_previous) store_tile<V>(pend, c.tid, lds, dbg);
+	}
+	if (pend.active) {      // a program without stream loads
+		resolve_tile<V>(pend, c.tid, lds_ctrl, tag, error_word, dbg);
+		store_tile<V>(pend, c.tid, lds, dbg);
 	}
 
 	// The program is a sequence of runs of ordinary instructions separated by the few special ones (acquireindex, outputs,
@@ -721,6 +801,7 @@ DEV void run_tile(const VvmExecDesc& d, const Ctx& c, uint32_t* lds_ctrl, uint32
 	// exactly one destination register (the linker splits the reference's two-output ops and the three-output noise
 	// built-in).  With one insert site the register vectors stay in place; a second one makes the compiler keep a copy of the
 	// whole register file.
+	const u64 tl1 = (dbg & 128u) ? __builtin_amdgcn_s_memtime() : 0;
 	VvmIns nxt;
 	nxt.w0 = sload32(prog, pc0 * 4 + 0); nxt.w1 = sload32(prog, pc0 * 4 + 1);
 	nxt.w2 = sload32(prog, pc0 * 4 + 2); nxt.w3 = sload32(prog, pc0 * 4 + 3);
@@ -736,7 +817,7 @@ DEV void run_tile(const VvmExecDesc& d, const Ctx& c, uint32_t* lds_ctrl, uint32
 			op = w0 & 0xFFu; aux = (w0 >> 16) & 0xFFu; aux2 = w0 >> 24;
 			const uint32_t nin = (w0 >> 8) & 7u;
 			o0 = ins.w1 & 0xFFFFu; o1 = ins.w1 >> 16; o2 = ins.w2 & 0xFFFFu; o3 = ins.w2 >> 16; o4 = ins.w3 & 0xFFFFu; o5 = ins.w3 >> 16;
-			if (op - 1u >= VVM_DOP_LOADN - 1u) break;          // done (0) or a special instruction
+			if (op - 1u >= VVM_DOP_LOADN16 - 1u) break;        // done (0) or a special instruction
 
 			float r[V];
 			const uint32_t dst = o5;
@@ -958,40 +1039,76 @@ DEV void run_tile(const VvmExecDesc& d, const Ctx& c, uint32_t* lds_ctrl, uint32
 				kb |= ((fbits(p[k]) >> 31) & ((c.inst0 + k < c.num_instances) ? 1u : 0u)) << k;
 			const uint2 rt = acquire_rank_and_publish(kb, c.tid, lds_ctrl, status, tile_local, tag, dbg);
 			t_keep = kb; t_rank = rt.x; t_total = SCALAR(rt.y); t_dataset = aux; t_pending = true;
-			if (dbg & 64u) continue;      // experiment: resolve the prefix at the first output instead
-		}
-		// the exclusive prefix over the previous tiles
-		if (t_pending) {
-			t_base = SCALAR(acquire_resolve_prefix(t_total, c.tid, lds_ctrl, status, tile_local, d.num_tiles, VVM_BLOCK_THREADS * V, tag,
-			                                       error_word, d.counts + t_dataset, dbg));
-			t_pending = false;
+			if ((dbg & 256u) && !have_claim) {      // experiment: claim the next tile here, so that the round trip is over when this tile ends
+				if (c.tid == 0) claimed = __hip_atomic_fetch_add(ticket_word, 1u, RLX_AGENT);
+				have_claim = true;
+			}
+			continue;
 		}
 		if (op == VVM_OP_done) break;
-		if (op == VVM_DOP_ACQUIRE) continue;
-		// aux = pair count (1..3), aux2 = dataset; pairs (o0,o1) (o2,o3) (o4,o5) = (source, output serial index)
+
+		// Output instruction: aux = pair count (1..3), aux2 = dataset; pairs (o0,o1) (o2,o3) (o4,o5) = (source, output serial index).
+		// The survivors' values are compacted into an LDS staging slot; store_tile writes them out later.
 		const uint32_t total = (aux2 == t_dataset) ? t_total : 0u;    // no acquireindex for this dataset: nothing is written (VectorVMRuntime.cpp:565, 769)
 		const uint32_t valid = min(c.num_instances - (c.inst0 - c.tid * V), (uint32_t)(VVM_BLOCK_THREADS * V));
 		const bool all_alive = (total == valid) && c.full;
-		const uint32_t kind = op - VVM_DOP_OUTPUT32;          // the four output opcodes in the order of store_compact's kinds
+		const uint32_t kind = op - VVM_DOP_OUTPUT32;          // 0: 32-bit value  1: float -> half  2: low 16 bits as they are  3: half bits -> float
+		float* stage = (float*)(lds + LDS_STAGE_OFF);
+		uint32_t* meta = (uint32_t*)(lds + LDS_STAGE_META_OFF);
 #pragma unroll
 		for (int j = 0; j < 3; ++j) {
 			if ((uint32_t)j >= aux) break;
 			const uint32_t src = (j == 0) ? o0 : (j == 1) ? o2 : o4;
 			const uint32_t out_idx = (j == 0) ? o1 : (j == 1) ? o3 : o5;
 			const uint64_t base = sload64(c.out_ptrs, out_idx);
-			if (base == 0 || total == 0 || (dbg & 8u)) continue;
+			if (base == 0 || total == 0) continue;
+			if (n_staged == VVM_STAGE_SLOTS) {       // out of slots: write what is staged now (this waits for the look-back)
+				Pending cur;
+				cur.active = true; cur.unresolved = t_pending; cur.total = t_total; cur.base = t_base; cur.n_staged = n_staged;
+				cur.tile_local = tile_local; cur.num_tiles = d.num_tiles; cur.status = status; cur.count_out = d.counts + t_dataset;
+				resolve_tile<V>(cur, c.tid, lds_ctrl, tag, error_word, dbg);
+				store_tile<V>(cur, c.tid, lds, dbg);
+				__syncthreads();      // the slots are written again right away
+				t_base = cur.base; t_pending = false; n_staged = 0;
+			}
 			float v[V];
 			fetch<V, SPILL>(RARGS, uni, c, src, v);
-			if (kind == 0 && all_alive) {
-				float* q = (float*)base + t_base;
-				if constexpr (V == 4) { f4u x; x.x = v[0]; x.y = v[1]; x.z = v[2]; x.w = v[3]; *(f4u*)(q + c.tid * 4) = x; }
-				else q[c.tid] = v[0];
-			} else {
-				if constexpr (V == 4) store_compact(kind, base, t_base + t_rank, t_keep, v[0], v[1], v[2], v[3]);
-				else store_compact(kind, base, t_base + t_rank, t_keep, v[0], 0.0f, 0.0f, 0.0f);
+#pragma unroll
+			for (int k = 0; k < V; ++k) {
+				// (kind 3 is outputdata_float_from_half, whose handler in the reference is an empty stub, VectorVMRuntime.cpp:573-577)
+				const float h1 = bitsf(store_half(v[k])), h3 = load_half(fbits(v[k]));
+				v[k] = (kind == 1) ? h1 : ((kind == 3) ? h3 : v[k]);
 			}
+			float* slot = stage + n_staged * (VVM_BLOCK_THREADS * V);
+			if (all_alive) {
+				if constexpr (V == 4) { f4a x; x.x = v[0]; x.y = v[1]; x.z = v[2]; x.w = v[3]; *(f4a*)(slot + c.tid * 4) = x; }
+				else slot[c.tid] = v[0];
+			} else {
+				// survivor j of the lane goes to rank + j; a dead instance's value goes to the thread's sink dword (no per-lane branch)
+				float* sink = stage + VVM_STAGE_SLOTS * (VVM_BLOCK_THREADS * V) + c.tid;
+				uint32_t r = t_rank;
+#pragma unroll
+				for (int k = 0; k < V; ++k) {
+					const bool keep = (t_keep >> k) & 1u;
+					float* q = keep ? (slot + r) : sink;
+					*q = v[k];
+					r += keep ? 1u : 0u;
+				}
+			}
+			// every thread writes the same two words: no single-lane branch needed
+			meta[2 * n_staged] = (uint32_t)base; meta[2 * n_staged + 1] = (uint32_t)(base >> 32);
+			meta[2 * VVM_STAGE_SLOTS + n_staged] = kind;
+			++n_staged;
 		}
 	}
+	if ((dbg & 128u) && c.tid == 0) {
+		lds_ctrl[21] += (uint32_t)((tl1 - tl0) >> 4);
+		lds_ctrl[22] += (uint32_t)((__builtin_amdgcn_s_memtime() - tl1) >> 4);
+	}
+	// hand the rest of the tile's work to the next tile's load phase
+	pend.active = (n_staged > 0) || t_pending;
+	pend.unresolved = t_pending; pend.total = t_total; pend.base = t_base; pend.n_staged = n_staged;
+	pend.tile_local = tile_local; pend.num_tiles = d.num_tiles; pend.status = status; pend.count_out = d.counts + t_dataset;
 }
 
 template <int V, bool SPILL, bool FULL>
@@ -1000,7 +1117,10 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (FULL ? 2 : (V == 4 ? 4 : 8
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	uint32_t* lds_ctrl = (uint32_t*)lds;
 	uint8_t* lds_perlin = lds + LDS_PERLIN_OFF;
-	float* lds_spill = (float*)(lds + LDS_SPILL_OFF);
+	float* lds_spill = (float*)(lds + LDS_SPILL_OFF(V));
+	Pending pend;
+	pend.active = false; pend.unresolved = false; pend.total = 0; pend.base = 0; pend.n_staged = 0; pend.tile_local = 0; pend.num_tiles = 0;
+	pend.status = nullptr; pend.count_out = nullptr;
 	const uint32_t tid = threadIdx.x;
 	// ticket counter of this workgroup's class (see VvmLaunchState); with fewer workgroups than classes only the first
 	// gridDim.x counters are in use
@@ -1011,13 +1131,19 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (FULL ? 2 : (V == 4 ? 4 : 8
 	const uint32_t tag = SCALAR(__hip_atomic_load((gu32*)&env.ls->epoch, RLX_AGENT)) & 0x3FFFFFFFu;
 	bool perlin_ready = false;
 
+	if (tid < 8) lds_ctrl[16 + tid] = 0;
 	// A tile is claimed when the workgroup is ready to start it, never ahead of time: the look-back of a tile waits for the
 	// counts of all earlier tiles, so a tile that is claimed but not yet running stalls every later one.
+	uint32_t claimed = 0;
+	bool have_claim = false;
 	for (;;) {
 		__syncthreads();
-		if (tid == 0) lds_ctrl[10] = __hip_atomic_fetch_add(ticket_word, 1u, RLX_AGENT);
+		const u64 tk0 = (env.debug_skip & 128u) ? __builtin_amdgcn_s_memtime() : 0;
+		if (tid == 0) lds_ctrl[10] = have_claim ? claimed : __hip_atomic_fetch_add(ticket_word, 1u, RLX_AGENT);
+		have_claim = false;
 		__syncthreads();
 		const uint32_t draw = SCALAR(lds_ctrl[10]);
+		if ((env.debug_skip & 128u) && tid == 0) { lds_ctrl[20] += (uint32_t)((__builtin_amdgcn_s_memtime() - tk0) >> 4); lds_ctrl[23] += 1u; }
 		if (draw >= (env.total_tiles + classes - 1u - cls) / classes) break;      // this class has that many tiles
 		const uint32_t ticket = draw * classes + cls;
 
@@ -1049,6 +1175,7 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (FULL ? 2 : (V == 4 ? 4 : 8
 			d.rand_seed_hi = sload32(dp, offsetof(VvmExecDesc, rand_seed_hi) / 4);
 			d.rand_instance_base = (int32_t)sload32(dp, offsetof(VvmExecDesc, rand_instance_base) / 4);
 			d.flags = sload32(dp, offsetof(VvmExecDesc, flags) / 4);
+			d.num_unif = sload32(dp, offsetof(VvmExecDesc, num_unif) / 4);
 		}
 		const uint32_t tile_local = ticket - d.first_tile;
 		const uint32_t tile_first = tile_local * (VVM_BLOCK_THREADS * V);
@@ -1065,12 +1192,18 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (FULL ? 2 : (V == 4 ? 4 : 8
 		c.inst0 = tile_first + tid * V;
 		c.num_instances = d.num_instances;
 		c.full = (tile_first + VVM_BLOCK_THREADS * V) <= d.num_instances;
-		if (!(env.debug_skip & 1u)) run_tile<V, SPILL, FULL>(d, c, lds_ctrl, tile_local, tag, error_word, env.debug_skip);
+		if (!(env.debug_skip & 1u)) run_tile<V, SPILL, FULL>(d, c, lds, tile_local, tag, error_word, env.debug_skip, pend, ticket_word, claimed, have_claim);
+	}
+	if (pend.active) {
+		resolve_tile<V>(pend, tid, lds_ctrl, tag, error_word, env.debug_skip);
+		store_tile<V>(pend, tid, lds, env.debug_skip);
 	}
 
 	// the last block to leave re-arms the launch words for the next launch
 	__syncthreads();
 	if (tid == 0) {
+		if (env.debug_skip & 128u)
+			for (int i = 0; i < 8; ++i) __hip_atomic_fetch_add((gu64*)&env.ls->stats[i], (u64)lds_ctrl[16 + i], RLX_AGENT);
 		const uint32_t n = __hip_atomic_fetch_add((gu32*)&env.ls->done, 1u, RLX_AGENT);
 		if (n + 1 == gridDim.x) {
 			uint32_t next = (env.ls->epoch + 1u) & 0x3FFFFFFFu;
@@ -1090,7 +1223,7 @@ extern "C" int vvm_launch_exec_kernel(int instances_per_lane, const VvmExecDesc*
 	KernelEnv env;
 	env.descs = descs; env.num_execs = num_execs; env.total_tiles = total_tiles; env.ls = ls; env.lds_spill_slots = lds_spill_slots;
 	{ const char* dbg = getenv("VVM_DEBUG_SKIP"); env.debug_skip = dbg ? (uint32_t)strtoul(dbg, nullptr, 0) : 0u; }
-	const size_t lds_bytes = LDS_SPILL_OFF + (size_t)lds_spill_slots * VVM_BLOCK_THREADS * 4u * (size_t)instances_per_lane;
+	const size_t lds_bytes = (instances_per_lane == 4 ? LDS_SPILL_OFF(4) : LDS_SPILL_OFF(1)) + (size_t)lds_spill_slots * VVM_BLOCK_THREADS * 4u * (size_t)instances_per_lane;
 	const bool spill = lds_spill_slots > 0;
 #ifdef VVM_EXPERIMENT_ONE_KERNEL
 	(void)spill; (void)full; hipLaunchKernelGGL((vvm_exec_kernel<VVM_EXPERIMENT_ONE_KERNEL>), dim3(grid), dim3(VVM_BLOCK_THREADS), lds_bytes, stream, env);
@@ -1126,4 +1259,4 @@ extern "C" int vvm_kernel_max_dynamic_lds(void)
 }
 
 extern "C" uint32_t vvm_kernel_resident_registers(int instances_per_lane) { return instances_per_lane == 4 ? RegTraits<4>::RV : RegTraits<1>::RV; }
-extern "C" uint32_t vvm_kernel_lds_fixed_bytes(void) { return LDS_SPILL_OFF; }
+extern "C" uint32_t vvm_kernel_lds_fixed_bytes(int instances_per_lane) { return instances_per_lane == 4 ? LDS_SPILL_OFF(4) : LDS_SPILL_OFF(1); }

@@ -307,11 +307,31 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 	for (uint8_t a : lp.acquires_dataset) acquired += a;
 	if (acquired > 1) { err = "acquireindex on more than one dataset in one script is not supported by the GPU executor"; return VVM_E_UNSUPPORTED_OP; }
 
+	// Every advancing input stream the script reads is loaded once, at the start of a tile, into a per-lane register of its own
+	// (VVM_DOP_LOADN / VVM_DOP_LOADN16, eight streams per instruction, in order of first use; 32-bit streams first).  The
+	// interpreter loop itself then never touches stream memory.
+	std::vector<uint32_t> prefetch32, prefetch16;
+	{
+		std::vector<uint8_t> seen(I, 0);
+		for (const Decoded& d : ins) {
+			auto consider = [&](uint16_t r) {
+				if (r == VVM_INVALID_REG || r < T + C || r >= T + C + I) return;
+				const uint32_t i = r - (T + C);
+				if (seen[i] || lp.inputs[i].noadvance) return;
+				seen[i] = 1;
+				(lp.inputs[i].type == 2 ? prefetch16 : prefetch32).push_back(i);
+			};
+			for (uint16_t r : d.in) consider(r);
+			for (auto& p : d.pairs) consider(p.first);
+		}
+	}
+	const uint32_t num_loaded = (uint32_t)(prefetch32.size() + prefetch16.size());
+
 	// choose the kernel shape
 	uint32_t V = 4, RV = 16;
-	if (force_narrow || nv > RV + kMaxSpillWide) { V = 1; RV = 32; }
-	if (nv > RV + (V == 4 ? kMaxSpillWide : kMaxSpillNarrow)) {
-		snprintf(msg, sizeof(msg), "script needs %u per-lane registers; the executor holds at most %u", nv, RV + kMaxSpillNarrow);
+	if (force_narrow || nv + num_loaded > RV + kMaxSpillWide) { V = 1; RV = 32; }
+	if (nv + num_loaded > RV + (V == 4 ? kMaxSpillWide : kMaxSpillNarrow)) {
+		snprintf(msg, sizeof(msg), "script needs %u per-lane registers; the executor holds at most %u", nv + num_loaded, RV + kMaxSpillNarrow);
 		err = msg;
 		return VVM_E_TOO_LARGE;
 	}
@@ -326,24 +346,12 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 	}
 	uint32_t next_vreg = nv;
 
-	// prefetch: advancing 32-bit inputs go to the free resident registers, in order of first use, eight per VVM_DOP_LOADN
+	// the loaded inputs follow the temps (consecutive numbers, which is what the load instructions address); when the resident
+	// registers run out they are the first to live in LDS
 	std::vector<int32_t> input_vreg(I, -1);
-	std::vector<uint32_t> prefetch;
-	if (next_vreg < RV) {
-		for (const Decoded& d : ins) {
-			auto consider = [&](uint16_t r) {
-				if (r == VVM_INVALID_REG || r < T + C || r >= T + C + I) return;
-				const uint32_t i = r - (T + C);
-				if (input_vreg[i] >= 0 || lp.inputs[i].noadvance || lp.inputs[i].type == 2) return;
-				if (next_vreg >= RV) return;
-				input_vreg[i] = (int32_t)next_vreg++;
-				prefetch.push_back(i);
-			};
-			for (uint16_t r : d.in) consider(r);
-			for (auto& p : d.pairs) consider(p.first);
-		}
-	}
-	lp.num_prefetched_inputs = (uint32_t)prefetch.size();
+	for (uint32_t i : prefetch32) input_vreg[i] = (int32_t)next_vreg++;
+	for (uint32_t i : prefetch16) input_vreg[i] = (int32_t)next_vreg++;
+	lp.num_prefetched_inputs = num_loaded;
 	lp.num_vregs = next_vreg;
 	lp.instances_per_lane = V;
 	lp.resident_regs = RV;
@@ -358,9 +366,7 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 		if (r < T + C + I) {
 			const uint32_t i = r - (T + C);
 			if (input_vreg[i] >= 0) return VVM_OPND(VVM_OPC_VREG, (uint32_t)input_vreg[i]);
-			const InputInfo& in = lp.inputs[i];
-			if (in.type == 2) return VVM_OPND(in.noadvance ? VVM_OPC_NOADV_HALF : VVM_OPC_HALF, i);
-			return VVM_OPND(in.noadvance ? VVM_OPC_NOADV : VVM_OPC_INPUT, i);
+			return VVM_OPND(lp.inputs[i].type == 2 ? VVM_OPC_NOADV_HALF : VVM_OPC_NOADV, i);
 		}
 		if (r < out0) return VVM_OPND(VVM_OPC_NONE, 0);   // input base copies: never operands
 		return VVM_OPND(VVM_OPC_VREG, place[(size_t)out_vreg[r - out0]]);
@@ -396,20 +402,24 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 			lp.code.push_back(k);
 		}
 	};
-	for (size_t i = 0; i < prefetch.size(); i += 8) {
-		const size_t n = std::min<size_t>(8, prefetch.size() - i);
-		uint64_t lo = 0; uint32_t hi = 0;     // eight 12-bit stream indices in 96 bits
-		for (size_t j = 0; j < n; ++j) {
-			const uint64_t idx = prefetch[i + j] & 0xFFFu;
-			const unsigned bit = 12u * (unsigned)j;
-			if (bit < 64) { lo |= idx << bit; if (bit + 12 > 64) hi |= (uint32_t)(idx >> (64 - bit)); }
-			else hi |= (uint32_t)(idx << (bit - 64));
+	auto emit_loads = [&](const std::vector<uint32_t>& prefetch, uint32_t dop) {
+		for (size_t i = 0; i < prefetch.size(); i += 8) {
+			const size_t n = std::min<size_t>(8, prefetch.size() - i);
+			uint64_t lo = 0; uint32_t hi = 0;     // eight 12-bit stream indices in 96 bits
+			for (size_t j = 0; j < n; ++j) {
+				const uint64_t idx = prefetch[i + j] & 0xFFFu;
+				const unsigned bit = 12u * (unsigned)j;
+				if (bit < 64) { lo |= idx << bit; if (bit + 12 > 64) hi |= (uint32_t)(idx >> (64 - bit)); }
+				else hi |= (uint32_t)(idx << (bit - 64));
+			}
+			VvmIns k;
+			k.w0 = VVM_INS_W0(dop, 0, 0, n, (uint32_t)input_vreg[prefetch[i]]);
+			k.w1 = (uint32_t)lo; k.w2 = (uint32_t)(lo >> 32); k.w3 = hi;
+			lp.code.push_back(k);
 		}
-		VvmIns k;
-		k.w0 = VVM_INS_W0(VVM_DOP_LOADN, 0, 0, n, (uint32_t)input_vreg[prefetch[i]]);
-		k.w1 = (uint32_t)lo; k.w2 = (uint32_t)(lo >> 32); k.w3 = hi;
-		lp.code.push_back(k);
-	}
+	};
+	emit_loads(prefetch32, VVM_DOP_LOADN);
+	emit_loads(prefetch16, VVM_DOP_LOADN16);
 	uint32_t rand_ordinal = 0;
 	for (const Decoded& d : ins) {
 		VvmIns k{0, 0, 0, 0};
