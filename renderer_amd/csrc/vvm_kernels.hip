@@ -62,7 +62,7 @@ template <typename VEC> __device__ __forceinline__ float vget(VEC v, uint32_t i)
 template <typename VEC> __device__ __forceinline__ VEC vset(VEC v, uint32_t i, float x) { v[i] = x; return v; }
 
 // LDS carve (dynamic region only, every offset a multiple of 16)
-//   [0, 256)      control words (uint32): [0..3] wave totals, [9] prefix, [10] ticket, [16..19] look-back statistics
+//   [0, 256)      control words (uint32), see the LC_ constants
 //   [256, 768)    Perlin permutation table
 //   [768, 896)    staged outputs: destination address (uint64 x VVM_STAGE_SLOTS) then kind (uint32 x VVM_STAGE_SLOTS)
 //   [896, ...)    output staging: VVM_STAGE_SLOTS slots of one tile's worth of 32-bit values, then one sink dword per thread
@@ -432,9 +432,12 @@ struct Ctx {
 	const uint8_t*  perlin_lds;
 	float*          spill;        // LDS, [slot][thread] (V floats per thread and slot)
 	uint32_t tid;
+	uint32_t wave;                // tid / 64 as a scalar
 	uint32_t inst0;               // index (within the Exec) of the lane's first instance
 	uint32_t num_instances;
-	bool     full;                // the whole tile is inside [0, num_instances)
+	uint32_t tile_first;          // index of the tile's first instance
+	uint32_t valid;               // instances of the tile that exist (the Exec's last tile may be partial)
+	uint32_t phase;               // tiles this workgroup has started; its parity selects the LDS word of double-buffered exchanges
 };
 
 // Register access.  The index is wave-uniform.  The VGPR vectors are read and written unconditionally (a branch around an
@@ -482,47 +485,58 @@ template <int V, bool SPILL> DEV void reg_spill(const Ctx& c, bool enable, uint3
 	} while (0)
 #define REG_WRITE(idx, arr) REG_WRITE_IF(true, idx, arr)
 
-// ---- stream access ------------------------------------------------------------------------------------
-// The loop that interprets ordinary instructions must not contain a single per-lane branch (see the note at f_div), and an
-// operand fetch can be a stream load.  In the last, partial tile of an Exec the loads therefore clamp the element index to
-// the last instance (num_instances >= 1 whenever a tile exists) and select zero for the instances past the end.
+// ---- memory access ------------------------------------------------------------------------------------
+// No branch in this kernel depends on the lane: every `if` and every loop condition is wave-uniform, and the kernel is compiled
+// so that such branches stay plain scalar branches.  One per-lane branch would make the compiler rewrite the control flow of
+// everything around it into flag-guarded if-chains, interpreter loop included (about three times the branches per interpreted
+// instruction).  Whatever has to happen for some lanes only goes through the bounds check of a buffer descriptor instead:
+// a lane that must not take part addresses past the end of the descriptor's range, where the hardware drops stores and
+// atomics and returns zero for loads (multi-dword accesses are checked per dword).
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+#define VVM_RSRC_FLAGS 0x00020000      // raw buffer, 32-bit data format (descriptor dword 3 for this target family)
+#define AUX_STREAM 2                   // nt: streamed once, keep it out of the way of the caches
+#define AUX_AGENT  16                  // sc1: device-scope visibility, what a relaxed agent-scope atomic access uses here
+DEV rsrc_t make_rsrc(uint64_t base, uint32_t num_bytes) { return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)num_bytes, VVM_RSRC_FLAGS); }
+
+// The tile's part of an input stream: lane t reads elements [V*t, V*t + V) of the tile; elements past the Exec's end read 0.
 template <int V> DEV void load_stream32(const Ctx& c, uint64_t base, float (&out)[V])
 {
-	if (c.full) {
-		const float* p = (const float*)base + c.inst0;
-		if constexpr (V == 4) { const f4u v = *(const f4u*)p; out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w; }
-		else out[0] = p[0];
+	const rsrc_t rs = make_rsrc(base + 4ull * c.tile_first, 4u * c.valid);
+	if constexpr (V == 4) {
+		const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(c.tid * 16u), 0, AUX_STREAM);
+		out[0] = bitsf(v.x); out[1] = bitsf(v.y); out[2] = bitsf(v.z); out[3] = bitsf(v.w);
 	} else {
-#pragma unroll
-		for (int k = 0; k < V; ++k) {
-			const uint32_t i = c.inst0 + k;
-			const float x = ((const float*)base)[min(i, c.num_instances - 1u)];
-			out[k] = (i < c.num_instances) ? x : 0.0f;
-		}
+		out[0] = bitsf(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(c.tid * 4u), 0, AUX_STREAM));
 	}
 }
 template <int V> DEV void load_stream16(const Ctx& c, uint64_t base, float (&out)[V])    // raw half bits, zero-extended
 {
-	if (c.full) {
-		const uint16_t* p = (const uint16_t*)base + c.inst0;
-		if constexpr (V == 4) { const h4u v = *(const h4u*)p; out[0] = bitsf(v.x); out[1] = bitsf(v.y); out[2] = bitsf(v.z); out[3] = bitsf(v.w); }
-		else out[0] = bitsf(p[0]);
-	} else {
+	const rsrc_t rs = make_rsrc(base + 2ull * c.tile_first, 2u * c.valid);
 #pragma unroll
-		for (int k = 0; k < V; ++k) {
-			const uint32_t i = c.inst0 + k;
-			const uint32_t x = ((const uint16_t*)base)[min(i, c.num_instances - 1u)];
-			out[k] = bitsf((i < c.num_instances) ? x : 0u);
-		}
-	}
+	for (int k = 0; k < V; ++k)
+		out[k] = bitsf((uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)((c.tid * V + k) * 2u), 0, AUX_STREAM));
+}
+// 64-bit device-scope store by the first lane of the calling wave
+DEV void store_u64_first_lane(gu64* addr, u64 value, uint32_t lane)
+{
+	const rsrc_t rs = make_rsrc((uint64_t)addr, 8u);
+	u32x2 v; v.x = (uint32_t)value; v.y = (uint32_t)(value >> 32);
+	__builtin_amdgcn_raw_buffer_store_b64(v, rs, (int)(lane == 0 ? 0u : 8u), 0, AUX_AGENT);
+}
+// device-scope fetch-and-add by the first lane of the calling wave; returns the old value as a scalar
+DEV uint32_t fetch_add_first_lane(gu32* addr, uint32_t value, uint32_t lane)
+{
+	const rsrc_t rs = make_rsrc((uint64_t)addr, 4u);
+	const int old = __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32((int)value, rs, (int)(lane == 0 ? 0u : 4u), 0, AUX_AGENT);
+	return SCALAR(old);
 }
 
 // Decoupled look-back over the Exec's tile words; called by wave 0 only.  Returns the exclusive prefix of `tile`.
 // Each round reads the VVM_LB_WINDOW tiles before `first` (VVM_LB_WINDOW / 64 words per lane, all loads in flight together),
 // waits until every one of them carries this launch's tag, and sums the counts back to the nearest tile whose word already
-// holds an inclusive prefix.  The window is sized to the number of tiles that are typically between a tile and the nearest
-// resolved predecessor (tiles start at ~65 per microsecond on a full device and a round trip takes a few microseconds),
-// so that one round is the common case.
+// holds an inclusive prefix.
 #define VVM_LB_WINDOW 256
 DEV uint32_t look_back(gu64* status, uint32_t tile, uint32_t tag, uint32_t lane, gu32* error_word, uint32_t& rounds, uint32_t& polls)
 {
@@ -565,14 +579,19 @@ DEV uint32_t look_back(gu64* status, uint32_t tile, uint32_t tag, uint32_t lane,
 	}
 }
 
+// LDS control words
+#define LC_WAVE_TOTALS 0      // [2][4]  survivor count of each wave, by parity of the tile
+#define LC_PREFIX      8      // [2]     resolved prefix, by parity of the resolve
+#define LC_TICKET      10     // [2]     claimed ticket, by parity of the tile
+#define LC_STATS       16     // [8]     profiling sums
+
 // acquireindex, first half: rank the tile's survivors and publish the tile's count.
 // keep_bits: bit k = instance k of the lane survives.  Returns (rank of the lane's first survivor within the tile, survivors
 // in the tile).  Survivors keep instance order (VectorVMRuntime.cpp:786-804, 824-878): a lane's instances are consecutive,
 // lanes are in instance order, so the rank is the number of surviving instances of all lower lanes and waves.
-DEV uint2 acquire_rank_and_publish(uint32_t keep_bits, uint32_t tid, uint32_t* lds_ctrl, gu64* status, uint32_t tile_local,
-                                                       uint32_t tag, uint32_t dbg)
+DEV uint2 acquire_rank_and_publish(uint32_t keep_bits, const Ctx& c, uint32_t* lds_ctrl, gu64* status, uint32_t tile_local, uint32_t tag, uint32_t dbg)
 {
-	const uint32_t lane = tid & 63u, wave = tid >> 6;
+	const uint32_t lane = c.tid & 63u;
 	uint32_t below = 0, wave_total = 0;
 #pragma unroll
 	for (int k = 0; k < 4; ++k) {
@@ -580,53 +599,23 @@ DEV uint2 acquire_rank_and_publish(uint32_t keep_bits, uint32_t tid, uint32_t* l
 		below += lanes_below(b);
 		wave_total += (uint32_t)__popcll(b);
 	}
-	__syncthreads();
-	if (lane == 0) lds_ctrl[wave] = wave_total;
-	__syncthreads();
+	uint32_t* totals = lds_ctrl + LC_WAVE_TOTALS + 4u * (c.phase & 1u);
+	totals[c.wave] = wave_total;            // every lane writes the wave's value
+	__syncthreads();                        // (the words alternate between tiles, so one barrier is enough)
 	uint32_t wave_off = 0, total = 0;
 #pragma unroll
 	for (uint32_t w = 0; w < VVM_BLOCK_THREADS / 64; ++w) {
-		const uint32_t x = lds_ctrl[w];
-		wave_off += (w < wave) ? x : 0u;
+		const uint32_t x = totals[w];
+		wave_off += (w < c.wave) ? x : 0u;
 		total += x;
 	}
-	if (tid == 0) {
+	total = SCALAR(total);
+	if (c.wave == 0 && !(tile_local == 0 && (dbg & 4u))) {
 		// the first tile's count is its inclusive prefix already
 		const u64 flag = (tile_local == 0) ? VVM_LB_INCLUSIVE : VVM_LB_AGGREGATE;
-		if (!(tile_local == 0 && (dbg & 4u))) __hip_atomic_store(status + tile_local, ((u64)tag << 34) | (flag << 32) | total, RLX_AGENT);
+		store_u64_first_lane(status + tile_local, ((u64)tag << 34) | (flag << 32) | total, lane);
 	}
 	return make_uint2(wave_off + below, total);
-}
-
-// acquireindex, second half: the exclusive prefix over the Exec's previous tiles.  Runs when the first output instruction
-// needs it (or at the end of the program), so that the instructions between the acquireindex and the outputs cover the
-// latency of the look-back.  The Exec's last tile also writes the dataset's survivor count.
-DEV uint32_t acquire_resolve_prefix(uint32_t total, uint32_t tid, uint32_t* lds_ctrl, gu64* status, uint32_t tile_local,
-                                                        uint32_t num_tiles, uint32_t tile_instances, uint32_t tag, gu32* error_word,
-                                                        int32_t* count_out, uint32_t dbg)
-{
-	uint32_t base = 0;
-	if (tile_local == 0) {
-		__syncthreads();      // callers rely on one barrier in here (see resolve_tile)
-	} else {
-		if ((tid >> 6) == 0) {
-			uint32_t rounds = 0, polls = 0;
-			const u64 t0 = (dbg & 128u) ? __builtin_amdgcn_s_memtime() : 0;
-			const uint32_t ex = (dbg & 32u) ? tile_local * tile_instances : look_back(status, tile_local, tag, tid & 63u, error_word, rounds, polls);
-			if (tid == 0) {
-				lds_ctrl[9] = ex;
-				__hip_atomic_store(status + tile_local, ((u64)tag << 34) | (VVM_LB_INCLUSIVE << 32) | (ex + total), RLX_AGENT);
-				if (dbg & 128u) {      // per-workgroup sums, added to VvmLaunchState::stats when the workgroup leaves
-					lds_ctrl[16] += 1u; lds_ctrl[17] += rounds; lds_ctrl[18] += polls;
-					lds_ctrl[19] += (uint32_t)((__builtin_amdgcn_s_memtime() - t0) >> 4);
-				}
-			}
-		}
-		__syncthreads();
-		base = lds_ctrl[9];
-	}
-	if (tile_local + 1 == num_tiles && tid == 0 && !(dbg & 16u)) *count_out = (int32_t)(base + total);
-	return base;
 }
 
 // What is left to do for a tile whose program has run: its outputs sit compacted in the LDS staging slots, and its prefix
@@ -644,45 +633,64 @@ struct Pending {
 
 // Finishing a tile takes two steps, both run by the NEXT tile while its input loads are in flight (also when the staging
 // slots run out, and after the last tile):
-//   resolve_tile  the look-back for the tile's exclusive prefix.  Its polls queue behind the input loads, so the two latencies
-//                 overlap instead of adding up.
+//   resolve_tile  the look-back for the tile's exclusive prefix (acquireindex, second half).  Its polls queue behind the
+//                 input loads, so the two latencies overlap instead of adding up.  The Exec's last tile also writes the
+//                 dataset's survivor count.  Contains one barrier, after which every thread's staged values are visible.
 //   store_tile    survivor i of the tile (the survivors were compacted when they were staged) goes to element base + i of
-//                 each staged output.  A thread moves V consecutive values, so every tile without a partial tail stores
-//                 128 bits per lane whatever its death rate.  Issued after the next tile's loads have arrived: stores and
-//                 loads share one completion counter, and a wait for loads would otherwise also wait for these stores.
-template <int V> DEV void resolve_tile(Pending& p, uint32_t tid, uint32_t* lds_ctrl, uint32_t tag, gu32* error_word, uint32_t dbg)
+//                 each staged output.  A thread moves V consecutive values, so every tile stores 128 bits per lane whatever
+//                 its death rate.  Issued after the next tile's loads have arrived: stores and loads share one completion
+//                 counter, and a wait for loads would otherwise also wait for these stores.
+template <int V> DEV void resolve_tile(Pending& p, const Ctx& c, uint32_t* lds_ctrl, uint32_t& resolves, uint32_t tag, gu32* error_word, uint32_t dbg)
 {
-	if (p.unresolved) {
-		p.base = SCALAR(acquire_resolve_prefix(p.total, tid, lds_ctrl, p.status, p.tile_local, p.num_tiles, VVM_BLOCK_THREADS * V, tag,
-		                                       error_word, p.count_out, dbg));
-		p.unresolved = false;
+	if (p.unresolved && p.tile_local != 0) {
+		uint32_t* slot = lds_ctrl + LC_PREFIX + (resolves & 1u);
+		++resolves;
+		if (c.wave == 0) {
+			const uint32_t lane = c.tid & 63u;
+			uint32_t rounds = 0, polls = 0;
+			const u64 t0 = (dbg & 128u) ? __builtin_amdgcn_s_memtime() : 0;
+			const uint32_t ex = (dbg & 32u) ? p.tile_local * (VVM_BLOCK_THREADS * V) : look_back(p.status, p.tile_local, tag, lane, error_word, rounds, polls);
+			*slot = ex;
+			store_u64_first_lane(p.status + p.tile_local, ((u64)tag << 34) | (VVM_LB_INCLUSIVE << 32) | (ex + p.total), lane);
+			if (dbg & 128u) {      // per-workgroup sums (all lanes of wave 0 write the same values)
+				uint32_t* st = lds_ctrl + LC_STATS;
+				const uint32_t s0 = st[0] + 1u, s1 = st[1] + rounds, s2 = st[2] + polls, s3 = st[3] + (uint32_t)((__builtin_amdgcn_s_memtime() - t0) >> 4);
+				st[0] = s0; st[1] = s1; st[2] = s2; st[3] = s3;
+			}
+		}
+		__syncthreads();
+		p.base = SCALAR(*slot);
 	} else {
-		__syncthreads();      // (acquire_resolve_prefix has one) every thread's staged values are in LDS
+		__syncthreads();
+		if (p.unresolved) p.base = 0;
 	}
+	if (p.unresolved && p.tile_local + 1 == p.num_tiles && c.wave == 0 && !(dbg & 16u)) *p.count_out = (int32_t)(p.base + p.total);
+	p.unresolved = false;
 }
-template <int V> DEV void store_tile(Pending& p, uint32_t tid, unsigned char* lds, uint32_t dbg)
+template <int V> DEV void store_tile(Pending& p, const Ctx& c, unsigned char* lds, uint32_t dbg)
 {
 	const uint32_t* meta = (const uint32_t*)(lds + LDS_STAGE_META_OFF);
 	const float* stage = (const float*)(lds + LDS_STAGE_OFF);
-	const uint32_t i0 = tid * V;
+	const uint32_t i0 = c.tid * V;
 	for (uint32_t s = 0; s < p.n_staged; ++s) {
 		const uint64_t ptr = ((uint64_t)SCALAR(meta[2 * s + 1]) << 32) | (uint64_t)SCALAR(meta[2 * s]);
 		const uint32_t kind = SCALAR(meta[2 * VVM_STAGE_SLOTS + s]);
 		const float* src = stage + s * (VVM_BLOCK_THREADS * V) + i0;
 		if (dbg & 8u) continue;
-		if (kind == 0 || kind == 3) {          // 32-bit destination
-			float* dst = (float*)ptr + p.base + i0;
+		if (kind == 0 || kind == 3) {          // 32-bit destination; elements at and past `total` are dropped by the bounds check
+			const rsrc_t rs = make_rsrc(ptr + 4ull * p.base, 4u * p.total);
 			if constexpr (V == 4) {
-				if (i0 + 4 <= p.total) { const f4a x = *(const f4a*)src; f4u y; y.x = x.x; y.y = x.y; y.z = x.z; y.w = x.w; *(f4u*)dst = y; }
-				else {
-#pragma unroll
-					for (int k = 0; k < 4; ++k) if (i0 + k < p.total) dst[k] = src[k];
-				}
-			} else if (i0 < p.total) dst[0] = src[0];
+				const f4a x = *(const f4a*)src;
+				u32x4 y; y.x = fbits(x.x); y.y = fbits(x.y); y.z = fbits(x.z); y.w = fbits(x.w);
+				__builtin_amdgcn_raw_buffer_store_b128(y, rs, (int)(i0 * 4u), 0, AUX_STREAM);
+			} else {
+				__builtin_amdgcn_raw_buffer_store_b32(fbits(src[0]), rs, (int)(i0 * 4u), 0, AUX_STREAM);
+			}
 		} else {                               // 16-bit destination, the staged value holds the bits
-			uint16_t* dst = (uint16_t*)ptr + p.base + i0;
+			const rsrc_t rs = make_rsrc(ptr + 2ull * p.base, 2u * p.total);
 #pragma unroll
-			for (int k = 0; k < V; ++k) if (i0 + k < p.total) dst[k] = (uint16_t)fbits(src[k]);
+			for (int k = 0; k < V; ++k)
+				__builtin_amdgcn_raw_buffer_store_b16((uint16_t)fbits(src[k]), rs, (int)((i0 + k) * 2u), 0, AUX_STREAM);
 		}
 	}
 	p.n_staged = 0;
@@ -734,7 +742,7 @@ struct KernelEnv {
 // ------------------------------------------------------------------------------------------------------
 template <int V, bool SPILL, bool FULL>
 DEV void run_tile(const VvmExecDesc& d, const Ctx& c, unsigned char* lds, uint32_t tile_local, uint32_t tag, gu32* error_word, uint32_t dbg, Pending& pend,
-                  gu32* ticket_word, uint32_t& claimed, bool& have_claim)
+                  uint32_t& resolves)
 {
 	RVEC R0 = 0.0f, R1 = 0.0f, R2 = 0.0f, R3 = 0.0f;
 	uint32_t* lds_ctrl = (uint32_t*)lds;
@@ -752,9 +760,9 @@ DEV void run_tile(const VvmExecDesc& d, const Ctx& c, unsigned char* lds, uint32
 	const uint32_t uni = fill_uniforms<0>(0u, c.consts, d.num_unif);
 	const u64 tl0 = (dbg & 128u) ? __builtin_amdgcn_s_memtime() : 0;
 
-	// Prologue: the program starts with its VVM_DOP_LOADN / VVM_DOP_LOADN16 instructions.  They run in a loop of their own so that the main
-	// loop below has exactly one place that inserts into the register vectors (with two, the compiler keeps a second copy
-	// of the whole register file alive across the loop).
+	// Prologue: the program starts with its VVM_DOP_LOADN / VVM_DOP_LOADN16 instructions.  They run in a loop of their own so
+	// that the main loop below has exactly one place that inserts into the register vectors (with two, the compiler keeps a
+	// second copy of the whole register file alive across the loop).
 	uint32_t pc0 = 0;
 	for (;; ++pc0) {
 		VvmIns ins;
@@ -780,22 +788,20 @@ DEV void run_tile(const VvmExecDesc& d, const Ctx& c, unsigned char* lds, uint32
 		}
 		// the previous tile's look-back runs while these loads are in flight, its stores are issued once they have arrived
 		const bool finish_previous = pend.active;
-		if (finish_previous) resolve_tile<V>(pend, c.tid, lds_ctrl, tag, error_word, dbg);
+		if (finish_previous) resolve_tile<V>(pend, c, lds_ctrl, resolves, tag, error_word, dbg);
 #pragma unroll
 		for (int j = 0; j < 8; ++j)
 			REG_WRITE_IF((uint32_t)j < aux, aux2 + j, st[j]);
-		if (finish_previous) store_tile<V>(pend, c.tid, lds, dbg);
+		if (finish_previous) store_tile<V>(pend, c, lds, dbg);
 	}
 	if (pend.active) {      // a program without stream loads
-		resolve_tile<V>(pend, c.tid, lds_ctrl, tag, error_word, dbg);
-		store_tile<V>(pend, c.tid, lds, dbg);
+		resolve_tile<V>(pend, c, lds_ctrl, resolves, tag, error_word, dbg);
+		store_tile<V>(pend, c, lds, dbg);
 	}
 
 	// The program is a sequence of runs of ordinary instructions separated by the few special ones (acquireindex, outputs,
-	// the end).  The inner loop interprets one run; all of its control flow is wave-uniform, which the kernel is compiled to
-	// keep as direct scalar branches.  The special instructions, which need per-lane branches (single-lane publishes,
-	// compacting stores), are handled between runs, outside that loop.  The next instruction is always fetched while the
-	// current one executes.
+	// the end).  The inner loop interprets one run; the special instructions are handled between runs.  The next instruction
+	// is always fetched while the current one executes.
 	//
 	// Every ordinary instruction ends at the single register write at the bottom of the inner loop: each device instruction has
 	// exactly one destination register (the linker splits the reference's two-output ops and the three-output noise
@@ -1037,12 +1043,8 @@ DEV void run_tile(const VvmExecDesc& d, const Ctx& c, unsigned char* lds, uint32
 #pragma unroll
 			for (int k = 0; k < V; ++k)
 				kb |= ((fbits(p[k]) >> 31) & ((c.inst0 + k < c.num_instances) ? 1u : 0u)) << k;
-			const uint2 rt = acquire_rank_and_publish(kb, c.tid, lds_ctrl, status, tile_local, tag, dbg);
+			const uint2 rt = acquire_rank_and_publish(kb, c, lds_ctrl, status, tile_local, tag, dbg);
 			t_keep = kb; t_rank = rt.x; t_total = SCALAR(rt.y); t_dataset = aux; t_pending = true;
-			if ((dbg & 256u) && !have_claim) {      // experiment: claim the next tile here, so that the round trip is over when this tile ends
-				if (c.tid == 0) claimed = __hip_atomic_fetch_add(ticket_word, 1u, RLX_AGENT);
-				have_claim = true;
-			}
 			continue;
 		}
 		if (op == VVM_OP_done) break;
@@ -1050,8 +1052,7 @@ DEV void run_tile(const VvmExecDesc& d, const Ctx& c, unsigned char* lds, uint32
 		// Output instruction: aux = pair count (1..3), aux2 = dataset; pairs (o0,o1) (o2,o3) (o4,o5) = (source, output serial index).
 		// The survivors' values are compacted into an LDS staging slot; store_tile writes them out later.
 		const uint32_t total = (aux2 == t_dataset) ? t_total : 0u;    // no acquireindex for this dataset: nothing is written (VectorVMRuntime.cpp:565, 769)
-		const uint32_t valid = min(c.num_instances - (c.inst0 - c.tid * V), (uint32_t)(VVM_BLOCK_THREADS * V));
-		const bool all_alive = (total == valid) && c.full;
+		const bool all_alive = (total == VVM_BLOCK_THREADS * V);
 		const uint32_t kind = op - VVM_DOP_OUTPUT32;          // 0: 32-bit value  1: float -> half  2: low 16 bits as they are  3: half bits -> float
 		float* stage = (float*)(lds + LDS_STAGE_OFF);
 		uint32_t* meta = (uint32_t*)(lds + LDS_STAGE_META_OFF);
@@ -1066,18 +1067,19 @@ DEV void run_tile(const VvmExecDesc& d, const Ctx& c, unsigned char* lds, uint32
 				Pending cur;
 				cur.active = true; cur.unresolved = t_pending; cur.total = t_total; cur.base = t_base; cur.n_staged = n_staged;
 				cur.tile_local = tile_local; cur.num_tiles = d.num_tiles; cur.status = status; cur.count_out = d.counts + t_dataset;
-				resolve_tile<V>(cur, c.tid, lds_ctrl, tag, error_word, dbg);
-				store_tile<V>(cur, c.tid, lds, dbg);
+				resolve_tile<V>(cur, c, lds_ctrl, resolves, tag, error_word, dbg);
+				store_tile<V>(cur, c, lds, dbg);
 				__syncthreads();      // the slots are written again right away
 				t_base = cur.base; t_pending = false; n_staged = 0;
 			}
 			float v[V];
 			fetch<V, SPILL>(RARGS, uni, c, src, v);
+			if (kind == 1) {
 #pragma unroll
-			for (int k = 0; k < V; ++k) {
-				// (kind 3 is outputdata_float_from_half, whose handler in the reference is an empty stub, VectorVMRuntime.cpp:573-577)
-				const float h1 = bitsf(store_half(v[k])), h3 = load_half(fbits(v[k]));
-				v[k] = (kind == 1) ? h1 : ((kind == 3) ? h3 : v[k]);
+				for (int k = 0; k < V; ++k) v[k] = bitsf(store_half(v[k]));
+			} else if (kind == 3) {      // outputdata_float_from_half, whose handler in the reference is an empty stub (VectorVMRuntime.cpp:573-577)
+#pragma unroll
+				for (int k = 0; k < V; ++k) v[k] = load_half(fbits(v[k]));
 			}
 			float* slot = stage + n_staged * (VVM_BLOCK_THREADS * V);
 			if (all_alive) {
@@ -1101,9 +1103,10 @@ DEV void run_tile(const VvmExecDesc& d, const Ctx& c, unsigned char* lds, uint32
 			++n_staged;
 		}
 	}
-	if ((dbg & 128u) && c.tid == 0) {
-		lds_ctrl[21] += (uint32_t)((tl1 - tl0) >> 4);
-		lds_ctrl[22] += (uint32_t)((__builtin_amdgcn_s_memtime() - tl1) >> 4);
+	if ((dbg & 128u) && c.wave == 0) {
+		uint32_t* st = lds_ctrl + LC_STATS;
+		const uint32_t s5 = st[5] + (uint32_t)((tl1 - tl0) >> 4), s6 = st[6] + (uint32_t)((__builtin_amdgcn_s_memtime() - tl1) >> 4);
+		st[5] = s5; st[6] = s6;
 	}
 	// hand the rest of the tile's work to the next tile's load phase
 	pend.active = (n_staged > 0) || t_pending;
@@ -1122,6 +1125,7 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (FULL ? 2 : (V == 4 ? 4 : 8
 	pend.active = false; pend.unresolved = false; pend.total = 0; pend.base = 0; pend.n_staged = 0; pend.tile_local = 0; pend.num_tiles = 0;
 	pend.status = nullptr; pend.count_out = nullptr;
 	const uint32_t tid = threadIdx.x;
+	const uint32_t wave = SCALAR(tid >> 6), lane = tid & 63u;
 	// ticket counter of this workgroup's class (see VvmLaunchState); with fewer workgroups than classes only the first
 	// gridDim.x counters are in use
 	const uint32_t classes = min(gridDim.x, VVM_TICKET_CLASSES);
@@ -1130,20 +1134,22 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (FULL ? 2 : (V == 4 ? 4 : 8
 	gu32* error_word = (gu32*)&env.ls->pad;
 	const uint32_t tag = SCALAR(__hip_atomic_load((gu32*)&env.ls->epoch, RLX_AGENT)) & 0x3FFFFFFFu;
 	bool perlin_ready = false;
+	uint32_t resolves = 0;
 
-	if (tid < 8) lds_ctrl[16 + tid] = 0;
+	if (wave == 0) lds_ctrl[LC_STATS + (lane & 7u)] = 0;
 	// A tile is claimed when the workgroup is ready to start it, never ahead of time: the look-back of a tile waits for the
 	// counts of all earlier tiles, so a tile that is claimed but not yet running stalls every later one.
-	uint32_t claimed = 0;
-	bool have_claim = false;
-	for (;;) {
-		__syncthreads();
+	for (uint32_t phase = 0;; ++phase) {
 		const u64 tk0 = (env.debug_skip & 128u) ? __builtin_amdgcn_s_memtime() : 0;
-		if (tid == 0) lds_ctrl[10] = have_claim ? claimed : __hip_atomic_fetch_add(ticket_word, 1u, RLX_AGENT);
-		have_claim = false;
-		__syncthreads();
-		const uint32_t draw = SCALAR(lds_ctrl[10]);
-		if ((env.debug_skip & 128u) && tid == 0) { lds_ctrl[20] += (uint32_t)((__builtin_amdgcn_s_memtime() - tk0) >> 4); lds_ctrl[23] += 1u; }
+		uint32_t* slot = lds_ctrl + LC_TICKET + (phase & 1u);
+		if (wave == 0) *slot = fetch_add_first_lane(ticket_word, 1u, lane);
+		__syncthreads();      // (the word alternates between tiles, so one barrier is enough)
+		const uint32_t draw = SCALAR(*slot);
+		if ((env.debug_skip & 128u) && wave == 0) {
+			uint32_t* st = lds_ctrl + LC_STATS;
+			const uint32_t s4 = st[4] + (uint32_t)((__builtin_amdgcn_s_memtime() - tk0) >> 4), s7 = st[7] + 1u;
+			st[4] = s4; st[7] = s7;
+		}
 		if (draw >= (env.total_tiles + classes - 1u - cls) / classes) break;      // this class has that many tiles
 		const uint32_t ticket = draw * classes + cls;
 
@@ -1188,25 +1194,33 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (FULL ? 2 : (V == 4 ? 4 : 8
 
 		Ctx c;
 		c.consts = d.consts; c.in_ptrs = d.in_ptrs; c.out_ptrs = d.out_ptrs;
-		c.perlin_lds = lds_perlin; c.spill = lds_spill; c.tid = tid;
+		c.perlin_lds = lds_perlin; c.spill = lds_spill; c.tid = tid; c.wave = wave;
 		c.inst0 = tile_first + tid * V;
 		c.num_instances = d.num_instances;
-		c.full = (tile_first + VVM_BLOCK_THREADS * V) <= d.num_instances;
-		if (!(env.debug_skip & 1u)) run_tile<V, SPILL, FULL>(d, c, lds, tile_local, tag, error_word, env.debug_skip, pend, ticket_word, claimed, have_claim);
+		c.tile_first = tile_first;
+		c.valid = min(d.num_instances - tile_first, (uint32_t)(VVM_BLOCK_THREADS * V));
+		c.phase = phase;
+		if (!(env.debug_skip & 1u)) run_tile<V, SPILL, FULL>(d, c, lds, tile_local, tag, error_word, env.debug_skip, pend, resolves);
 	}
 	if (pend.active) {
-		resolve_tile<V>(pend, tid, lds_ctrl, tag, error_word, env.debug_skip);
-		store_tile<V>(pend, tid, lds, env.debug_skip);
+		Ctx c;
+		c.consts = nullptr; c.in_ptrs = nullptr; c.out_ptrs = nullptr; c.perlin_lds = lds_perlin; c.spill = lds_spill;
+		c.tid = tid; c.wave = wave; c.inst0 = 0; c.num_instances = 0; c.tile_first = 0; c.valid = 0; c.phase = 0;
+		resolve_tile<V>(pend, c, lds_ctrl, resolves, tag, error_word, env.debug_skip);
+		store_tile<V>(pend, c, lds, env.debug_skip);
 	}
 
-	// the last block to leave re-arms the launch words for the next launch
+	// the last workgroup to leave re-arms the launch words for the next launch
 	__syncthreads();
-	if (tid == 0) {
+	if (wave == 0) {
 		if (env.debug_skip & 128u)
-			for (int i = 0; i < 8; ++i) __hip_atomic_fetch_add((gu64*)&env.ls->stats[i], (u64)lds_ctrl[16 + i], RLX_AGENT);
-		const uint32_t n = __hip_atomic_fetch_add((gu32*)&env.ls->done, 1u, RLX_AGENT);
-		if (n + 1 == gridDim.x) {
-			uint32_t next = (env.ls->epoch + 1u) & 0x3FFFFFFFu;
+			for (int i = 0; i < 8; ++i) {
+				const rsrc_t rs = make_rsrc((uint64_t)&env.ls->stats[i], 8u);      // 64-bit add by the first lane
+				(void)__builtin_amdgcn_raw_ptr_buffer_atomic_add_i32((int)lds_ctrl[LC_STATS + i], rs, (int)(lane == 0 ? 0u : 8u), 0, AUX_AGENT);
+			}
+		const uint32_t n = fetch_add_first_lane((gu32*)&env.ls->done, 1u, lane);
+		if (n + 1 == gridDim.x) {      // (every lane of the wave stores the same values)
+			uint32_t next = (tag + 1u) & 0x3FFFFFFFu;
 			if (next == 0) next = 1;
 			__hip_atomic_store((gu32*)&env.ls->epoch, next, RLX_AGENT);
 			__hip_atomic_store((gu32*)&env.ls->done, 0u, RLX_AGENT);
