@@ -12,6 +12,8 @@ import os
 from typing import List, Optional, Sequence
 
 VVM_OK = 0
+(VVM_E_INVALID_ARG, VVM_E_EXTFN_MISMATCH, VVM_E_NO_BYTECODE, VVM_E_UNSUPPORTED_OP, VVM_E_BAD_BLOB, VVM_E_HIP, VVM_E_RCCL,
+ VVM_E_TOO_LARGE) = range(1, 9)      # include/vvm_abi.h status codes
 VVM_EXTFN_HOST_CALLBACK, VVM_EXTFN_PERLIN3, VVM_EXTFN_CURL_NOISE3 = 0, 1, 2
 VVM_EXEC_NO_VGPR_WIDE = 1
 

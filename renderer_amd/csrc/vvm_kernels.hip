@@ -79,6 +79,9 @@ DEV float    bitsf(uint32_t u) { return __uint_as_float(u); }
 DEV float    mask(bool b) { return bitsf(b ? 0xFFFFFFFFu : 0u); }
 
 // ---- lane arithmetic ---------------------------------------------------------------------------------
+// correctly rounded square root (_mm_sqrt_ps); HIP's __fsqrt_rn is the hardware approximation unless OCML's rounded
+// operations are enabled, the plain sqrtf is IEEE under the compiler's default -fhip-fp32-correctly-rounded-divide-sqrt
+DEV float ieee_sqrt(float a) { return __builtin_sqrtf(a); }
 DEV float f_sel(float m, float a, float b) { uint32_t M = fbits(m); return bitsf((M & fbits(a)) | (~M & fbits(b))); }   // SSE.h:1805-1810
 DEV float f_min(float a, float b) { return (a < b) ? a : b; }                  // _mm_min_ps: second operand when unordered or equal, SSE.h:2380-2383
 DEV float f_max(float a, float b) { return (a > b) ? a : b; }                  // SSE.h:2404-2407
@@ -89,8 +92,8 @@ DEV float f_mad(float a, float b, float c) { return (a * b) + c; }             /
 // per-lane branch in the interpreter loop, and one per-lane branch anywhere in that loop makes the compiler rewrite all of
 // its (wave-uniform) control flow into flag-guarded if-chains.
 DEV float f_div(float a, float b) { const float q = a / b; return (f_abs(b) > 1.e-8f) ? q : 0.0f; }                     // RT.cpp:1909
-DEV float f_sqrtg(float a) { const float q = __fsqrt_rn(a); return (a > 1.e-8f) ? q : 0.0f; }                           // RT.cpp:1914
-DEV float f_rsq(float a) { const float q = 1.0f / __fsqrt_rn(a); return (a > 1.e-8f) ? q : 0.0f; }                      // RT.cpp:1913, SSE.h:2014-2022
+DEV float f_sqrtg(float a) { const float q = ieee_sqrt(a); return (a > 1.e-8f) ? q : 0.0f; }                           // RT.cpp:1914
+DEV float f_rsq(float a) { const float q = 1.0f / ieee_sqrt(a); return (a > 1.e-8f) ? q : 0.0f; }                      // RT.cpp:1913, SSE.h:2014-2022
 DEV float f_rcp(float a) { const float q = __builtin_amdgcn_rcpf(a); return (f_abs(a) > 1.e-8f) ? q : 0.0f; }           // RT.cpp:1912 (hardware estimate, SSE.h:2121-2125)
 DEV float f_lerp(float a, float b, float c) { return f_mad(b, c, a * (1.0f - c)); }           // VCOMMON.inl:532-536
 DEV float f_clamp(float a, float b, float c) { return f_min(f_max(a, b), c); }                // VCOMMON.inl:495-498
@@ -959,7 +962,7 @@ DEV void run_tile(const VvmExecDesc& d, const Ctx& c, unsigned char* lds, uint32
 			case VVM_OP_mad_sub0: SETF(f_mad(A, B, C) - D);
 			case VVM_OP_mad_sub1: SETF(D - f_mad(A, B, C));
 			case VVM_OP_mad_mul: SETF(f_mad(A, B, C) * D);
-			case VVM_OP_mad_sqrt: SETF(__fsqrt_rn(f_mad(A, B, C)));      // unguarded, RT.cpp:2033
+			case VVM_OP_mad_sqrt: SETF(ieee_sqrt(f_mad(A, B, C)));      // unguarded, RT.cpp:2033
 			case VVM_OP_mad_mad0: SETF(f_mad(D, E, f_mad(A, B, C)));
 			case VVM_OP_mad_mad1: SETF(f_mad(f_mad(A, B, C), D, E));
 			case VVM_OP_mul_mad0: SETF(f_mad(A * B, C, D));

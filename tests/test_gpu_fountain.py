@@ -24,8 +24,9 @@ def _check(w, consts, ins, n, **kw):
         b = ref[k][off:off + ref_n].view(np.uint32)
         bad = np.nonzero(a != b)[0]
         assert bad.size == 0, "stream %d differs at %s (n=%d)" % (k, bad[:8], n)
-        # nothing before InstanceOffset is touched
+        # nothing before InstanceOffset or past the survivors is touched
         assert np.all(got[k][:off].view(np.uint32) == 0xCDCDCDCD)
+        assert np.all(got[k][off + got_n:].view(np.uint32) == 0xCDCDCDCD)
     return got_n, info
 
 

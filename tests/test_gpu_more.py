@@ -1,0 +1,260 @@
+"""GPU parity beyond the single-op cases: long look-back chains, untouched tails, the transcendental script with the noise
+built-ins, batched Execs with distinct bytecode, asynchronous Execs, and full-size (64 Mi) properties.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from op_cases import ALL_ONES
+from renderer_amd import abi, scripts
+from renderer_amd.assembler import FLOAT, Script
+from renderer_amd.runtime import VectorVMState
+from vm_harness import PAD, run_hip, run_oracle, ulp_diff
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+def _bits(a):
+    return a.view(np.uint32)
+
+
+# ---- compaction at scale -------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("pattern", ["half", "sparse", "dense", "bursts", "none_alive", "all_alive"])
+def test_long_look_back_chains(pattern):
+    """About 2000 tiles: many more than one look-back window, with death patterns that make tile counts vary wildly."""
+    w = scripts.fountain()
+    n = 2_000_003
+    ins = scripts.fountain_streams_np(0, n)
+    idx = np.arange(n)
+    rng = np.random.default_rng(11)
+    dead = {"half": rng.random(n) < 0.5, "sparse": rng.random(n) < 0.999, "dense": rng.random(n) < 0.001,
+            "bursts": (idx // 37123) % 3 != 0, "none_alive": np.ones(n, bool), "all_alive": np.zeros(n, bool)}[pattern]
+    ins[6] = np.where(dead, ins[7], ins[6] * f32(0.0)).astype(f32)
+    ref, ref_n, _ = run_oracle(w.script, [w.constants], ins, [f32] * 8, n)
+    got, got_n, _ = run_hip(w.script, [w.constants], ins, [f32] * 8, n)
+    assert got_n == ref_n == int((~dead).sum())
+    for k in range(8):
+        assert np.array_equal(_bits(got[k][:got_n]), _bits(ref[k][:ref_n])), "stream %d" % k
+        assert np.all(_bits(got[k][got_n:]) == 0xCDCDCDCD), "stream %d written past its survivors" % k
+
+
+@pytest.mark.parametrize("n", [1, 5, 1023, 1024, 1025, 5000])
+def test_nothing_is_written_past_the_survivors(n):
+    w = scripts.fountain()
+    ins = scripts.fountain_streams_np(0, n, kill_half=True)
+    for off in (0, 3):
+        got, got_n, _ = run_hip(w.script, [w.constants], ins, [f32] * 8, n, instance_offset=off)
+        for k in range(8):
+            assert np.all(_bits(got[k][:off]) == 0xCDCDCDCD) and np.all(_bits(got[k][off + got_n:]) == 0xCDCDCDCD)
+
+
+def test_more_outputs_than_staging_slots():
+    """Twelve output streams: the kernel stages eight per flush and writes the rest in a second one."""
+    s = Script()
+    x = [s.input(0, FLOAT, i) for i in range(3)]
+    keep = s.temp(); s.op("cmplt", x[0], x[1], keep)
+    s.acquireindex(keep, 0)
+    outs = []
+    for i in range(12):
+        t = s.temp()
+        s.op("mad", x[i % 3], s.const(i % 4), x[(i + 1) % 3], t)
+        outs.append(t)
+    s.output_data(FLOAT, 0, [(t, s.output(0, FLOAT, i)) for i, t in enumerate(outs)])
+    built = s.build()
+    consts = np.array([0.5, 1.5, -2.0, 3.25], f32).tobytes()
+    n = 7001
+    rng = np.random.default_rng(2)
+    ins = [rng.standard_normal(n).astype(f32) for _ in range(3)]
+    ref, ref_n, _ = run_oracle(built, [consts], ins, [f32] * 12, n)
+    got, got_n, _ = run_hip(built, [consts], ins, [f32] * 12, n)
+    assert got_n == ref_n
+    for k in range(12):
+        assert np.array_equal(_bits(got[k][:got_n]), _bits(ref[k][:ref_n])), k
+        assert np.all(_bits(got[k][got_n:]) == 0xCDCDCDCD)
+
+
+def test_outputs_without_acquireindex_write_nothing():
+    """No acquireindex for the dataset: the reference's output handlers see zero instances (VectorVMRuntime.cpp:565, 769)."""
+    s = Script()
+    t = s.temp()
+    s.op("add", s.input(0, FLOAT, 0), s.const(0), t)
+    s.output_data(FLOAT, 0, [(t, s.output(0, FLOAT, 0))])
+    built = s.build()
+    n = 3000
+    x = np.ones(n, f32)
+    ref, ref_n, _ = run_oracle(built, [bytes(16)], [x], [f32], n)
+    got, got_n, _ = run_hip(built, [bytes(16)], [x], [f32], n)
+    assert got_n == ref_n == 0
+    assert np.all(_bits(got[0]) == 0xCDCDCDCD)
+
+
+# ---- the transcendental script -------------------------------------------------------------------------------------------------
+def test_transcendental_script_with_curl_noise():
+    """sin_cos, exp and the curl-noise built-in.  The kernel evaluates the same polynomials and the same Perlin lattice code in
+    the oracle's operation order, so the bound is tight: <= 2 ulp on the displaced position (observed 0)."""
+    w = scripts.transcendental(True)
+    n = 100_003
+    ins = scripts.transcendental_streams_np(0, n)
+    ref, ref_n, _ = run_oracle(w.script, [w.constants], ins, [f32] * 4, n, ext_fns=list(w.ext_fns))
+    got, got_n, info = run_hip(w.script, [w.constants], ins, [f32] * 4, n, ext_fns=list(w.ext_fns))
+    assert got_n == ref_n == n
+    worst = 0
+    for k in range(4):
+        d = ulp_diff(got[k][:n], ref[k][:n])
+        worst = max(worst, int(d.max()))
+    assert worst <= 2, "max ulp distance %d" % worst
+
+
+def test_perlin_builtin():
+    s = Script()
+    s.acquireindex(s.const(0), 0)
+    x = [s.input(0, FLOAT, i) for i in range(3)]
+    t = s.temp()
+    f = s.ext_fn(3, 1)
+    s.call(f, x, [t])
+    s.output_data(FLOAT, 0, [(t, s.output(0, FLOAT, 0))])
+    built = s.build()
+    n = 20000
+    rng = np.random.default_rng(4)
+    ins = [(rng.standard_normal(n) * 40).astype(f32) for _ in range(3)]
+    ins[0][:4] = [0.0, 1.0, -3.0, 255.5]
+    ref, _, _ = run_oracle(built, [ALL_ONES], ins, [f32], n, ext_fns=[abi.VVM_EXTFN_PERLIN3])
+    got, got_n, _ = run_hip(built, [ALL_ONES], ins, [f32], n, ext_fns=[abi.VVM_EXTFN_PERLIN3])
+    assert got_n == n
+    assert ulp_diff(got[0][:n], ref[0][:n]).max() <= 2
+
+
+def test_host_callback_is_refused_by_the_gpu_executor():
+    w = scripts.transcendental(True)
+    n = 16
+    ins = scripts.transcendental_streams_np(0, n)
+    with pytest.raises(abi.VVMError) as e:
+        run_hip(w.script, [w.constants], ins, [f32] * 4, n, ext_fns=[lambda ctx: None])
+    assert e.value.code == abi.VVM_E_UNSUPPORTED_OP
+
+
+# ---- batched and asynchronous Execs -------------------------------------------------------------------------------------------
+class _DeviceStreams:
+    def __init__(self, be, arrays, out_count, n, fill=0xCD):
+        self.be, self.n = be, n
+        self.ins, self.outs = [], []
+        for a in arrays:
+            buf = np.zeros(n + PAD, a.dtype); buf[:n] = a[:n]
+            p = be.lib.vvm_device_alloc(buf.nbytes); assert p
+            be._check(be.lib.vvm_device_upload(p, buf.ctypes.data, buf.nbytes), "upload")
+            self.ins.append(p)
+        for _ in range(out_count):
+            p = be.lib.vvm_device_alloc((n + PAD) * 4); assert p
+            be._check(be.lib.vvm_device_memset(p, fill, (n + PAD) * 4), "memset")
+            self.outs.append(p)
+
+    def download(self, k):
+        h = np.empty(self.n + PAD, f32)
+        self.be._check(self.be.lib.vvm_device_download(h.ctypes.data, self.outs[k], h.nbytes), "download")
+        return h
+
+    def free(self):
+        for p in self.ins + self.outs:
+            self.be.lib.vvm_device_free(p)
+
+
+def test_batched_execs_with_distinct_bytecode():
+    """One launch for many emitters, each with its own script variant, constants and size; same results as one Exec each."""
+    be = abi.load_hip_backend()
+    emitters = 48
+    sizes = [0, 1, 7, 1024, 1025, 3000] + [2000 + 97 * e for e in range(emitters - 6)]
+    states, frames, streams, refs, opts = [], [], [], [], []
+    try:
+        for e in range(emitters):
+            w = scripts.fountain(variant=e % 64)
+            n = sizes[e]
+            ins = scripts.fountain_streams_np(e * 100000, max(n, 1), kill_half=(e % 2 == 0))
+            ref, ref_n, _ = run_oracle(w.script, [w.constants], ins, [f32] * 8, n)
+            refs.append((ref, ref_n))
+            ds = _DeviceStreams(be, ins, 8, max(n, 1))
+            streams.append(ds)
+            st = VectorVMState(w.script.blob, be)
+            states.append(st)
+            frames.append(st.frame([abi.DataSet(ds.ins, ds.outs, 0)], n, [w.constants]))
+            opts.append(abi.ExecOptions(0, 0, 0, None, 0))
+        be.exec_batch(frames, opts)
+        for e in range(emitters):
+            ref, ref_n = refs[e]
+            assert frames[e].survivors(0) == ref_n, "emitter %d" % e
+            for k in range(8):
+                got = streams[e].download(k)
+                assert np.array_equal(_bits(got[:ref_n]), _bits(ref[k][:ref_n])), "emitter %d stream %d" % (e, k)
+                assert np.all(_bits(got[ref_n:]) == 0xCDCDCDCD)
+        # a second batch on the same states re-uses the launch words
+        be.exec_batch(frames, opts)
+        for e in range(emitters):
+            assert frames[e].survivors(0) == refs[e][1]
+    finally:
+        for st in states:
+            st.close()
+        for ds in streams:
+            ds.free()
+
+
+def test_async_execs_in_a_row():
+    be = abi.load_hip_backend()
+    w = scripts.fountain()
+    n = 200_000
+    ins = scripts.fountain_streams_np(0, n, kill_half=True)
+    ref, ref_n, _ = run_oracle(w.script, [w.constants], ins, [f32] * 8, n)
+    ds = _DeviceStreams(be, ins, 8, n)
+    st = VectorVMState(w.script.blob, be)
+    try:
+        frame = st.frame([abi.DataSet(ds.ins, ds.outs, 0)], n, [w.constants])
+        for _ in range(12):                      # more Execs in flight than parameter slots
+            st.exec_async(frame)
+        assert st.finish(frame) == ref_n
+        for k in range(8):
+            assert np.array_equal(_bits(ds.download(k)[:ref_n]), _bits(ref[k][:ref_n]))
+    finally:
+        st.close()
+        ds.free()
+
+
+# ---- full size ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kill_half", [False, True])
+def test_full_size_against_torch(kill_half):
+    """64 Mi particles (the benchmark's size).  The oracle would take minutes here; the fountain script is four IEEE operations
+    per output, which torch evaluates unfused on the device, and boolean-mask indexing keeps order: bit-exact expected values."""
+    import torch
+    n = 64 * 1024 * 1024
+    dev = torch.device("cuda", 0)
+    be = abi.load_hip_backend()
+    w = scripts.fountain()
+    ins = scripts.fountain_streams_torch(0, n, dev, kill_half=kill_half, pad=64)
+    outs = [torch.full((n + 64,), -7.0, dtype=torch.float32, device=dev) for _ in range(8)]
+    torch.cuda.synchronize()
+    st = VectorVMState(w.script.blob, be)
+    try:
+        frame = st.frame([abi.DataSet([t.data_ptr() for t in ins], [t.data_ptr() for t in outs], 0)], n, [w.constants])
+        surv = st.exec(frame)
+        dt, g, drag = torch.tensor(1.0 / 60.0, dtype=torch.float32), torch.tensor(-980.0, dtype=torch.float32), torch.tensor(0.98, dtype=torch.float32)
+        age1 = ins[6][:n] + dt
+        keep = age1 < ins[7][:n]
+        assert surv == int(keep.sum().item())
+        if not kill_half:
+            assert surv == n
+        for c in range(3):
+            gc = g if c == 2 else torch.tensor(0.0)
+            v1 = (gc.to(dev) * dt.to(dev) + ins[3 + c][:n]) * drag.to(dev)
+            p1 = v1 * dt.to(dev) + ins[c][:n]
+            assert torch.equal(outs[3 + c][:surv].view(torch.int32), v1[keep].view(torch.int32)), "velocity %d" % c
+            assert torch.equal(outs[c][:surv].view(torch.int32), p1[keep].view(torch.int32)), "position %d" % c
+        assert torch.equal(outs[6][:surv].view(torch.int32), age1[keep].view(torch.int32))
+        assert torch.equal(outs[7][:surv].view(torch.int32), ins[7][:n][keep].view(torch.int32))
+        for k in range(8):
+            assert bool((outs[k][surv:] == -7.0).all()), "stream %d written past its survivors" % k
+        # idempotence: a second Exec on the same inputs gives the same outputs
+        first = [o[:surv].clone() for o in outs]
+        assert st.exec(frame) == surv
+        for k in range(8):
+            assert torch.equal(first[k].view(torch.int32), outs[k][:surv].view(torch.int32))
+    finally:
+        st.close()
