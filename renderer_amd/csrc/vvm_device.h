@@ -29,9 +29,11 @@ enum : uint32_t {
 // ---- device-only opcodes (the reference's opcodes keep their numbers 0..178) ----
 enum : uint32_t {
 	VVM_DOP_LOADN16 = 190, // the same for 16-bit streams: the raw bits, zero-extended
-	VVM_DOP_LOADN  = 191,  // load up to 8 32-bit input streams into consecutive virtual registers (program prologue only)
+	VVM_DOP_LOADN  = 191,  // load up to 8 32-bit input streams into consecutive virtual registers (program prologue only):
+	                       // aux = count, aux2 = first register, w1 = first slot of VvmExecDesc::load_ptrs
 	VVM_DOP_ACQUIRE = 192, // acquireindex; every opcode from here on produces no register result
-	VVM_DOP_OUTPUT32 = 193, // up to 3 (src,dst) pairs of outputdata_float / outputdata_int32
+	VVM_DOP_OUTPUT32 = 193, // up to 3 (src,dst) pairs of outputdata_float / outputdata_int32: aux = count, aux2 = dataset,
+	                        // o0..o2 = sources, w3 = first slot of VvmExecDesc::out_list
 	VVM_DOP_OUTPUT16 = 194, // up to 3 pairs of outputdata_half (float register -> half stream)
 	VVM_DOP_OUTPUT16_FROM16 = 195,
 	VVM_DOP_OUTPUT32_FROM16 = 196
@@ -51,8 +53,10 @@ struct VvmIns {
 struct VvmExecDesc {
 	const VvmIns*   prog;
 	const uint32_t* consts;        // NumConstBuffers dwords, remapped order, zero-padded to a multiple of 4 dwords
-	const uint64_t* in_ptrs;       // byte address of element [InstanceOffset] of every remapped input stream
-	const uint64_t* out_ptrs;      // byte address of element [InstanceOffset] of every output, by output serial index (0 = none)
+	const uint64_t* in_ptrs;       // byte address of element [InstanceOffset] of every remapped input stream (no-advance operands)
+	const uint64_t* load_ptrs;     // the same addresses in load-list order: 8 per load instruction, 64-byte aligned
+	const uint64_t* out_list;      // byte address of element [InstanceOffset] of every output, in output-list order: 4 per output
+	                               // instruction, 32-byte aligned (0 = the script has no such output)
 	unsigned long long* status;    // one look-back word per tile of this Exec
 	int32_t*        counts;        // survivor count per output dataset (written by the Exec's last tile)
 	const uint8_t*  perlin;        // 512-byte permutation table when the script calls a noise built-in
@@ -64,7 +68,7 @@ struct VvmExecDesc {
 	int32_t  rand_instance_base;
 	uint32_t flags;
 	uint32_t num_unif;             // constants copied into the uniform register, a multiple of 4, at most VVM_MAX_UNIFORMS
-	uint32_t pad[1];
+	uint32_t pad[3];
 };
 
 enum : uint32_t {

@@ -191,7 +191,7 @@ struct PreparedExec {
 	const VvmIns* d_code = nullptr;
 	uint32_t tiles = 0;
 	size_t bytes = 0;           // parameter block: desc + consts + in_ptrs + out_ptrs
-	size_t off_consts = 0, off_in = 0, off_out = 0;
+	size_t off_consts = 0, off_in = 0, off_load = 0, off_out = 0;
 };
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) & ~(a - 1); }
@@ -233,8 +233,10 @@ int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, P
 	const uint32_t O = std::max<uint32_t>(s.num_outputs_remapped, s.num_output_instructions);
 	pe.off_consts = align_up(sizeof(VvmExecDesc), 16);
 	pe.off_in = align_up(pe.off_consts + 4u * (size_t)s.num_consts, 16);     // (so the table is padded to a multiple of 4 dwords)
-	pe.off_out = align_up(pe.off_in + 8u * (size_t)s.num_inputs, 16);
-	pe.bytes = align_up(pe.off_out + 8u * (size_t)O, 256);
+	pe.off_load = align_up(pe.off_in + 8u * (size_t)s.num_inputs, 64);
+	pe.off_out = align_up(pe.off_load + 8u * pe.lp->load_list.size(), 64);
+	pe.bytes = align_up(pe.off_out + 8u * pe.lp->out_list.size(), 256);      // (the block itself is 256-byte aligned)
+	(void)O;
 	return VVM_OK;
 }
 
@@ -249,7 +251,8 @@ int fill_params(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* op
 	d->prog = pe.d_code;
 	d->consts = (const uint32_t*)(dev + pe.off_consts);
 	d->in_ptrs = (const uint64_t*)(dev + pe.off_in);
-	d->out_ptrs = (const uint64_t*)(dev + pe.off_out);
+	d->load_ptrs = (const uint64_t*)(dev + pe.off_load);
+	d->out_list = (const uint64_t*)(dev + pe.off_out);
 	d->status = d_status;
 	d->counts = st->d_counts;
 	d->perlin = st->d_perlin;
@@ -279,11 +282,13 @@ int fill_params(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* op
 		const uint64_t stride = (in.type == 2) ? 2 : 4;
 		in_ptrs[i] = (uint64_t)(uintptr_t)ds.InputRegisters.data[idx] + (uint64_t)(int64_t)ds.InstanceOffset * stride;
 	}
-	uint64_t* out_ptrs = (uint64_t*)(host + pe.off_out);                                                // RT.cpp:418-441
-	const uint32_t O = std::max<uint32_t>(s.num_outputs_remapped, s.num_output_instructions);
-	for (uint32_t i = 0; i < O; ++i) {
-		out_ptrs[i] = 0;
-		if (i >= s.num_outputs_remapped || s.out_dst[i] == 0xFFFF) continue;
+	uint64_t* load_ptrs = (uint64_t*)(host + pe.off_load);
+	for (size_t i = 0; i < lp.load_list.size(); ++i) load_ptrs[i] = lp.load_list[i] >= 0 ? in_ptrs[lp.load_list[i]] : 0;
+	uint64_t* out_list = (uint64_t*)(host + pe.off_out);                                                // RT.cpp:418-441
+	for (size_t k = 0; k < lp.out_list.size(); ++k) {
+		out_list[k] = 0;
+		const int32_t i = lp.out_list[k];
+		if (i < 0 || (uint32_t)i >= s.num_outputs_remapped || s.out_dst[i] == 0xFFFF) continue;
 		const uint8_t dsi = s.out_dataset[i];
 		const uint16_t ty = s.out_type[i];
 		if ((int)dsi >= ctx->DataSets.num || ty > 2) return fail(VVM_E_INVALID_ARG, "script writes a dataset the context does not provide");
@@ -291,7 +296,7 @@ int fill_params(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* op
 		const uint32_t idx = ds.OutputRegisterTypeOffsets[ty] + s.out_dst[i];
 		if ((int)idx >= ds.OutputRegisters.num) return fail(VVM_E_INVALID_ARG, "output register index past OutputRegisters.num");
 		const uint64_t stride = (ty == 2) ? 2 : 4;
-		out_ptrs[i] = (uint64_t)(uintptr_t)ds.OutputRegisters.data[idx] + (uint64_t)(int64_t)ds.InstanceOffset * stride;
+		out_list[k] = (uint64_t)(uintptr_t)ds.OutputRegisters.data[idx] + (uint64_t)(int64_t)ds.InstanceOffset * stride;
 	}
 	// the reference's chunk bookkeeping has no meaning here; report one chunk that holds everything
 	ctx->Internal.NumBytesRequiredPerBatch = 0;

@@ -49,6 +49,22 @@ __device__ __forceinline__ uint64_t sload64(const void* p, uint32_t i)
 	return ((uint64_t)SCALAR((uint32_t)(v >> 32)) << 32) | (uint64_t)SCALAR((uint32_t)v);
 }
 
+// 2^K consecutive 64-bit table entries with one scalar load (the table must be aligned to the size of the load)
+typedef uint32_t su32x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t su32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ void sload64x4(const void* p, uint32_t first, uint64_t (&out)[4])
+{
+	const su32x8 v = *(const __attribute__((address_space(4))) su32x8*)(uintptr_t)((const uint64_t*)p + first);
+#pragma unroll
+	for (int i = 0; i < 4; ++i) out[i] = ((uint64_t)SCALAR(v[2 * i + 1]) << 32) | (uint64_t)SCALAR(v[2 * i]);
+}
+__device__ __forceinline__ void sload64x8(const void* p, uint32_t first, uint64_t (&out)[8])
+{
+	const su32x16 v = *(const __attribute__((address_space(4))) su32x16*)(uintptr_t)((const uint64_t*)p + first);
+#pragma unroll
+	for (int i = 0; i < 8; ++i) out[i] = ((uint64_t)SCALAR(v[2 * i + 1]) << 32) | (uint64_t)SCALAR(v[2 * i]);
+}
+
 // VGPR-resident virtual registers: one vector per instance slot of the lane, R<k>[i] = register i of the lane's k-th
 // instance.  The vectors are plain local values that are passed to helpers BY VALUE and assigned back: handed around by
 // reference they stay in a stack object whose run-time-indexed element stores the compiler leaves in scratch memory; as
@@ -431,7 +447,8 @@ DEV uint32_t wave_sum(uint32_t v)
 struct Ctx {
 	const uint32_t* consts;
 	const uint64_t* in_ptrs;
-	const uint64_t* out_ptrs;
+	const uint64_t* load_ptrs;
+	const uint64_t* out_list;
 	const uint8_t*  perlin_lds;
 	float*          spill;        // LDS, [slot][thread] (V floats per thread and slot)
 	uint32_t tid;
@@ -541,9 +558,19 @@ DEV uint32_t fetch_add_first_lane(gu32* addr, uint32_t value, uint32_t lane)
 // waits until every one of them carries this launch's tag, and sums the counts back to the nearest tile whose word already
 // holds an inclusive prefix.
 #define VVM_LB_WINDOW 256
-DEV uint32_t look_back(gu64* status, uint32_t tile, uint32_t tag, uint32_t lane, gu32* error_word, uint32_t& rounds, uint32_t& polls)
+#define VVM_LB_WORDS_PER_LANE (VVM_LB_WINDOW / 64)
+// The loads of one poll: lane l reads the words of tiles first - l - 64 j.
+DEV void look_back_poll(gu64* status, int32_t first, uint32_t lane, u64 (&w)[VVM_LB_WORDS_PER_LANE])
 {
-	constexpr int WPL = VVM_LB_WINDOW / 64;
+#pragma unroll
+	for (int j = 0; j < VVM_LB_WORDS_PER_LANE; ++j)
+		w[j] = __hip_atomic_load(status + max(first - (int32_t)lane - 64 * j, 0), RLX_AGENT);
+}
+// `pre` holds a first poll that the caller issued earlier (have_pre), so that its round trip overlaps other work.
+DEV uint32_t look_back(gu64* status, uint32_t tile, uint32_t tag, uint32_t lane, gu32* error_word, uint32_t& rounds, uint32_t& polls,
+                       const u64 (&pre)[VVM_LB_WORDS_PER_LANE], bool have_pre)
+{
+	constexpr int WPL = VVM_LB_WORDS_PER_LANE;
 	uint32_t sum = 0;
 	int32_t first = (int32_t)tile - 1;
 	for (;;) {
@@ -552,12 +579,18 @@ DEV uint32_t look_back(gu64* status, uint32_t tile, uint32_t tag, uint32_t lane,
 		++rounds;
 		for (;;) {
 			bool ok = true;
-			++polls;
+			if (have_pre) {
+#pragma unroll
+				for (int j = 0; j < WPL; ++j) w[j] = pre[j];
+				have_pre = false;
+			} else {
+				++polls;
+				look_back_poll(status, first, lane, w);
+			}
 #pragma unroll
 			for (int j = 0; j < WPL; ++j) {
 				const int32_t mine = first - (int32_t)lane - 64 * j;
-				const u64 x = __hip_atomic_load(status + max(mine, 0), RLX_AGENT);
-				w[j] = (mine >= 0) ? x : (((u64)tag << 34) | (VVM_LB_INCLUSIVE << 32));     // before the first tile: prefix 0
+				w[j] = (mine >= 0) ? w[j] : (((u64)tag << 34) | (VVM_LB_INCLUSIVE << 32));     // before the first tile: prefix 0
 				ok = ok && ((uint32_t)(w[j] >> 34) == tag);
 			}
 			if (__all(ok)) break;
@@ -643,7 +676,8 @@ struct Pending {
 //                 each staged output.  A thread moves V consecutive values, so every tile stores 128 bits per lane whatever
 //                 its death rate.  Issued after the next tile's loads have arrived: stores and loads share one completion
 //                 counter, and a wait for loads would otherwise also wait for these stores.
-template <int V> DEV void resolve_tile(Pending& p, const Ctx& c, uint32_t* lds_ctrl, uint32_t& resolves, uint32_t tag, gu32* error_word, uint32_t dbg)
+template <int V> DEV void resolve_tile(Pending& p, const Ctx& c, uint32_t* lds_ctrl, uint32_t& resolves, uint32_t tag, gu32* error_word, uint32_t dbg,
+                                     const u64 (&pre)[VVM_LB_WORDS_PER_LANE], bool have_pre)
 {
 	if (p.unresolved && p.tile_local != 0) {
 		uint32_t* slot = lds_ctrl + LC_PREFIX + (resolves & 1u);
@@ -652,7 +686,7 @@ template <int V> DEV void resolve_tile(Pending& p, const Ctx& c, uint32_t* lds_c
 			const uint32_t lane = c.tid & 63u;
 			uint32_t rounds = 0, polls = 0;
 			const u64 t0 = (dbg & 128u) ? __builtin_amdgcn_s_memtime() : 0;
-			const uint32_t ex = (dbg & 32u) ? p.tile_local * (VVM_BLOCK_THREADS * V) : look_back(p.status, p.tile_local, tag, lane, error_word, rounds, polls);
+			const uint32_t ex = (dbg & 32u) ? p.tile_local * (VVM_BLOCK_THREADS * V) : look_back(p.status, p.tile_local, tag, lane, error_word, rounds, polls, pre, have_pre);
 			*slot = ex;
 			store_u64_first_lane(p.status + p.tile_local, ((u64)tag << 34) | (VVM_LB_INCLUSIVE << 32) | (ex + p.total), lane);
 			if (dbg & 128u) {      // per-workgroup sums (all lanes of wave 0 write the same values)
@@ -745,7 +779,7 @@ struct KernelEnv {
 // ------------------------------------------------------------------------------------------------------
 template <int V, bool SPILL, bool FULL>
 DEV void run_tile(const VvmExecDesc& d, const Ctx& c, unsigned char* lds, uint32_t tile_local, uint32_t tag, gu32* error_word, uint32_t dbg, Pending& pend,
-                  uint32_t& resolves)
+                  uint32_t& resolves, const u64 (&pre)[VVM_LB_WORDS_PER_LANE], bool have_pre)
 {
 	RVEC R0 = 0.0f, R1 = 0.0f, R2 = 0.0f, R3 = 0.0f;
 	uint32_t* lds_ctrl = (uint32_t*)lds;
@@ -763,44 +797,57 @@ DEV void run_tile(const VvmExecDesc& d, const Ctx& c, unsigned char* lds, uint32
 	const uint32_t uni = fill_uniforms<0>(0u, c.consts, d.num_unif);
 	const u64 tl0 = (dbg & 128u) ? __builtin_amdgcn_s_memtime() : 0;
 
-	// Prologue: the program starts with its VVM_DOP_LOADN / VVM_DOP_LOADN16 instructions.  They run in a loop of their own so
-	// that the main loop below has exactly one place that inserts into the register vectors (with two, the compiler keeps a
-	// second copy of the whole register file alive across the loop).
+	// Prologue: the program starts with its VVM_DOP_LOADN / VVM_DOP_LOADN16 instructions.  They run ahead of the main loop so
+	// that the main loop has exactly one place that inserts into the register vectors (with two, the compiler keeps a second
+	// copy of the whole register file alive across the loop).
+	//   aux = count (1..8), aux2 = first destination register, w1 = first of eight slots of the load list: the eight stream
+	//   addresses arrive with one scalar load, then all stream loads are issued back to back.
+	//   Unused slots write (zeros) to the first slot's register, and the first slot is written last: every write is a plain
+	//   insert, none has to read the register it might have to preserve.
+#define VVM_ISSUE_LOADS(W0, W1, ST) do { \
+		const uint32_t lop_ = (W0) & 0xFFu, cnt_ = ((W0) >> 16) & 0xFFu; \
+		uint64_t ptr_[8]; \
+		sload64x8(c.load_ptrs, (W1), ptr_); \
+		_Pragma("unroll") for (int j = 0; j < 8; ++j) { \
+			_Pragma("unroll") for (int k = 0; k < V; ++k) (ST)[j][k] = 0.0f; \
+			if ((uint32_t)j < cnt_ && !(dbg & 2u)) { \
+				if (lop_ == VVM_DOP_LOADN) load_stream32<V>(c, ptr_[j], (ST)[j]); \
+				else load_stream16<V>(c, ptr_[j], (ST)[j]); \
+			} \
+		} \
+	} while (0)
+#define VVM_WRITE_LOADS(W0, ST) do { \
+		const uint32_t cnt_ = ((W0) >> 16) & 0xFFu, dst_ = (W0) >> 24; \
+		_Pragma("unroll") for (int j = 7; j >= 0; --j) REG_WRITE(((uint32_t)j < cnt_) ? dst_ + j : dst_, (ST)[j]); \
+	} while (0)
+	// The first load instruction is handled apart: while its loads are in flight the previous tile's look-back is resolved,
+	// and once they have arrived the previous tile's stores are issued.  The register vectors come into existence only after
+	// that, which keeps them out of the register budget of the look-back.
 	uint32_t pc0 = 0;
-	for (;; ++pc0) {
-		VvmIns ins;
-		ins.w0 = sload32(prog, pc0 * 4 + 0);
-		const uint32_t lop = ins.w0 & 0xFFu;
-		if (lop != VVM_DOP_LOADN && lop != VVM_DOP_LOADN16) break;
-		ins.w1 = sload32(prog, pc0 * 4 + 1); ins.w2 = sload32(prog, pc0 * 4 + 2); ins.w3 = sload32(prog, pc0 * 4 + 3);
-		const uint32_t aux = (ins.w0 >> 16) & 0xFFu, aux2 = ins.w0 >> 24;
-		// aux = count (1..8), aux2 = first destination register; eight 12-bit stream indices in w1..w3
+	{
+		const uint32_t w0 = sload32(prog, 0), w1 = sload32(prog, 1);
+		const uint32_t lop = w0 & 0xFFu;
+		const bool loads_first = (lop == VVM_DOP_LOADN || lop == VVM_DOP_LOADN16);
 		float st[8][V];
-		const u64 lo = (u64)ins.w1 | ((u64)ins.w2 << 32);
-#pragma unroll
-		for (int j = 0; j < 8; ++j) {
-#pragma unroll
-			for (int k = 0; k < V; ++k) st[j][k] = 0.0f;
-			if ((uint32_t)j < aux && !(dbg & 2u)) {
-				const uint32_t idx = (j < 5) ? (uint32_t)(lo >> (12 * j)) & 0xFFFu
-				                    : (j == 5) ? (uint32_t)((lo >> 60) | ((u64)(ins.w3 & 0xFFu) << 4)) & 0xFFFu
-				                               : (ins.w3 >> (8 + 12 * (j - 6))) & 0xFFFu;
-				if (lop == VVM_DOP_LOADN) load_stream32<V>(c, sload64(c.in_ptrs, idx), st[j]);
-				else load_stream16<V>(c, sload64(c.in_ptrs, idx), st[j]);
-			}
-		}
-		// the previous tile's look-back runs while these loads are in flight, its stores are issued once they have arrived
+		if (loads_first) { VVM_ISSUE_LOADS(w0, w1, st); pc0 = 1; }
 		const bool finish_previous = pend.active;
-		if (finish_previous) resolve_tile<V>(pend, c, lds_ctrl, resolves, tag, error_word, dbg);
-#pragma unroll
-		for (int j = 0; j < 8; ++j)
-			REG_WRITE_IF((uint32_t)j < aux, aux2 + j, st[j]);
+		if (finish_previous) resolve_tile<V>(pend, c, lds_ctrl, resolves, tag, error_word, dbg, pre, have_pre);
+		if (loads_first) VVM_WRITE_LOADS(w0, st);
 		if (finish_previous) store_tile<V>(pend, c, lds, dbg);
 	}
-	if (pend.active) {      // a program without stream loads
-		resolve_tile<V>(pend, c, lds_ctrl, resolves, tag, error_word, dbg);
-		store_tile<V>(pend, c, lds, dbg);
+	if (pc0 != 0) {
+		for (;; ++pc0) {      // further load instructions (more than eight streams of one width, or both widths)
+			const uint32_t w0 = sload32(prog, pc0 * 4 + 0);
+			const uint32_t lop = w0 & 0xFFu;
+			if (lop != VVM_DOP_LOADN && lop != VVM_DOP_LOADN16) break;
+			const uint32_t w1 = sload32(prog, pc0 * 4 + 1);
+			float st[8][V];
+			VVM_ISSUE_LOADS(w0, w1, st);
+			VVM_WRITE_LOADS(w0, st);
+		}
 	}
+#undef VVM_ISSUE_LOADS
+#undef VVM_WRITE_LOADS
 
 	// The program is a sequence of runs of ordinary instructions separated by the few special ones (acquireindex, outputs,
 	// the end).  The inner loop interprets one run; the special instructions are handled between runs.  The next instruction
@@ -1052,25 +1099,26 @@ DEV void run_tile(const VvmExecDesc& d, const Ctx& c, unsigned char* lds, uint32
 		}
 		if (op == VVM_OP_done) break;
 
-		// Output instruction: aux = pair count (1..3), aux2 = dataset; pairs (o0,o1) (o2,o3) (o4,o5) = (source, output serial index).
+		// Output instruction: aux = pair count (1..3), aux2 = dataset; sources o0..o2, destinations = output-list slots from w3.
 		// The survivors' values are compacted into an LDS staging slot; store_tile writes them out later.
 		const uint32_t total = (aux2 == t_dataset) ? t_total : 0u;    // no acquireindex for this dataset: nothing is written (VectorVMRuntime.cpp:565, 769)
 		const bool all_alive = (total == VVM_BLOCK_THREADS * V);
 		const uint32_t kind = op - VVM_DOP_OUTPUT32;          // 0: 32-bit value  1: float -> half  2: low 16 bits as they are  3: half bits -> float
 		float* stage = (float*)(lds + LDS_STAGE_OFF);
 		uint32_t* meta = (uint32_t*)(lds + LDS_STAGE_META_OFF);
+		uint64_t out_ptr[4];
+		sload64x4(c.out_list, o4 | (o5 << 16), out_ptr);      // w3 = first of the instruction's four output-list slots
 #pragma unroll
 		for (int j = 0; j < 3; ++j) {
 			if ((uint32_t)j >= aux) break;
-			const uint32_t src = (j == 0) ? o0 : (j == 1) ? o2 : o4;
-			const uint32_t out_idx = (j == 0) ? o1 : (j == 1) ? o3 : o5;
-			const uint64_t base = sload64(c.out_ptrs, out_idx);
+			const uint32_t src = (j == 0) ? o0 : (j == 1) ? o1 : o2;
+			const uint64_t base = out_ptr[j];
 			if (base == 0 || total == 0) continue;
 			if (n_staged == VVM_STAGE_SLOTS) {       // out of slots: write what is staged now (this waits for the look-back)
 				Pending cur;
 				cur.active = true; cur.unresolved = t_pending; cur.total = t_total; cur.base = t_base; cur.n_staged = n_staged;
 				cur.tile_local = tile_local; cur.num_tiles = d.num_tiles; cur.status = status; cur.count_out = d.counts + t_dataset;
-				resolve_tile<V>(cur, c, lds_ctrl, resolves, tag, error_word, dbg);
+				resolve_tile<V>(cur, c, lds_ctrl, resolves, tag, error_word, dbg, pre, false);
 				store_tile<V>(cur, c, lds, dbg);
 				__syncthreads();      // the slots are written again right away
 				t_base = cur.base; t_pending = false; n_staged = 0;
@@ -1145,7 +1193,16 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (FULL ? 2 : (V == 4 ? 4 : 8
 	for (uint32_t phase = 0;; ++phase) {
 		const u64 tk0 = (env.debug_skip & 128u) ? __builtin_amdgcn_s_memtime() : 0;
 		uint32_t* slot = lds_ctrl + LC_TICKET + (phase & 1u);
-		if (wave == 0) *slot = fetch_add_first_lane(ticket_word, 1u, lane);
+		// Wave 0 draws the ticket and, in the shadow of that round trip, issues the first look-back poll for the tile the
+		// workgroup has just finished; the poll is examined after this tile's stream loads have been issued (resolve_tile).
+		u64 pre[VVM_LB_WORDS_PER_LANE] = {};
+		const bool have_pre = pend.active && pend.unresolved && pend.tile_local != 0 && !(env.debug_skip & (32u | 512u));
+		if (wave == 0) {
+			const rsrc_t rs = make_rsrc((uint64_t)ticket_word, 4u);
+			const int drawn = __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, rs, (int)(lane == 0 ? 0u : 4u), 0, AUX_AGENT);
+			if (have_pre) look_back_poll(pend.status, (int32_t)pend.tile_local - 1, lane, pre);
+			*slot = SCALAR(drawn);
+		}
 		__syncthreads();      // (the word alternates between tiles, so one barrier is enough)
 		const uint32_t draw = SCALAR(*slot);
 		if ((env.debug_skip & 128u) && wave == 0) {
@@ -1172,7 +1229,8 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (FULL ? 2 : (V == 4 ? 4 : 8
 			d.prog = (const VvmIns*)sload64(dp, offsetof(VvmExecDesc, prog) / 8);
 			d.consts = (const uint32_t*)sload64(dp, offsetof(VvmExecDesc, consts) / 8);
 			d.in_ptrs = (const uint64_t*)sload64(dp, offsetof(VvmExecDesc, in_ptrs) / 8);
-			d.out_ptrs = (const uint64_t*)sload64(dp, offsetof(VvmExecDesc, out_ptrs) / 8);
+			d.load_ptrs = (const uint64_t*)sload64(dp, offsetof(VvmExecDesc, load_ptrs) / 8);
+			d.out_list = (const uint64_t*)sload64(dp, offsetof(VvmExecDesc, out_list) / 8);
 			d.status = (unsigned long long*)sload64(dp, offsetof(VvmExecDesc, status) / 8);
 			d.counts = (int32_t*)sload64(dp, offsetof(VvmExecDesc, counts) / 8);
 			d.perlin = (const uint8_t*)sload64(dp, offsetof(VvmExecDesc, perlin) / 8);
@@ -1196,20 +1254,21 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (FULL ? 2 : (V == 4 ? 4 : 8
 		}
 
 		Ctx c;
-		c.consts = d.consts; c.in_ptrs = d.in_ptrs; c.out_ptrs = d.out_ptrs;
+		c.consts = d.consts; c.in_ptrs = d.in_ptrs; c.load_ptrs = d.load_ptrs; c.out_list = d.out_list;
 		c.perlin_lds = lds_perlin; c.spill = lds_spill; c.tid = tid; c.wave = wave;
 		c.inst0 = tile_first + tid * V;
 		c.num_instances = d.num_instances;
 		c.tile_first = tile_first;
 		c.valid = min(d.num_instances - tile_first, (uint32_t)(VVM_BLOCK_THREADS * V));
 		c.phase = phase;
-		if (!(env.debug_skip & 1u)) run_tile<V, SPILL, FULL>(d, c, lds, tile_local, tag, error_word, env.debug_skip, pend, resolves);
+		if (!(env.debug_skip & 1u)) run_tile<V, SPILL, FULL>(d, c, lds, tile_local, tag, error_word, env.debug_skip, pend, resolves, pre, have_pre);
 	}
 	if (pend.active) {
 		Ctx c;
-		c.consts = nullptr; c.in_ptrs = nullptr; c.out_ptrs = nullptr; c.perlin_lds = lds_perlin; c.spill = lds_spill;
+		c.consts = nullptr; c.in_ptrs = nullptr; c.load_ptrs = nullptr; c.out_list = nullptr; c.perlin_lds = lds_perlin; c.spill = lds_spill;
 		c.tid = tid; c.wave = wave; c.inst0 = 0; c.num_instances = 0; c.tile_first = 0; c.valid = 0; c.phase = 0;
-		resolve_tile<V>(pend, c, lds_ctrl, resolves, tag, error_word, env.debug_skip);
+		const u64 none[VVM_LB_WORDS_PER_LANE] = {};
+		resolve_tile<V>(pend, c, lds_ctrl, resolves, tag, error_word, env.debug_skip, none, false);
 		store_tile<V>(pend, c, lds, env.debug_skip);
 	}
 

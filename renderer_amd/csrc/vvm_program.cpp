@@ -402,19 +402,17 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 			lp.code.push_back(k);
 		}
 	};
+	// A load instruction names eight consecutive slots of the load list (one stream address each, in the order the loads are
+	// issued), so the kernel fetches all eight addresses with one scalar load.  -1 pads a partly used instruction.
+	lp.load_list.clear();
+	lp.out_list.clear();
 	auto emit_loads = [&](const std::vector<uint32_t>& prefetch, uint32_t dop) {
 		for (size_t i = 0; i < prefetch.size(); i += 8) {
 			const size_t n = std::min<size_t>(8, prefetch.size() - i);
-			uint64_t lo = 0; uint32_t hi = 0;     // eight 12-bit stream indices in 96 bits
-			for (size_t j = 0; j < n; ++j) {
-				const uint64_t idx = prefetch[i + j] & 0xFFFu;
-				const unsigned bit = 12u * (unsigned)j;
-				if (bit < 64) { lo |= idx << bit; if (bit + 12 > 64) hi |= (uint32_t)(idx >> (64 - bit)); }
-				else hi |= (uint32_t)(idx << (bit - 64));
-			}
 			VvmIns k;
 			k.w0 = VVM_INS_W0(dop, 0, 0, n, (uint32_t)input_vreg[prefetch[i]]);
-			k.w1 = (uint32_t)lo; k.w2 = (uint32_t)(lo >> 32); k.w3 = hi;
+			k.w1 = (uint32_t)lp.load_list.size(); k.w2 = 0; k.w3 = 0;
+			for (size_t j = 0; j < 8; ++j) lp.load_list.push_back(j < n ? (int32_t)prefetch[i + j] : -1);
 			lp.code.push_back(k);
 		}
 	};
@@ -454,13 +452,16 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 			else if (d.op == VVM_OP_outputdata_float_from_half) dop = VVM_DOP_OUTPUT32_FROM16;
 			for (size_t i = 0; i < d.pairs.size(); i += 3) {
 				const size_t n = std::min<size_t>(3, d.pairs.size() - i);
-				uint32_t o[6] = {0, 0, 0, 0, 0, 0};
-				for (size_t j = 0; j < n; ++j) {
-					o[2 * j] = operand(d.pairs[i + j].first);
-					o[2 * j + 1] = d.pairs[i + j].second - out0;     // output serial index
+				// sources in o0..o2; the destinations are four consecutive slots of the output list (-1 pads), first slot in w3
+				uint32_t o[3] = {0, 0, 0};
+				if (lp.out_list.size() + 4 > 0xFFFFu) { err = "too many output instructions"; return VVM_E_TOO_LARGE; }
+				k.w3 = (uint32_t)lp.out_list.size();
+				for (size_t j = 0; j < 4; ++j) {
+					if (j < n) o[j] = operand(d.pairs[i + j].first);
+					lp.out_list.push_back(j < n ? (int32_t)(d.pairs[i + j].second - out0) : -1);     // output serial index
 				}
 				k.w0 = VVM_INS_W0(dop, 0, 0, n, d.dataset);
-				k.w1 = o[0] | (o[1] << 16); k.w2 = o[2] | (o[3] << 16); k.w3 = o[4] | (o[5] << 16);
+				k.w1 = o[0] | (o[1] << 16); k.w2 = o[2];
 				lp.code.push_back(k);
 			}
 			break;
