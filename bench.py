@@ -62,11 +62,19 @@ def cpu_baseline(workload_name, seconds=12.0, n=1 << 20):
                       "reference structure (interpreted, 4-wide SSE, 64 KB-page chunks), not the reference's own binary" % (reps, n, el)}
 
 
-class _DevPtr:
-    """Zero-copy torch view of a raw device pointer (through __cuda_array_interface__)."""
-
-    def __init__(self, ptr, n):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (ptr, False), "version": 2}
+def recorded_traffic(workload, particles):
+    """HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE).  Counters cannot be read from inside this process;
+    tools/pmc_traffic.sh collects them with rocprofv3 in separate passes of this same command and profiles/ holds the result.
+    Returned only when it was taken on this workload and size."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if t.get("workload") == workload and t.get("particles_per_gpu") == particles:
+        return t.get("hbm_bytes_per_launch")
+    return None
 
 
 def main():
@@ -167,7 +175,7 @@ def main():
                        "parallelism": "instance ranges sharded over %d GPU(s); all-gather of survivor counts" % world if distributed
                        else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": None, "kernel": "vvm_exec_kernel", "kernel_ms": kernel_ms, "launches": launches,
+                         "traffic": recorded_traffic(args.workload, n), "kernel": "vvm_exec_kernel", "kernel_ms": kernel_ms, "launches": launches,
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
         if not args.no_cpu_baseline and world == 1:

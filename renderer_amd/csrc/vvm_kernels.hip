@@ -820,31 +820,15 @@ DEV void run_tile(const VvmExecDesc& d, const Ctx& c, unsigned char* lds, uint32
 		const uint32_t cnt_ = ((W0) >> 16) & 0xFFu, dst_ = (W0) >> 24; \
 		_Pragma("unroll") for (int j = 7; j >= 0; --j) REG_WRITE(((uint32_t)j < cnt_) ? dst_ + j : dst_, (ST)[j]); \
 	} while (0)
-	// The first load instruction is handled apart: while its loads are in flight the previous tile's look-back is resolved,
-	// and once they have arrived the previous tile's stores are issued.  The register vectors come into existence only after
-	// that, which keeps them out of the register budget of the look-back.
 	uint32_t pc0 = 0;
-	{
-		const uint32_t w0 = sload32(prog, 0), w1 = sload32(prog, 1);
+	for (;; ++pc0) {
+		const uint32_t w0 = sload32(prog, pc0 * 4 + 0);
 		const uint32_t lop = w0 & 0xFFu;
-		const bool loads_first = (lop == VVM_DOP_LOADN || lop == VVM_DOP_LOADN16);
+		if (lop != VVM_DOP_LOADN && lop != VVM_DOP_LOADN16) break;
+		const uint32_t w1 = sload32(prog, pc0 * 4 + 1);
 		float st[8][V];
-		if (loads_first) { VVM_ISSUE_LOADS(w0, w1, st); pc0 = 1; }
-		const bool finish_previous = pend.active;
-		if (finish_previous) resolve_tile<V>(pend, c, lds_ctrl, resolves, tag, error_word, dbg, pre, have_pre);
-		if (loads_first) VVM_WRITE_LOADS(w0, st);
-		if (finish_previous) store_tile<V>(pend, c, lds, dbg);
-	}
-	if (pc0 != 0) {
-		for (;; ++pc0) {      // further load instructions (more than eight streams of one width, or both widths)
-			const uint32_t w0 = sload32(prog, pc0 * 4 + 0);
-			const uint32_t lop = w0 & 0xFFu;
-			if (lop != VVM_DOP_LOADN && lop != VVM_DOP_LOADN16) break;
-			const uint32_t w1 = sload32(prog, pc0 * 4 + 1);
-			float st[8][V];
-			VVM_ISSUE_LOADS(w0, w1, st);
-			VVM_WRITE_LOADS(w0, st);
-		}
+		VVM_ISSUE_LOADS(w0, w1, st);
+		VVM_WRITE_LOADS(w0, st);
 	}
 #undef VVM_ISSUE_LOADS
 #undef VVM_WRITE_LOADS
@@ -1095,8 +1079,16 @@ DEV void run_tile(const VvmExecDesc& d, const Ctx& c, unsigned char* lds, uint32
 				kb |= ((fbits(p[k]) >> 31) & ((c.inst0 + k < c.num_instances) ? 1u : 0u)) << k;
 			const uint2 rt = acquire_rank_and_publish(kb, c, lds_ctrl, status, tile_local, tag, dbg);
 			t_keep = kb; t_rank = rt.x; t_total = SCALAR(rt.y); t_dataset = aux; t_pending = true;
-			continue;
 		}
+		// The previous tile is finished here: after this tile has published its own count (every later tile's look-back waits
+		// for that word, so it goes out first), and before this tile needs the staging slots.  The first poll of the previous
+		// tile's look-back has been in flight since this tile was claimed.
+		if (pend.active) {
+			resolve_tile<V>(pend, c, lds_ctrl, resolves, tag, error_word, dbg, pre, have_pre);
+			store_tile<V>(pend, c, lds, dbg);
+			__syncthreads();      // every thread has read its staged values: the slots may be written again
+		}
+		if (op == VVM_DOP_ACQUIRE) continue;
 		if (op == VVM_OP_done) break;
 
 		// Output instruction: aux = pair count (1..3), aux2 = dataset; sources o0..o2, destinations = output-list slots from w3.
