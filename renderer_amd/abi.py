@@ -303,14 +303,22 @@ class HipBackend(Backend):
         self._check(self.lib.vvm_exec_finish(C.byref(frame.ctx)), "vvm_exec_finish")
 
     def exec_batch(self, frames: Sequence[CallFrame], opts: Optional[Sequence[ExecOptions]] = None) -> None:
+        arr, oarr = self.pack_batch(frames, opts)
+        self.exec_batch_packed(arr, oarr)
+
+    @staticmethod
+    def pack_batch(frames: Sequence[CallFrame], opts: Optional[Sequence[ExecOptions]] = None):
+        """The contiguous vvm_exec_context / vvm_exec_options arrays vvm_exec_batch takes.  Results (DataSetAccessIndex) land in
+        the frames' dataset metas, which the copies point to; a caller that runs the same batch every tick packs once."""
         n = len(frames)
         arr = (ExecContext * n)()
         for i, f in enumerate(frames):
             C.memmove(C.byref(arr[i]), C.byref(f.ctx), C.sizeof(ExecContext))
-        oarr = None
-        if opts is not None:
-            oarr = (ExecOptions * n)(*opts)
-        self._check(self.lib.vvm_exec_batch(arr, n, oarr), "vvm_exec_batch")
+        oarr = (ExecOptions * n)(*opts) if opts is not None else None
+        return arr, oarr
+
+    def exec_batch_packed(self, arr, oarr=None) -> None:
+        self._check(self.lib.vvm_exec_batch(arr, len(arr), oarr), "vvm_exec_batch")
 
     def inspect_blob(self, blob: bytes) -> ProgramInfo:
         """Thaw + link only (no device needed); raises VVMError with the linker's message on a bad script."""

@@ -126,6 +126,8 @@ struct vvm_state {
 	hipStream_t stream = nullptr;
 	bool own_stream = false;
 	hipStream_t last_stream = nullptr;
+	bool in_flight = false;                // an asynchronous Exec has been enqueued and not finished yet
+	uint64_t batch_stamp = 0;              // the last vvm_exec_batch call this state took part in
 
 	// map caches, VectorVMRuntime.cpp:485-553 (constants only: inputs are classified at link time)
 	bool maps_ready = false;
@@ -242,7 +244,7 @@ int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, P
 
 // Fills one parameter block at `host` that will live at device address `dev`.
 int fill_params(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, const PreparedExec& pe, uint8_t* host,
-                uint8_t* dev, unsigned long long* d_status, uint32_t first_tile)
+                uint8_t* dev, unsigned long long* d_status, uint32_t first_tile, int32_t* d_counts = nullptr)
 {
 	const vvm::ThawedScript& s = st->script;
 	const vvm::LinkedProgram& lp = *pe.lp;
@@ -254,7 +256,7 @@ int fill_params(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* op
 	d->load_ptrs = (const uint64_t*)(dev + pe.off_load);
 	d->out_list = (const uint64_t*)(dev + pe.off_out);
 	d->status = d_status;
-	d->counts = st->d_counts;
+	d->counts = d_counts ? d_counts : st->d_counts;
 	d->perlin = st->d_perlin;
 	d->num_instances = (uint32_t)ctx->NumInstances;
 	d->num_tiles = pe.tiles;
@@ -394,6 +396,7 @@ VVM_API int vvm_exec_async(vvm_exec_context* ctx, const vvm_exec_options* opt)
 	hipStream_t stream = (opt && opt->Stream) ? (hipStream_t)opt->Stream : st->stream;
 	if (st->last_stream && st->last_stream != stream) HIP_TRY(hipStreamSynchronize(st->last_stream));
 	st->last_stream = stream;
+	st->in_flight = true;
 	if (pe.tiles == 0) {     // nothing to run: zero chunks in the reference too (RT.cpp:2277)
 		st->h_counts[0] = 0;
 		for (uint32_t i = 0; i < st->script.max_output_dataset; ++i) st->h_counts[i] = 0;
@@ -437,6 +440,7 @@ VVM_API int vvm_exec_finish(vvm_exec_context* ctx)
 	vvm_state* st = ctx->VVMState;
 	const bool ran = ctx->NumInstances > 0;
 	if (st->last_stream) HIP_TRY(hipStreamSynchronize(st->last_stream));
+	st->in_flight = false;
 	if (ran) {
 		const size_t ncounts = std::max<uint32_t>(st->script.max_output_dataset, 1);
 		const VvmLaunchState* ls = (const VvmLaunchState*)(st->h_counts + ncounts + 4);
@@ -466,6 +470,7 @@ struct BatchWorkspace {
 	std::mutex mutex;
 	uint8_t* host = nullptr; uint8_t* dev = nullptr; size_t bytes = 0;
 	unsigned long long* d_status = nullptr; uint32_t status_capacity = 0;
+	int32_t* d_counts = nullptr; int32_t* h_counts = nullptr; size_t counts_capacity = 0;   // survivor counts of all Execs of a batch
 	VvmLaunchState* d_launch[8] = {};
 	VvmLaunchState* h_launch = nullptr;
 	hipStream_t stream = nullptr;
@@ -480,6 +485,8 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 	std::lock_guard<std::mutex> lock(g_batch.mutex);
 	int rc = ensure_device_info();
 	if (rc != VVM_OK) return rc;
+	static uint64_t batch_counter = 0;
+	const uint64_t stamp = ++batch_counter;      // (under the workspace mutex)
 	std::vector<PreparedExec> pes((size_t)n);
 	// group by kernel shape: (instances per lane, spill, full)
 	struct Group { int key; std::vector<int> members; uint32_t tiles = 0; uint32_t spill = 0; };
@@ -487,12 +494,12 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 	size_t total_bytes = 0; uint32_t total_tiles = 0;
 	for (int i = 0; i < n; ++i) {
 		if (!ctxs[i].VVMState) return fail(VVM_E_INVALID_ARG, "null state in batch");
-		for (int j = 0; j < i; ++j)
-			if (ctxs[j].VVMState == ctxs[i].VVMState) return fail(VVM_E_INVALID_ARG, "a state appears twice in one batch (one Exec at a time per state)");
+		if (ctxs[i].VVMState->batch_stamp == stamp) return fail(VVM_E_INVALID_ARG, "a state appears twice in one batch (one Exec at a time per state)");
+		ctxs[i].VVMState->batch_stamp = stamp;
 		rc = prepare(ctxs[i].VVMState, &ctxs[i], opts ? &opts[i] : nullptr, pes[(size_t)i]);
 		if (rc != VVM_OK) return rc;
 		vvm_state* st = ctxs[i].VVMState;
-		if (st->last_stream) { HIP_TRY(hipStreamSynchronize(st->last_stream)); }
+		if (st->in_flight && st->last_stream) { HIP_TRY(hipStreamSynchronize(st->last_stream)); st->in_flight = false; }
 		const vvm::LinkedProgram& lp = *pes[(size_t)i].lp;
 		const int key = (int)lp.instances_per_lane * 4 + (lp.lds_spill_slots ? 2 : 0) + (lp.full_kernel ? 1 : 0);
 		Group* g = nullptr;
@@ -517,6 +524,19 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 			HIP_TRY(hipMalloc((void**)&g_batch.d_launch[g], sizeof(VvmLaunchState)));
 			HIP_TRY(reset_launch_state(g_batch.d_launch[g]));
 		}
+
+	// one counts array for the whole batch (a device-to-host copy per state would cost more than the kernel)
+	std::vector<size_t> counts_off((size_t)n);
+	size_t total_counts = 0;
+	for (int i = 0; i < n; ++i) { counts_off[(size_t)i] = total_counts; total_counts += std::max<uint32_t>(ctxs[i].VVMState->script.max_output_dataset, 1); }
+	if (total_counts > g_batch.counts_capacity) {
+		if (g_batch.d_counts) (void)hipFree(g_batch.d_counts);
+		if (g_batch.h_counts) (void)hipHostFree(g_batch.h_counts);
+		g_batch.counts_capacity = total_counts + total_counts / 4 + 64;
+		HIP_TRY(hipMalloc((void**)&g_batch.d_counts, g_batch.counts_capacity * 4));
+		HIP_TRY(hipHostMalloc((void**)&g_batch.h_counts, g_batch.counts_capacity * 4, hipHostMallocDefault));
+	}
+	HIP_TRY(hipMemsetAsync(g_batch.d_counts, 0, total_counts * 4, g_batch.stream));
 
 	// Descriptors of one group are contiguous (the kernel indexes them); their tables follow all descriptors.
 	size_t desc_off = 0;
@@ -543,7 +563,8 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 			scratch.assign(pe.bytes, 0);
 			// tables live at table_off in the device buffer; fill_params computes table addresses as dev + pe.off_*
 			uint8_t* dev_block = g_batch.dev + table_off;
-			rc = fill_params(st, &ctxs[i], opts ? &opts[i] : nullptr, pe, scratch.data(), dev_block, g_batch.d_status + status_off, first_tile);
+			rc = fill_params(st, &ctxs[i], opts ? &opts[i] : nullptr, pe, scratch.data(), dev_block, g_batch.d_status + status_off, first_tile,
+			                 g_batch.d_counts + counts_off[(size_t)i]);
 			if (rc != VVM_OK) return rc;
 			memcpy(g_batch.host + desc_off, scratch.data(), sizeof(VvmExecDesc));
 			memcpy(g_batch.host + table_off, scratch.data(), pe.bytes);
@@ -564,12 +585,13 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 		if (lrc != 0) return hip_fail((hipError_t)lrc, "batched kernel launch");
 		HIP_TRY(hipMemcpyAsync(&g_batch.h_launch[g], g_batch.d_launch[g], 80, hipMemcpyDeviceToHost, g_batch.stream));
 	}
+	HIP_TRY(hipMemcpyAsync(g_batch.h_counts, g_batch.d_counts, total_counts * 4, hipMemcpyDeviceToHost, g_batch.stream));
+	HIP_TRY(hipStreamSynchronize(g_batch.stream));
 	for (int i = 0; i < n; ++i) {
 		vvm_state* st = ctxs[i].VVMState;
 		const size_t ncounts = std::max<uint32_t>(st->script.max_output_dataset, 1);
-		HIP_TRY(hipMemcpyAsync(st->h_counts, st->d_counts, ncounts * 4, hipMemcpyDeviceToHost, g_batch.stream));
+		memcpy(st->h_counts, g_batch.h_counts + counts_off[(size_t)i], ncounts * 4);
 	}
-	HIP_TRY(hipStreamSynchronize(g_batch.stream));
 	for (size_t g = 0; g < groups.size(); ++g)
 		if (groups[g].tiles && g_batch.h_launch[g].pad != 0) {
 			(void)reset_launch_state(g_batch.d_launch[g]);

@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""The benchmark configurations other than the headline one (bench.py holds that):
+
+  transcendental   16 Mi particles, sin_cos + exp + curl-noise script            (BASELINE.json configs[2])
+  kill_half        64 Mi particles, fountain with 50 % death                      (configs[3], one GPU's share scaled down)
+  batch            4096 emitters x 16 Ki particles, 64 distinct bytecode bodies, one launch per kernel shape  (configs[4])
+
+Prints one JSON object per configuration.  Times are wall-clock around synchronous calls (vvm_exec / vvm_exec_batch), so
+they include the launch and the parameter upload; `kernel_ms` is the device time from HIP events where available.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--which", default="transcendental,kill_half,batch")
+    ap.add_argument("--steps", type=int, default=10)
+    args = ap.parse_args()
+    import torch
+    from renderer_amd import abi, scripts
+    from renderer_amd.runtime import VectorVMState
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    be = abi.load_hip_backend()
+    PAD = 64
+
+    def run_single(name, w, ins, n_out, n, ext=()):
+        outs = [torch.zeros(n + PAD, dtype=torch.float32, device=dev) for _ in range(n_out)]
+        torch.cuda.synchronize()
+        st = VectorVMState(w.script.blob, be)
+        frame = st.frame([abi.DataSet([t.data_ptr() for t in ins], [t.data_ptr() for t in outs], 0)], n, [w.constants], list(ext))
+        for _ in range(3):
+            surv = st.exec(frame)
+        st.enable_timing(True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            st.exec_async(frame)
+        surv = st.finish(frame)
+        el = time.perf_counter() - t0
+        ms, launches = st.collect_kernel_ms()
+        info = st.info()
+        st.close()
+        kernel_ms = ms / max(launches, 1)
+        alg = info.BytesInPerInstance * n + info.BytesOutPerInstance * surv
+        print(json.dumps({"config": name, "particles": n, "survivors": surv, "steps": args.steps, "ms_per_step": el / args.steps * 1e3,
+                          "kernel_ms": kernel_ms, "updates_per_s": n * args.steps / el, "algorithmic_GBps": alg / kernel_ms / 1e6,
+                          "frac_of_8TBps": alg / kernel_ms / 1e6 / 8000.0, "instances_per_lane": int(info.InstancesPerLane)}), flush=True)
+
+    which = args.which.split(",")
+    if "transcendental" in which:
+        n = 16 * 1024 * 1024
+        w = scripts.transcendental(True)
+        run_single("transcendental 16Mi (sin_cos, exp, curl_noise3)", w, scripts.transcendental_streams_torch(0, n, dev, pad=PAD), 4, n, w.ext_fns)
+    if "kill_half" in which:
+        n = 64 * 1024 * 1024
+        w = scripts.fountain()
+        run_single("fountain 64Mi, 50% death", w, scripts.fountain_streams_torch(0, n, dev, kill_half=True, pad=PAD), 8, n)
+    if "batch" in which:
+        emitters, per = 4096, 16384
+        total = emitters * per
+        ins = scripts.fountain_streams_torch(0, total, dev, kill_half=True, pad=PAD)
+        outs = [torch.zeros(total + PAD, dtype=torch.float32, device=dev) for _ in range(8)]
+        torch.cuda.synchronize()
+        workloads = [scripts.fountain(variant=v) for v in range(64)]
+        states, frames, opts = [], [], []
+        for e in range(emitters):
+            w = workloads[e % 64]
+            st = VectorVMState(w.script.blob, be)
+            states.append(st)
+            off = e * per * 4
+            frames.append(st.frame([abi.DataSet([t.data_ptr() + off for t in ins], [t.data_ptr() + off for t in outs], 0)], per, [w.constants]))
+            opts.append(abi.ExecOptions(0, 0, 0, None, 0))
+        arr, oarr = be.pack_batch(frames, opts)
+        for _ in range(2):
+            be.exec_batch_packed(arr, oarr)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            be.exec_batch_packed(arr, oarr)
+        el = time.perf_counter() - t0
+        surv = sum(f.survivors(0) for f in frames)
+        alg = 32.0 * total + 32.0 * surv
+        print(json.dumps({"config": "batch 4096 emitters x 16Ki, 64 bytecode variants", "particles": total, "survivors": surv, "steps": args.steps,
+                          "ms_per_step": el / args.steps * 1e3, "updates_per_s": total * args.steps / el,
+                          "algorithmic_GBps_wallclock": alg * args.steps / el / 1e9}), flush=True)
+        for st in states:
+            st.close()
+
+
+if __name__ == "__main__":
+    main()
