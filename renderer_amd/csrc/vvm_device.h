@@ -33,11 +33,20 @@ enum : uint32_t {
 	                       // aux = count, aux2 = first register, w1 = first slot of VvmExecDesc::load_ptrs
 	VVM_DOP_ACQUIRE = 192, // acquireindex; every opcode from here on produces no register result
 	VVM_DOP_OUTPUT32 = 193, // up to 3 (src,dst) pairs of outputdata_float / outputdata_int32: aux = count, aux2 = dataset,
-	                        // o0..o2 = sources, w3 = first slot of VvmExecDesc::out_list
+	                        // o0..o2 = sources, w3 = the first pair's slot of VvmExecDesc::out_list (the pairs of one
+	                        // instruction lie in one group of VVM_STAGE_SLOTS slots)
 	VVM_DOP_OUTPUT16 = 194, // up to 3 pairs of outputdata_half (float register -> half stream)
 	VVM_DOP_OUTPUT16_FROM16 = 195,
-	VVM_DOP_OUTPUT32_FROM16 = 196
+	VVM_DOP_OUTPUT32_FROM16 = 196,
+	VVM_DOP_FLUSH = 197     // between two groups of output slots: write out what the output instructions before it have staged
 };
+
+// Output values wait in LDS staging slots until the tile's output position is known; one group of slots is written out at a time.
+#define VVM_STAGE_SLOTS 8
+// entry of VvmExecDesc::out_list: byte address in the low 48 bits (0 = nothing is written), flags above
+#define VVM_OUT_IS16 (1ull << 62)         // the destination stream has 16-bit elements
+#define VVM_OUT_GROUP16 (1ull << 61)      // on a group's first entry: some entry of the group has VVM_OUT_IS16
+#define VVM_OUT_ADDR_MASK 0x0000FFFFFFFFFFFFull
 
 // Device instruction, 16 bytes:
 //   w0: op[0:8) nin[8:11) nout[11:13) aux[16:24) aux2[24:32)
@@ -55,8 +64,8 @@ struct VvmExecDesc {
 	const uint32_t* consts;        // NumConstBuffers dwords, remapped order, zero-padded to a multiple of 4 dwords
 	const uint64_t* in_ptrs;       // byte address of element [InstanceOffset] of every remapped input stream (no-advance operands)
 	const uint64_t* load_ptrs;     // the same addresses in load-list order: 8 per load instruction, 64-byte aligned
-	const uint64_t* out_list;      // byte address of element [InstanceOffset] of every output, in output-list order: 4 per output
-	                               // instruction, 32-byte aligned (0 = the script has no such output)
+	const uint64_t* out_list;      // element [InstanceOffset] of every output in staging order (see VVM_OUT_*), in groups of
+	                               // VVM_STAGE_SLOTS entries, 64-byte aligned
 	unsigned long long* status;    // one look-back word per tile of this Exec
 	int32_t*        counts;        // survivor count per output dataset (written by the Exec's last tile)
 	const uint8_t*  perlin;        // 512-byte permutation table when the script calls a noise built-in

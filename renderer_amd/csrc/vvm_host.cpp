@@ -236,8 +236,8 @@ int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, P
 	pe.off_consts = align_up(sizeof(VvmExecDesc), 16);
 	pe.off_in = align_up(pe.off_consts + 4u * (size_t)s.num_consts, 16);     // (so the table is padded to a multiple of 4 dwords)
 	pe.off_load = align_up(pe.off_in + 8u * (size_t)s.num_inputs, 64);
-	pe.off_out = align_up(pe.off_load + 8u * pe.lp->load_list.size(), 64);
-	pe.bytes = align_up(pe.off_out + 8u * pe.lp->out_list.size(), 256);      // (the block itself is 256-byte aligned)
+	pe.off_out = align_up(pe.off_load + 8u * pe.lp->load_list.size(), 64) + 64;      // (the entry before the list is in use too)
+	pe.bytes = align_up(pe.off_out + 8u * align_up(pe.lp->out_list.size(), VVM_STAGE_SLOTS), 256);      // (the block itself is 256-byte aligned)
 	(void)O;
 	return VVM_OK;
 }
@@ -287,8 +287,13 @@ int fill_params(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* op
 	uint64_t* load_ptrs = (uint64_t*)(host + pe.off_load);
 	for (size_t i = 0; i < lp.load_list.size(); ++i) load_ptrs[i] = lp.load_list[i] >= 0 ? in_ptrs[lp.load_list[i]] : 0;
 	uint64_t* out_list = (uint64_t*)(host + pe.off_out);                                                // RT.cpp:418-441
+	memset(out_list, 0, pe.bytes - pe.off_out);
+	{   // the entry before the list: where the Exec's last tile writes the survivor count of the acquired dataset
+		uint32_t acquired = 0;
+		for (size_t k = 0; k < lp.acquires_dataset.size(); ++k) if (lp.acquires_dataset[k]) acquired = (uint32_t)k;
+		out_list[-1] = (uint64_t)(uintptr_t)(d->counts + acquired);
+	}
 	for (size_t k = 0; k < lp.out_list.size(); ++k) {
-		out_list[k] = 0;
 		const int32_t i = lp.out_list[k];
 		if (i < 0 || (uint32_t)i >= s.num_outputs_remapped || s.out_dst[i] == 0xFFFF) continue;
 		const uint8_t dsi = s.out_dataset[i];
@@ -298,7 +303,13 @@ int fill_params(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* op
 		const uint32_t idx = ds.OutputRegisterTypeOffsets[ty] + s.out_dst[i];
 		if ((int)idx >= ds.OutputRegisters.num) return fail(VVM_E_INVALID_ARG, "output register index past OutputRegisters.num");
 		const uint64_t stride = (ty == 2) ? 2 : 4;
-		out_list[k] = (uint64_t)(uintptr_t)ds.OutputRegisters.data[idx] + (uint64_t)(int64_t)ds.InstanceOffset * stride;
+		if (!ds.OutputRegisters.data[idx]) continue;
+		const uint64_t addr = (uint64_t)(uintptr_t)ds.OutputRegisters.data[idx] + (uint64_t)(int64_t)ds.InstanceOffset * stride;
+		if (addr & ~VVM_OUT_ADDR_MASK) return fail(VVM_E_INVALID_ARG, "output register address does not fit 48 bits");
+		out_list[k] = addr | (lp.out_is16[k] ? VVM_OUT_IS16 : 0);
+	}
+	for (size_t k = 0; k < lp.out_list.size(); ++k) {
+		if (lp.out_is16[k]) out_list[k & ~(size_t)(VVM_STAGE_SLOTS - 1)] |= VVM_OUT_GROUP16;
 	}
 	// the reference's chunk bookkeeping has no meaning here; report one chunk that holds everything
 	ctx->Internal.NumBytesRequiredPerBatch = 0;

@@ -52,6 +52,13 @@ __device__ __forceinline__ uint64_t sload64(const void* p, uint32_t i)
 // 2^K consecutive 64-bit table entries with one scalar load (the table must be aligned to the size of the load)
 typedef uint32_t su32x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t su32x16 __attribute__((ext_vector_type(16)));
+// four consecutive dwords at a 32-bit byte offset (one scalar load that takes the offset as it is)
+typedef uint32_t su32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void sload32x4_at(const void* p, uint32_t byte_offset, uint32_t& w0, uint32_t& w1, uint32_t& w2, uint32_t& w3)
+{
+	const su32x4 v = *(const __attribute__((address_space(4))) su32x4*)((uintptr_t)p + (uint64_t)byte_offset);
+	w0 = SCALAR(v[0]); w1 = SCALAR(v[1]); w2 = SCALAR(v[2]); w3 = SCALAR(v[3]);
+}
 __device__ __forceinline__ void sload64x4(const void* p, uint32_t first, uint64_t (&out)[4])
 {
 	const su32x8 v = *(const __attribute__((address_space(4))) su32x8*)(uintptr_t)((const uint64_t*)p + first);
@@ -80,10 +87,9 @@ template <typename VEC> __device__ __forceinline__ VEC vset(VEC v, uint32_t i, f
 // LDS carve (dynamic region only, every offset a multiple of 16)
 //   [0, 256)      control words (uint32), see the LC_ constants
 //   [256, 768)    Perlin permutation table
-//   [768, 896)    staged outputs: destination address (uint64 x VVM_STAGE_SLOTS) then kind (uint32 x VVM_STAGE_SLOTS)
+//   [768, 896)    unused
 //   [896, ...)    output staging: VVM_STAGE_SLOTS slots of one tile's worth of 32-bit values, then one sink dword per thread
 //   then          register spill slots
-#define VVM_STAGE_SLOTS     8u
 #define LDS_PERLIN_OFF      256
 #define LDS_STAGE_META_OFF  768
 #define LDS_STAGE_OFF       896
@@ -444,10 +450,13 @@ DEV uint32_t wave_sum(uint32_t v)
 #define CREGS RVEC R0, RVEC R1, RVEC R2, RVEC R3
 #define RARGS R0, R1, R2, R3
 
+// (Fields of the Exec descriptor that an instruction needs rarely are read from the descriptor where they are used, with a
+// scalar load: a value kept in a scalar register for the whole tile costs more than the occasional load.)
+#define DESC_U32(dp, field) sload32((dp), offsetof(VvmExecDesc, field) / 4)
+#define DESC_PTR(dp, field) sload64((dp), offsetof(VvmExecDesc, field) / 8)
 struct Ctx {
+	const void*     dp;           // the Exec's VvmExecDesc
 	const uint32_t* consts;
-	const uint64_t* in_ptrs;
-	const uint64_t* load_ptrs;
 	const uint64_t* out_list;
 	const uint8_t*  perlin_lds;
 	float*          spill;        // LDS, [slot][thread] (V floats per thread and slot)
@@ -567,7 +576,7 @@ DEV void look_back_poll(gu64* status, int32_t first, uint32_t lane, u64 (&w)[VVM
 		w[j] = __hip_atomic_load(status + max(first - (int32_t)lane - 64 * j, 0), RLX_AGENT);
 }
 // `pre` holds a first poll that the caller issued earlier (have_pre), so that its round trip overlaps other work.
-DEV uint32_t look_back(gu64* status, uint32_t tile, uint32_t tag, uint32_t lane, gu32* error_word, uint32_t& rounds, uint32_t& polls,
+DEV uint32_t look_back(gu64* status, uint32_t tile, uint32_t tag, uint32_t lane, VvmLaunchState* ls, uint32_t& rounds, uint32_t& polls,
                        const u64 (&pre)[VVM_LB_WORDS_PER_LANE], bool have_pre)
 {
 	constexpr int WPL = VVM_LB_WORDS_PER_LANE;
@@ -595,7 +604,7 @@ DEV uint32_t look_back(gu64* status, uint32_t tile, uint32_t tag, uint32_t lane,
 			}
 			if (__all(ok)) break;
 			if (++spins > (1u << 22)) {     // a predecessor never published: give up rather than hang the device
-				__hip_atomic_store(error_word, 1u, RLX_AGENT);
+				__hip_atomic_store((gu32*)&ls->pad, 1u, RLX_AGENT);
 				return sum;
 			}
 			__builtin_amdgcn_s_sleep(1);
@@ -661,11 +670,15 @@ struct Pending {
 	bool     unresolved;   // the tile's count is published, its exclusive prefix not yet known
 	uint32_t total;        // survivors in the tile
 	uint32_t base;         // exclusive prefix (valid once resolved)
-	uint32_t n_staged;     // staging slots in use
-	uint32_t tile_local, num_tiles;
+	bool     last;         // the Exec's last tile: it writes the dataset's survivor count
+	uint32_t stage_end;    // output-list index one past the last staged slot (0: nothing staged); the slots in use are the
+	                       // entries of its group of VVM_STAGE_SLOTS up to there
+	uint32_t tile_local;
 	gu64*    status;
-	int32_t* count_out;
+	const uint64_t* out_list;      // the Exec's output list; the entry before it is the address of the survivor count
 };
+#define STAGED_COUNT(end) ((end) ? (((end) - 1u) & (VVM_STAGE_SLOTS - 1u)) + 1u : 0u)
+#define STAGED_FIRST(end) ((end) ? ((end) - 1u) & ~(VVM_STAGE_SLOTS - 1u) : 0u)
 
 // Finishing a tile takes two steps, both run by the NEXT tile while its input loads are in flight (also when the staging
 // slots run out, and after the last tile):
@@ -676,7 +689,7 @@ struct Pending {
 //                 each staged output.  A thread moves V consecutive values, so every tile stores 128 bits per lane whatever
 //                 its death rate.  Issued after the next tile's loads have arrived: stores and loads share one completion
 //                 counter, and a wait for loads would otherwise also wait for these stores.
-template <int V> DEV void resolve_tile(Pending& p, const Ctx& c, uint32_t* lds_ctrl, uint32_t& resolves, uint32_t tag, gu32* error_word, uint32_t dbg,
+template <int V> DEV void resolve_tile(Pending& p, const Ctx& c, uint32_t* lds_ctrl, uint32_t& resolves, uint32_t tag, VvmLaunchState* ls, uint32_t dbg,
                                      const u64 (&pre)[VVM_LB_WORDS_PER_LANE], bool have_pre)
 {
 	if (p.unresolved && p.tile_local != 0) {
@@ -686,7 +699,7 @@ template <int V> DEV void resolve_tile(Pending& p, const Ctx& c, uint32_t* lds_c
 			const uint32_t lane = c.tid & 63u;
 			uint32_t rounds = 0, polls = 0;
 			const u64 t0 = (dbg & 128u) ? __builtin_amdgcn_s_memtime() : 0;
-			const uint32_t ex = (dbg & 32u) ? p.tile_local * (VVM_BLOCK_THREADS * V) : look_back(p.status, p.tile_local, tag, lane, error_word, rounds, polls, pre, have_pre);
+			const uint32_t ex = (dbg & 32u) ? p.tile_local * (VVM_BLOCK_THREADS * V) : look_back(p.status, p.tile_local, tag, lane, ls, rounds, polls, pre, have_pre);
 			*slot = ex;
 			store_u64_first_lane(p.status + p.tile_local, ((u64)tag << 34) | (VVM_LB_INCLUSIVE << 32) | (ex + p.total), lane);
 			if (dbg & 128u) {      // per-workgroup sums (all lanes of wave 0 write the same values)
@@ -701,36 +714,64 @@ template <int V> DEV void resolve_tile(Pending& p, const Ctx& c, uint32_t* lds_c
 		__syncthreads();
 		if (p.unresolved) p.base = 0;
 	}
-	if (p.unresolved && p.tile_local + 1 == p.num_tiles && c.wave == 0 && !(dbg & 16u)) *p.count_out = (int32_t)(p.base + p.total);
+	if (p.unresolved && p.last && c.wave == 0 && !(dbg & 16u)) *(int32_t*)sload64(p.out_list - 1, 0) = (int32_t)(p.base + p.total);
 	p.unresolved = false;
+}
+// One staging slot to its destination: entry `e` of the output list, 32-bit values at src[0..V).  off4 = 4 * base and
+// rec4 = 4 * total come from the caller (the same for every slot).  Elements at and past `total` are dropped by the bounds
+// check; so is everything when the entry has no destination.
+template <int V, bool ANY16> DEV void store_slot(uint64_t e, const float* q, uint32_t i0, uint64_t off4, uint32_t rec4)
+{
+	const uint64_t ptr = e & VVM_OUT_ADDR_MASK;
+	if (ANY16 && (e & VVM_OUT_IS16)) {       // 16-bit destination, the staged value holds the bits
+		const rsrc_t rs = make_rsrc(ptr + (off4 >> 1), ptr ? (rec4 >> 1) : 0u);
+#pragma unroll
+		for (int k = 0; k < V; ++k)
+			__builtin_amdgcn_raw_buffer_store_b16((uint16_t)fbits(q[k]), rs, (int)((i0 + k) * 2u), 0, AUX_STREAM);
+		return;
+	}
+	const rsrc_t rs = make_rsrc(ptr + off4, ptr ? rec4 : 0u);
+	if constexpr (V == 4) {
+		const f4a x = *(const f4a*)q;
+		u32x4 y; y.x = fbits(x.x); y.y = fbits(x.y); y.z = fbits(x.z); y.w = fbits(x.w);
+		__builtin_amdgcn_raw_buffer_store_b128(y, rs, (int)(i0 * 4u), 0, AUX_STREAM);
+	} else {
+		__builtin_amdgcn_raw_buffer_store_b32(fbits(q[0]), rs, (int)(i0 * 4u), 0, AUX_STREAM);
+	}
+}
+template <int V, bool ANY16> DEV void store_slots(const uint64_t (&entry)[VVM_STAGE_SLOTS], uint32_t n, const float* src, uint32_t i0, uint64_t off4, uint32_t rec4)
+{
+	// the staged slots are 0 .. n-1: enter the chain at slot n-1 and fall through to slot 0 (no per-slot loop test)
+#define VVM_SLOT(s) store_slot<V, ANY16>(entry[s], src + (s) * (VVM_BLOCK_THREADS * V), i0, off4, rec4)
+	switch (n) {
+	case 8: VVM_SLOT(7); [[fallthrough]];
+	case 7: VVM_SLOT(6); [[fallthrough]];
+	case 6: VVM_SLOT(5); [[fallthrough]];
+	case 5: VVM_SLOT(4); [[fallthrough]];
+	case 4: VVM_SLOT(3); [[fallthrough]];
+	case 3: VVM_SLOT(2); [[fallthrough]];
+	case 2: VVM_SLOT(1); [[fallthrough]];
+	case 1: VVM_SLOT(0); [[fallthrough]];
+	default: break;
+	}
+#undef VVM_SLOT
 }
 template <int V> DEV void store_tile(Pending& p, const Ctx& c, unsigned char* lds, uint32_t dbg)
 {
-	const uint32_t* meta = (const uint32_t*)(lds + LDS_STAGE_META_OFF);
-	const float* stage = (const float*)(lds + LDS_STAGE_OFF);
-	const uint32_t i0 = c.tid * V;
-	for (uint32_t s = 0; s < p.n_staged; ++s) {
-		const uint64_t ptr = ((uint64_t)SCALAR(meta[2 * s + 1]) << 32) | (uint64_t)SCALAR(meta[2 * s]);
-		const uint32_t kind = SCALAR(meta[2 * VVM_STAGE_SLOTS + s]);
-		const float* src = stage + s * (VVM_BLOCK_THREADS * V) + i0;
-		if (dbg & 8u) continue;
-		if (kind == 0 || kind == 3) {          // 32-bit destination; elements at and past `total` are dropped by the bounds check
-			const rsrc_t rs = make_rsrc(ptr + 4ull * p.base, 4u * p.total);
-			if constexpr (V == 4) {
-				const f4a x = *(const f4a*)src;
-				u32x4 y; y.x = fbits(x.x); y.y = fbits(x.y); y.z = fbits(x.z); y.w = fbits(x.w);
-				__builtin_amdgcn_raw_buffer_store_b128(y, rs, (int)(i0 * 4u), 0, AUX_STREAM);
-			} else {
-				__builtin_amdgcn_raw_buffer_store_b32(fbits(src[0]), rs, (int)(i0 * 4u), 0, AUX_STREAM);
-			}
-		} else {                               // 16-bit destination, the staged value holds the bits
-			const rsrc_t rs = make_rsrc(ptr + 2ull * p.base, 2u * p.total);
-#pragma unroll
-			for (int k = 0; k < V; ++k)
-				__builtin_amdgcn_raw_buffer_store_b16((uint16_t)fbits(src[k]), rs, (int)((i0 + k) * 2u), 0, AUX_STREAM);
-		}
+	static_assert(VVM_STAGE_SLOTS == 8, "store_slots is written for eight slots");
+	const uint32_t n_staged = STAGED_COUNT(p.stage_end);
+	if (n_staged != 0 && !(dbg & 8u)) {
+		// slot s holds the values for entry first + s of the Exec's output list: all eight entries arrive with one scalar load
+		uint64_t entry[VVM_STAGE_SLOTS];
+		sload64x8(p.out_list, STAGED_FIRST(p.stage_end), entry);
+		const uint32_t i0 = c.tid * V;
+		const float* src = (const float*)(lds + LDS_STAGE_OFF) + i0;
+		const uint64_t off4 = 4ull * p.base;
+		const uint32_t rec4 = 4u * p.total;
+		if (entry[0] & VVM_OUT_GROUP16) store_slots<V, true>(entry, n_staged, src, i0, off4, rec4);
+		else store_slots<V, false>(entry, n_staged, src, i0, off4, rec4);
 	}
-	p.n_staged = 0;
+	p.stage_end = 0;
 	p.active = false;
 }
 
@@ -745,9 +786,9 @@ template <int V> DEV void fetch_slow(const Ctx& c, uint32_t o, float (&out)[V])
 	const uint32_t cls = VVM_OPND_CLS(o), idx = VVM_OPND_IDX(o);
 	uint32_t u = 0;
 	if (cls == VVM_OPC_CONST) u = sload32(c.consts, idx);
-	else if (cls == VVM_OPC_NOADV) u = sload32((const void*)sload64(c.in_ptrs, idx), 0);      // element [InstanceOffset], VectorVMRuntime.cpp:381-401
+	else if (cls == VVM_OPC_NOADV) u = sload32((const void*)sload64((const void*)DESC_PTR(c.dp, in_ptrs), idx), 0);      // element [InstanceOffset], VectorVMRuntime.cpp:381-401
 	else if (cls == VVM_OPC_NOADV_HALF) {                                                     // converted once, like VectorVMRuntime.cpp:388-394
-		const uint64_t a = sload64(c.in_ptrs, idx);
+		const uint64_t a = sload64((const void*)DESC_PTR(c.dp, in_ptrs), idx);
 		const uint32_t w = sload32((const void*)(a & ~3ull), 0);
 		u = fbits(load_half((a & 2ull) ? (w >> 16) : (w & 0xFFFFu)));
 	}
@@ -778,23 +819,21 @@ struct KernelEnv {
 
 // ------------------------------------------------------------------------------------------------------
 template <int V, bool SPILL, bool FULL>
-DEV void run_tile(const VvmExecDesc& d, const Ctx& c, unsigned char* lds, uint32_t tile_local, uint32_t tag, gu32* error_word, uint32_t dbg, Pending& pend,
+DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c, unsigned char* lds, uint32_t tile_local, uint32_t tag, VvmLaunchState* ls, uint32_t dbg, Pending& pend,
                   uint32_t& resolves, const u64 (&pre)[VVM_LB_WORDS_PER_LANE], bool have_pre)
 {
 	RVEC R0 = 0.0f, R1 = 0.0f, R2 = 0.0f, R3 = 0.0f;
 	uint32_t* lds_ctrl = (uint32_t*)lds;
 	// acquireindex state of the tile: all wave-uniform except keep and rank
 	uint32_t t_keep = 0, t_rank = 0;
-	uint32_t t_total = 0, t_base = 0, t_dataset = ~0u;
+	uint32_t t_total = 0, t_base = 0;
 	bool t_pending = false;          // the tile's count is published, its prefix not yet resolved
-	uint32_t n_staged = 0;           // staging slots this tile has filled
-	const VvmIns* prog = d.prog;
-	gu64* status = (gu64*)d.status;
+	uint32_t stage_end = 0;          // output-list index one past the last slot this tile has staged (0: nothing staged)
 
 	// Uniform registers: lane i of `uni` holds constant i.  Filled by scalar loads and lane writes (the table is padded to a
 	// multiple of four dwords): a vector load would leave a pending-load wait on every later read of `uni`, and that wait
 	// would also cover the previous tile's output stores.
-	const uint32_t uni = fill_uniforms<0>(0u, c.consts, d.num_unif);
+	const uint32_t uni = fill_uniforms<0>(0u, c.consts, DESC_U32(c.dp, num_unif));
 	const u64 tl0 = (dbg & 128u) ? __builtin_amdgcn_s_memtime() : 0;
 
 	// Prologue: the program starts with its VVM_DOP_LOADN / VVM_DOP_LOADN16 instructions.  They run ahead of the main loop so
@@ -802,12 +841,12 @@ DEV void run_tile(const VvmExecDesc& d, const Ctx& c, unsigned char* lds, uint32
 	// copy of the whole register file alive across the loop).
 	//   aux = count (1..8), aux2 = first destination register, w1 = first of eight slots of the load list: the eight stream
 	//   addresses arrive with one scalar load, then all stream loads are issued back to back.
-	//   Unused slots write (zeros) to the first slot's register, and the first slot is written last: every write is a plain
-	//   insert, none has to read the register it might have to preserve.
+	//   Unused slots write (zeros) to the last used slot's register, and the slots are written from the last one down: every
+	//   write is a plain insert, none has to read the register it might have to preserve.
 #define VVM_ISSUE_LOADS(W0, W1, ST) do { \
 		const uint32_t lop_ = (W0) & 0xFFu, cnt_ = ((W0) >> 16) & 0xFFu; \
 		uint64_t ptr_[8]; \
-		sload64x8(c.load_ptrs, (W1), ptr_); \
+		sload64x8(load_ptrs, (W1), ptr_); \
 		_Pragma("unroll") for (int j = 0; j < 8; ++j) { \
 			_Pragma("unroll") for (int k = 0; k < V; ++k) (ST)[j][k] = 0.0f; \
 			if ((uint32_t)j < cnt_ && !(dbg & 2u)) { \
@@ -818,8 +857,9 @@ DEV void run_tile(const VvmExecDesc& d, const Ctx& c, unsigned char* lds, uint32
 	} while (0)
 #define VVM_WRITE_LOADS(W0, ST) do { \
 		const uint32_t cnt_ = ((W0) >> 16) & 0xFFu, dst_ = (W0) >> 24; \
-		_Pragma("unroll") for (int j = 7; j >= 0; --j) REG_WRITE(((uint32_t)j < cnt_) ? dst_ + j : dst_, (ST)[j]); \
+		_Pragma("unroll") for (int j = 7; j >= 0; --j) REG_WRITE(dst_ + min((uint32_t)j, cnt_ - 1u), (ST)[j]); \
 	} while (0)
+	const void* load_ptrs = (const void*)DESC_PTR(c.dp, load_ptrs);
 	uint32_t pc0 = 0;
 	for (;; ++pc0) {
 		const uint32_t w0 = sload32(prog, pc0 * 4 + 0);
@@ -843,16 +883,15 @@ DEV void run_tile(const VvmExecDesc& d, const Ctx& c, unsigned char* lds, uint32
 	// whole register file.
 	const u64 tl1 = (dbg & 128u) ? __builtin_amdgcn_s_memtime() : 0;
 	VvmIns nxt;
-	nxt.w0 = sload32(prog, pc0 * 4 + 0); nxt.w1 = sload32(prog, pc0 * 4 + 1);
-	nxt.w2 = sload32(prog, pc0 * 4 + 2); nxt.w3 = sload32(prog, pc0 * 4 + 3);
-	uint32_t pc = pc0 + 1;
+	uint32_t pc = pc0 * (uint32_t)sizeof(VvmIns);       // byte offset of the next instruction to fetch
+	sload32x4_at(prog, pc, nxt.w0, nxt.w1, nxt.w2, nxt.w3);
+	pc += (uint32_t)sizeof(VvmIns);
 	for (;;) {
 		uint32_t op, aux, aux2, o0, o1, o2, o3, o4, o5;
 		for (;;) {
 			const VvmIns ins = nxt;
-			nxt.w0 = sload32(prog, pc * 4 + 0); nxt.w1 = sload32(prog, pc * 4 + 1);
-			nxt.w2 = sload32(prog, pc * 4 + 2); nxt.w3 = sload32(prog, pc * 4 + 3);
-			++pc;
+			sload32x4_at(prog, pc, nxt.w0, nxt.w1, nxt.w2, nxt.w3);
+			pc += (uint32_t)sizeof(VvmIns);
 			const uint32_t w0 = ins.w0;
 			op = w0 & 0xFFu; aux = (w0 >> 16) & 0xFFu; aux2 = w0 >> 24;
 			const uint32_t nin = (w0 >> 8) & 7u;
@@ -1033,13 +1072,13 @@ DEV void run_tile(const VvmExecDesc& d, const Ctx& c, unsigned char* lds, uint32
 			case VVM_OP_select_add: SETF(f_sel(A, B, C) + D);
 			case VVM_OP_sin_cos: if constexpr (FULL) { _Pragma("unroll") LANES { float sn, cs; f_sincos(A, sn, cs); r[k] = aux ? cs : sn; } } break;   // aux: 0 sine, 1 cosine
 			case VVM_OP_half_to_float: SETF(load_half(UA));             // RT.cpp:1113-1127
-			case VVM_OP_exec_index: SETI((uint32_t)d.exec_index_base + inst_i + k);                       // RT.cpp:880-900
-			case VVM_OP_exec_indexf: SETF(i2f((int32_t)((uint32_t)d.exec_index_base + inst_i + k)));      // RT.cpp:902-923
-			case VVM_OP_exec_index_addi: SETI((uint32_t)d.exec_index_base + inst_i + k + UA);             // RT.cpp:925-951
+			case VVM_OP_exec_index: SETI(DESC_U32(c.dp, exec_index_base) + inst_i + k);                       // RT.cpp:880-900
+			case VVM_OP_exec_indexf: SETF(i2f((int32_t)(DESC_U32(c.dp, exec_index_base) + inst_i + k)));      // RT.cpp:902-923
+			case VVM_OP_exec_index_addi: SETI(DESC_U32(c.dp, exec_index_base) + inst_i + k + UA);             // RT.cpp:925-951
 			// aux2 = ordinal of the random op within the script
-			case VVM_OP_random: SETF(rand01(rand_u32(d.rand_seed_lo, d.rand_seed_hi, (uint32_t)d.rand_instance_base + inst_i + k, aux2)) * A);
-			case VVM_OP_randomi: SETI(cvtt(rand01(rand_u32(d.rand_seed_lo, d.rand_seed_hi, (uint32_t)d.rand_instance_base + inst_i + k, aux2)) * i2f(IA)));
-			case VVM_OP_random_add: SETF(rand01(rand_u32(d.rand_seed_lo, d.rand_seed_hi, (uint32_t)d.rand_instance_base + inst_i + k, aux2)) * A + B);
+			case VVM_OP_random: SETF(rand01(rand_u32(DESC_U32(c.dp, rand_seed_lo), DESC_U32(c.dp, rand_seed_hi), DESC_U32(c.dp, rand_instance_base) + inst_i + k, aux2)) * A);
+			case VVM_OP_randomi: SETI(cvtt(rand01(rand_u32(DESC_U32(c.dp, rand_seed_lo), DESC_U32(c.dp, rand_seed_hi), DESC_U32(c.dp, rand_instance_base) + inst_i + k, aux2)) * i2f(IA)));
+			case VVM_OP_random_add: SETF(rand01(rand_u32(DESC_U32(c.dp, rand_seed_lo), DESC_U32(c.dp, rand_seed_hi), DESC_U32(c.dp, rand_instance_base) + inst_i + k, aux2)) * A + B);
 			case VVM_OP_external_func_call:
 				// aux = built-in id, aux2 = which output this device instruction produces (VectorVMRuntime.cpp:1450-1464 lists the
 				// operands as inputs then outputs; the linker emits one instruction per output in use)
@@ -1078,72 +1117,72 @@ DEV void run_tile(const VvmExecDesc& d, const Ctx& c, unsigned char* lds, uint32
 			for (int k = 0; k < V; ++k)
 				kb |= ((fbits(p[k]) >> 31) & ((c.inst0 + k < c.num_instances) ? 1u : 0u)) << k;
 			const uint2 rt = acquire_rank_and_publish(kb, c, lds_ctrl, status, tile_local, tag, dbg);
-			t_keep = kb; t_rank = rt.x; t_total = SCALAR(rt.y); t_dataset = aux; t_pending = true;
+			t_keep = kb; t_rank = rt.x; t_total = SCALAR(rt.y); t_pending = true;
 		}
 		// The previous tile is finished here: after this tile has published its own count (every later tile's look-back waits
 		// for that word, so it goes out first), and before this tile needs the staging slots.  The first poll of the previous
 		// tile's look-back has been in flight since this tile was claimed.
 		if (pend.active) {
-			resolve_tile<V>(pend, c, lds_ctrl, resolves, tag, error_word, dbg, pre, have_pre);
+			resolve_tile<V>(pend, c, lds_ctrl, resolves, tag, ls, dbg, pre, have_pre);
 			store_tile<V>(pend, c, lds, dbg);
 			__syncthreads();      // every thread has read its staged values: the slots may be written again
 		}
 		if (op == VVM_DOP_ACQUIRE) continue;
 		if (op == VVM_OP_done) break;
 
-		// Output instruction: aux = pair count (1..3), aux2 = dataset; sources o0..o2, destinations = output-list slots from w3.
-		// The survivors' values are compacted into an LDS staging slot; store_tile writes them out later.
-		const uint32_t total = (aux2 == t_dataset) ? t_total : 0u;    // no acquireindex for this dataset: nothing is written (VectorVMRuntime.cpp:565, 769)
-		const bool all_alive = (total == VVM_BLOCK_THREADS * V);
-		const uint32_t kind = op - VVM_DOP_OUTPUT32;          // 0: 32-bit value  1: float -> half  2: low 16 bits as they are  3: half bits -> float
-		float* stage = (float*)(lds + LDS_STAGE_OFF);
-		uint32_t* meta = (uint32_t*)(lds + LDS_STAGE_META_OFF);
-		uint64_t out_ptr[4];
-		sload64x4(c.out_list, o4 | (o5 << 16), out_ptr);      // w3 = first of the instruction's four output-list slots
+		if (op == VVM_DOP_FLUSH) {
+			// the next output instruction starts a new group of staging slots: write out the staged group now (this waits for the
+			// tile's look-back)
+			Pending cur;
+			cur.active = true; cur.unresolved = t_pending; cur.total = t_total; cur.base = t_base;
+			cur.stage_end = stage_end; cur.last = last_tile;
+			cur.tile_local = tile_local; cur.status = status; cur.out_list = c.out_list;
+			resolve_tile<V>(cur, c, lds_ctrl, resolves, tag, ls, dbg, pre, false);
+			store_tile<V>(cur, c, lds, dbg);
+			__syncthreads();      // the slots are written again right away
+			t_base = cur.base; t_pending = false; stage_end = 0;
+			continue;
+		}
+
+		// Output instruction: aux = pair count (1..3), sources o0..o2, w3 = output-list index of the first pair; the pair's staging
+		// slot is that index modulo VVM_STAGE_SLOTS.  The survivors' values are compacted into the slot; store_tile writes them
+		// out later.  Without an acquireindex before it nothing survives (VectorVMRuntime.cpp:565, 769): everything goes to
+		// the sink, and the host leaves such an output's list entry empty.
+		{
+			const bool all_alive = (t_total == VVM_BLOCK_THREADS * V);
+			const uint32_t kind = op - VVM_DOP_OUTPUT32;          // 0: 32-bit value  1: float -> half  2: low 16 bits as they are  3: half bits -> float
+			const uint32_t first_slot = o4 | (o5 << 16);
+			float* slot = (float*)(lds + LDS_STAGE_OFF) + (first_slot & (VVM_STAGE_SLOTS - 1u)) * (VVM_BLOCK_THREADS * V);
+			float* sink = (float*)(lds + LDS_STAGE_OFF) + VVM_STAGE_SLOTS * (VVM_BLOCK_THREADS * V) + c.tid;
+			uint64_t srcs = (uint64_t)o0 | ((uint64_t)o1 << 16) | ((uint64_t)o2 << 32);
+			for (uint32_t j = 0; j < aux; ++j, srcs >>= 16, slot += VVM_BLOCK_THREADS * V) {
+				float v[V];
+				fetch<V, SPILL>(RARGS, uni, c, (uint32_t)srcs & 0xFFFFu, v);
+				if (kind & 1u) {
+					if (kind == 1) {
 #pragma unroll
-		for (int j = 0; j < 3; ++j) {
-			if ((uint32_t)j >= aux) break;
-			const uint32_t src = (j == 0) ? o0 : (j == 1) ? o1 : o2;
-			const uint64_t base = out_ptr[j];
-			if (base == 0 || total == 0) continue;
-			if (n_staged == VVM_STAGE_SLOTS) {       // out of slots: write what is staged now (this waits for the look-back)
-				Pending cur;
-				cur.active = true; cur.unresolved = t_pending; cur.total = t_total; cur.base = t_base; cur.n_staged = n_staged;
-				cur.tile_local = tile_local; cur.num_tiles = d.num_tiles; cur.status = status; cur.count_out = d.counts + t_dataset;
-				resolve_tile<V>(cur, c, lds_ctrl, resolves, tag, error_word, dbg, pre, false);
-				store_tile<V>(cur, c, lds, dbg);
-				__syncthreads();      // the slots are written again right away
-				t_base = cur.base; t_pending = false; n_staged = 0;
-			}
-			float v[V];
-			fetch<V, SPILL>(RARGS, uni, c, src, v);
-			if (kind == 1) {
+						for (int k = 0; k < V; ++k) v[k] = bitsf(store_half(v[k]));
+					} else {      // outputdata_float_from_half, whose handler in the reference is an empty stub (VectorVMRuntime.cpp:573-577)
 #pragma unroll
-				for (int k = 0; k < V; ++k) v[k] = bitsf(store_half(v[k]));
-			} else if (kind == 3) {      // outputdata_float_from_half, whose handler in the reference is an empty stub (VectorVMRuntime.cpp:573-577)
+						for (int k = 0; k < V; ++k) v[k] = load_half(fbits(v[k]));
+					}
+				}
+				if (all_alive) {
+					if constexpr (V == 4) { f4a x; x.x = v[0]; x.y = v[1]; x.z = v[2]; x.w = v[3]; *(f4a*)(slot + c.tid * 4) = x; }
+					else slot[c.tid] = v[0];
+				} else {
+					// survivor j of the lane goes to rank + j; a dead instance's value goes to the thread's sink dword (no per-lane branch)
+					uint32_t r = t_rank;
 #pragma unroll
-				for (int k = 0; k < V; ++k) v[k] = load_half(fbits(v[k]));
-			}
-			float* slot = stage + n_staged * (VVM_BLOCK_THREADS * V);
-			if (all_alive) {
-				if constexpr (V == 4) { f4a x; x.x = v[0]; x.y = v[1]; x.z = v[2]; x.w = v[3]; *(f4a*)(slot + c.tid * 4) = x; }
-				else slot[c.tid] = v[0];
-			} else {
-				// survivor j of the lane goes to rank + j; a dead instance's value goes to the thread's sink dword (no per-lane branch)
-				float* sink = stage + VVM_STAGE_SLOTS * (VVM_BLOCK_THREADS * V) + c.tid;
-				uint32_t r = t_rank;
-#pragma unroll
-				for (int k = 0; k < V; ++k) {
-					const bool keep = (t_keep >> k) & 1u;
-					float* q = keep ? (slot + r) : sink;
-					*q = v[k];
-					r += keep ? 1u : 0u;
+					for (int k = 0; k < V; ++k) {
+						const bool keep = (t_keep >> k) & 1u;
+						float* q = keep ? (slot + r) : sink;
+						*q = v[k];
+						r += keep ? 1u : 0u;
+					}
 				}
 			}
-			// every thread writes the same two words: no single-lane branch needed
-			meta[2 * n_staged] = (uint32_t)base; meta[2 * n_staged + 1] = (uint32_t)(base >> 32);
-			meta[2 * VVM_STAGE_SLOTS + n_staged] = kind;
-			++n_staged;
+			stage_end = first_slot + aux;
 		}
 	}
 	if ((dbg & 128u) && c.wave == 0) {
@@ -1152,29 +1191,29 @@ DEV void run_tile(const VvmExecDesc& d, const Ctx& c, unsigned char* lds, uint32
 		st[5] = s5; st[6] = s6;
 	}
 	// hand the rest of the tile's work to the next tile's load phase
-	pend.active = (n_staged > 0) || t_pending;
-	pend.unresolved = t_pending; pend.total = t_total; pend.base = t_base; pend.n_staged = n_staged;
-	pend.tile_local = tile_local; pend.num_tiles = d.num_tiles; pend.status = status; pend.count_out = d.counts + t_dataset;
+	pend.active = (stage_end != 0) || t_pending;
+	pend.unresolved = t_pending; pend.total = t_total; pend.base = t_base; pend.stage_end = stage_end; pend.last = last_tile;
+	pend.tile_local = tile_local; pend.status = status; pend.out_list = c.out_list;
 }
 
-template <int V, bool SPILL, bool FULL>
+// DBG: the bring-up switches of KernelEnv::debug_skip are compiled in (one instantiation only); otherwise they cost nothing.
+template <int V, bool SPILL, bool FULL, bool DBG = false>
 __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (FULL ? 2 : (V == 4 ? 4 : 8))) vvm_exec_kernel(KernelEnv env)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+	const uint32_t dbgw = DBG ? env.debug_skip : 0u;
 	uint32_t* lds_ctrl = (uint32_t*)lds;
 	uint8_t* lds_perlin = lds + LDS_PERLIN_OFF;
 	float* lds_spill = (float*)(lds + LDS_SPILL_OFF(V));
 	Pending pend;
-	pend.active = false; pend.unresolved = false; pend.total = 0; pend.base = 0; pend.n_staged = 0; pend.tile_local = 0; pend.num_tiles = 0;
-	pend.status = nullptr; pend.count_out = nullptr;
+	pend.active = false; pend.unresolved = false; pend.last = false; pend.total = 0; pend.base = 0; pend.stage_end = 0; pend.tile_local = 0;
+	pend.status = nullptr; pend.out_list = nullptr;
 	const uint32_t tid = threadIdx.x;
 	const uint32_t wave = SCALAR(tid >> 6), lane = tid & 63u;
 	// ticket counter of this workgroup's class (see VvmLaunchState); with fewer workgroups than classes only the first
 	// gridDim.x counters are in use
 	const uint32_t classes = min(gridDim.x, VVM_TICKET_CLASSES);
 	const uint32_t cls = blockIdx.x % classes;
-	gu32* ticket_word = (gu32*)&env.ls->tickets[cls * (VVM_TICKET_STRIDE_BYTES / 4u)];
-	gu32* error_word = (gu32*)&env.ls->pad;
 	const uint32_t tag = SCALAR(__hip_atomic_load((gu32*)&env.ls->epoch, RLX_AGENT)) & 0x3FFFFFFFu;
 	bool perlin_ready = false;
 	uint32_t resolves = 0;
@@ -1183,21 +1222,21 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (FULL ? 2 : (V == 4 ? 4 : 8
 	// A tile is claimed when the workgroup is ready to start it, never ahead of time: the look-back of a tile waits for the
 	// counts of all earlier tiles, so a tile that is claimed but not yet running stalls every later one.
 	for (uint32_t phase = 0;; ++phase) {
-		const u64 tk0 = (env.debug_skip & 128u) ? __builtin_amdgcn_s_memtime() : 0;
+		const u64 tk0 = (dbgw & 128u) ? __builtin_amdgcn_s_memtime() : 0;
 		uint32_t* slot = lds_ctrl + LC_TICKET + (phase & 1u);
 		// Wave 0 draws the ticket and, in the shadow of that round trip, issues the first look-back poll for the tile the
 		// workgroup has just finished; the poll is examined after this tile's stream loads have been issued (resolve_tile).
 		u64 pre[VVM_LB_WORDS_PER_LANE] = {};
-		const bool have_pre = pend.active && pend.unresolved && pend.tile_local != 0 && !(env.debug_skip & (32u | 512u));
+		const bool have_pre = pend.active && pend.unresolved && pend.tile_local != 0 && !(dbgw & (32u | 512u));
 		if (wave == 0) {
-			const rsrc_t rs = make_rsrc((uint64_t)ticket_word, 4u);
+			const rsrc_t rs = make_rsrc((uint64_t)&env.ls->tickets[cls * (VVM_TICKET_STRIDE_BYTES / 4u)], 4u);
 			const int drawn = __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, rs, (int)(lane == 0 ? 0u : 4u), 0, AUX_AGENT);
 			if (have_pre) look_back_poll(pend.status, (int32_t)pend.tile_local - 1, lane, pre);
 			*slot = SCALAR(drawn);
 		}
 		__syncthreads();      // (the word alternates between tiles, so one barrier is enough)
 		const uint32_t draw = SCALAR(*slot);
-		if ((env.debug_skip & 128u) && wave == 0) {
+		if ((dbgw & 128u) && wave == 0) {
 			uint32_t* st = lds_ctrl + LC_STATS;
 			const uint32_t s4 = st[4] + (uint32_t)((__builtin_amdgcn_s_memtime() - tk0) >> 4), s7 = st[7] + 1u;
 			st[4] = s4; st[7] = s7;
@@ -1215,59 +1254,43 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (FULL ? 2 : (V == 4 ? 4 : 8
 			}
 			e = lo;
 		}
-		VvmExecDesc d;
-		{
-			const void* dp = env.descs + e;
-			d.prog = (const VvmIns*)sload64(dp, offsetof(VvmExecDesc, prog) / 8);
-			d.consts = (const uint32_t*)sload64(dp, offsetof(VvmExecDesc, consts) / 8);
-			d.in_ptrs = (const uint64_t*)sload64(dp, offsetof(VvmExecDesc, in_ptrs) / 8);
-			d.load_ptrs = (const uint64_t*)sload64(dp, offsetof(VvmExecDesc, load_ptrs) / 8);
-			d.out_list = (const uint64_t*)sload64(dp, offsetof(VvmExecDesc, out_list) / 8);
-			d.status = (unsigned long long*)sload64(dp, offsetof(VvmExecDesc, status) / 8);
-			d.counts = (int32_t*)sload64(dp, offsetof(VvmExecDesc, counts) / 8);
-			d.perlin = (const uint8_t*)sload64(dp, offsetof(VvmExecDesc, perlin) / 8);
-			d.num_instances = sload32(dp, offsetof(VvmExecDesc, num_instances) / 4);
-			d.num_tiles = sload32(dp, offsetof(VvmExecDesc, num_tiles) / 4);
-			d.first_tile = sload32(dp, offsetof(VvmExecDesc, first_tile) / 4);
-			d.exec_index_base = (int32_t)sload32(dp, offsetof(VvmExecDesc, exec_index_base) / 4);
-			d.rand_seed_lo = sload32(dp, offsetof(VvmExecDesc, rand_seed_lo) / 4);
-			d.rand_seed_hi = sload32(dp, offsetof(VvmExecDesc, rand_seed_hi) / 4);
-			d.rand_instance_base = (int32_t)sload32(dp, offsetof(VvmExecDesc, rand_instance_base) / 4);
-			d.flags = sload32(dp, offsetof(VvmExecDesc, flags) / 4);
-			d.num_unif = sload32(dp, offsetof(VvmExecDesc, num_unif) / 4);
-		}
-		const uint32_t tile_local = ticket - d.first_tile;
+		const void* dp = env.descs + e;
+		const uint32_t num_instances = DESC_U32(dp, num_instances);
+		const uint32_t tile_local = ticket - DESC_U32(dp, first_tile);
 		const uint32_t tile_first = tile_local * (VVM_BLOCK_THREADS * V);
+		const bool last_tile = (tile_local + 1u == DESC_U32(dp, num_tiles));
 
-		if (FULL && (d.flags & VVM_DESC_USES_PERLIN) && !perlin_ready) {
-			for (uint32_t i = tid; i < 512; i += VVM_BLOCK_THREADS) lds_perlin[i] = d.perlin[i];
+		if (FULL && (DESC_U32(dp, flags) & VVM_DESC_USES_PERLIN) && !perlin_ready) {
+			const uint8_t* perlin = (const uint8_t*)DESC_PTR(dp, perlin);
+			for (uint32_t i = tid; i < 512; i += VVM_BLOCK_THREADS) lds_perlin[i] = perlin[i];
 			perlin_ready = true;
 			__syncthreads();
 		}
 
 		Ctx c;
-		c.consts = d.consts; c.in_ptrs = d.in_ptrs; c.load_ptrs = d.load_ptrs; c.out_list = d.out_list;
+		c.dp = dp; c.consts = (const uint32_t*)DESC_PTR(dp, consts); c.out_list = (const uint64_t*)DESC_PTR(dp, out_list);
 		c.perlin_lds = lds_perlin; c.spill = lds_spill; c.tid = tid; c.wave = wave;
 		c.inst0 = tile_first + tid * V;
-		c.num_instances = d.num_instances;
+		c.num_instances = num_instances;
 		c.tile_first = tile_first;
-		c.valid = min(d.num_instances - tile_first, (uint32_t)(VVM_BLOCK_THREADS * V));
+		c.valid = min(num_instances - tile_first, (uint32_t)(VVM_BLOCK_THREADS * V));
 		c.phase = phase;
-		if (!(env.debug_skip & 1u)) run_tile<V, SPILL, FULL>(d, c, lds, tile_local, tag, error_word, env.debug_skip, pend, resolves, pre, have_pre);
+		if (!(dbgw & 1u))
+			run_tile<V, SPILL, FULL>((const VvmIns*)DESC_PTR(dp, prog), (gu64*)DESC_PTR(dp, status), last_tile, c, lds, tile_local, tag, env.ls, dbgw, pend, resolves, pre, have_pre);
 	}
 	if (pend.active) {
 		Ctx c;
-		c.consts = nullptr; c.in_ptrs = nullptr; c.load_ptrs = nullptr; c.out_list = nullptr; c.perlin_lds = lds_perlin; c.spill = lds_spill;
+		c.dp = nullptr; c.consts = nullptr; c.out_list = nullptr; c.perlin_lds = lds_perlin; c.spill = lds_spill;
 		c.tid = tid; c.wave = wave; c.inst0 = 0; c.num_instances = 0; c.tile_first = 0; c.valid = 0; c.phase = 0;
 		const u64 none[VVM_LB_WORDS_PER_LANE] = {};
-		resolve_tile<V>(pend, c, lds_ctrl, resolves, tag, error_word, env.debug_skip, none, false);
-		store_tile<V>(pend, c, lds, env.debug_skip);
+		resolve_tile<V>(pend, c, lds_ctrl, resolves, tag, env.ls, dbgw, none, false);
+		store_tile<V>(pend, c, lds, dbgw);
 	}
 
 	// the last workgroup to leave re-arms the launch words for the next launch
 	__syncthreads();
 	if (wave == 0) {
-		if (env.debug_skip & 128u)
+		if (dbgw & 128u)
 			for (int i = 0; i < 8; ++i) {
 				const rsrc_t rs = make_rsrc((uint64_t)&env.ls->stats[i], 8u);      // 64-bit add by the first lane
 				(void)__builtin_amdgcn_raw_ptr_buffer_atomic_add_i32((int)lds_ctrl[LC_STATS + i], rs, (int)(lane == 0 ? 0u : 8u), 0, AUX_AGENT);
@@ -1300,7 +1323,9 @@ extern "C" int vvm_launch_exec_kernel(int instances_per_lane, const VvmExecDesc*
 #define VVM_LAUNCH(V, S, F) hipLaunchKernelGGL((vvm_exec_kernel<V, S, F>), dim3(grid), dim3(VVM_BLOCK_THREADS), lds_bytes, stream, env)
 	if (instances_per_lane == 4) {
 		if (full) { if (spill) VVM_LAUNCH(4, true, true); else VVM_LAUNCH(4, false, true); }
-		else      { if (spill) VVM_LAUNCH(4, true, false); else VVM_LAUNCH(4, false, false); }
+		else if (spill) VVM_LAUNCH(4, true, false);
+		else if (env.debug_skip) hipLaunchKernelGGL((vvm_exec_kernel<4, false, false, true>), dim3(grid), dim3(VVM_BLOCK_THREADS), lds_bytes, stream, env);
+		else VVM_LAUNCH(4, false, false);
 	} else {
 		if (full) { if (spill) VVM_LAUNCH(1, true, true); else VVM_LAUNCH(1, false, true); }
 		else      { if (spill) VVM_LAUNCH(1, true, false); else VVM_LAUNCH(1, false, false); }

@@ -406,6 +406,7 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 	// issued), so the kernel fetches all eight addresses with one scalar load.  -1 pads a partly used instruction.
 	lp.load_list.clear();
 	lp.out_list.clear();
+	lp.out_is16.clear();
 	auto emit_loads = [&](const std::vector<uint32_t>& prefetch, uint32_t dop) {
 		for (size_t i = 0; i < prefetch.size(); i += 8) {
 			const size_t n = std::min<size_t>(8, prefetch.size() - i);
@@ -419,6 +420,7 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 	emit_loads(prefetch32, VVM_DOP_LOADN);
 	emit_loads(prefetch16, VVM_DOP_LOADN16);
 	uint32_t rand_ordinal = 0;
+	int acquired_dataset = -1;       // dataset of the acquireindex seen so far (a script has at most one)
 	for (const Decoded& d : ins) {
 		VvmIns k{0, 0, 0, 0};
 		switch (d.kind) {
@@ -441,6 +443,7 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 			break;
 		}
 		case K_ACQUIRE:
+			acquired_dataset = (int)d.dataset;
 			k.w0 = VVM_INS_W0(VVM_DOP_ACQUIRE, 1, 0, d.dataset, 0);
 			k.w1 = operand(d.in[0]);
 			lp.code.push_back(k);
@@ -450,19 +453,31 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 			if (d.op == VVM_OP_outputdata_half) dop = VVM_DOP_OUTPUT16;
 			else if (d.op == VVM_OP_outputdata_half_from_half) dop = VVM_DOP_OUTPUT16_FROM16;
 			else if (d.op == VVM_OP_outputdata_float_from_half) dop = VVM_DOP_OUTPUT32_FROM16;
-			for (size_t i = 0; i < d.pairs.size(); i += 3) {
-				const size_t n = std::min<size_t>(3, d.pairs.size() - i);
-				// sources in o0..o2; the destinations are four consecutive slots of the output list (-1 pads), first slot in w3
+			// An output that no acquireindex precedes, or whose dataset is not the acquired one, writes nothing
+			// (VectorVMRuntime.cpp:565, 769): its list entry stays empty.
+			const bool live = acquired_dataset >= 0 && (uint32_t)acquired_dataset == d.dataset;
+			for (size_t i = 0; i < d.pairs.size();) {
+				// sources in o0..o2; the destinations are consecutive entries of the output list, first one in w3.  The list is
+				// cut into groups of VVM_STAGE_SLOTS entries (one staging slot each); an instruction never straddles two groups,
+				// and a flush instruction separates the groups.
+				const size_t at = lp.out_list.size();
+				if (at != 0 && at % VVM_STAGE_SLOTS == 0) {
+					VvmIns f{VVM_INS_W0(VVM_DOP_FLUSH, 0, 0, 0, 0), 0, 0, 0};
+					lp.code.push_back(f);
+				}
+				const size_t n = std::min<size_t>(std::min<size_t>(3, d.pairs.size() - i), VVM_STAGE_SLOTS - at % VVM_STAGE_SLOTS);
 				uint32_t o[3] = {0, 0, 0};
-				if (lp.out_list.size() + 4 > 0xFFFFu) { err = "too many output instructions"; return VVM_E_TOO_LARGE; }
-				k.w3 = (uint32_t)lp.out_list.size();
-				for (size_t j = 0; j < 4; ++j) {
-					if (j < n) o[j] = operand(d.pairs[i + j].first);
-					lp.out_list.push_back(j < n ? (int32_t)(d.pairs[i + j].second - out0) : -1);     // output serial index
+				if (at + n > 0xFFFFu) { err = "too many outputs"; return VVM_E_TOO_LARGE; }
+				k.w3 = (uint32_t)at;
+				for (size_t j = 0; j < n; ++j) {
+					o[j] = operand(d.pairs[i + j].first);
+					lp.out_list.push_back(live ? (int32_t)(d.pairs[i + j].second - out0) : -1);      // output serial index
+					lp.out_is16.push_back(dop == VVM_DOP_OUTPUT16 || dop == VVM_DOP_OUTPUT16_FROM16);
 				}
 				k.w0 = VVM_INS_W0(dop, 0, 0, n, d.dataset);
 				k.w1 = o[0] | (o[1] << 16); k.w2 = o[2];
 				lp.code.push_back(k);
+				i += n;
 			}
 			break;
 		}

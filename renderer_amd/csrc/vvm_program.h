@@ -47,7 +47,8 @@ struct LinkedProgram {
 	uint32_t bytes_in_per_instance = 0, bytes_out_per_instance = 0;
 	uint32_t num_prefetched_inputs = 0;
 	std::vector<int32_t> load_list;    // remapped input index per load slot (8 per load instruction), -1 = unused slot
-	std::vector<int32_t> out_list;     // output serial index per output slot (4 per output instruction), -1 = unused slot
+	std::vector<int32_t> out_list;     // output serial index per output-list entry (staging order), -1 = nothing is written
+	std::vector<uint8_t> out_is16;     // per entry: the destination stream has 16-bit elements
 };
 
 // Returns VVM_OK or an error code with `err` filled.
