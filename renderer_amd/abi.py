@@ -269,6 +269,8 @@ class HipBackend(Backend):
         L.vvm_inspect_blob.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(ProgramInfo)]
         L.vvm_inspect_code.restype = C.c_int
         L.vvm_inspect_code.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_uint32), C.c_int32]
+        L.vvm_set_page_size_kb.restype = None
+        L.vvm_set_page_size_kb.argtypes = [C.c_int]
         L.vvm_device_alloc.restype = C.c_void_p
         L.vvm_device_alloc.argtypes = [C.c_size_t]
         L.vvm_device_free.restype = None
@@ -325,6 +327,10 @@ class HipBackend(Backend):
         pi = ProgramInfo()
         self._check(self.lib.vvm_inspect_blob(blob, len(blob), C.byref(pi)), "vvm_inspect_blob")
         return pi
+
+    def set_page_size_kb(self, kb: int) -> None:
+        """vm.PageSizeInKB of the reference (VectorVMRuntime.cpp:44-50); 0 restores the default of 64."""
+        self.lib.vvm_set_page_size_kb(kb)
 
     def inspect_code(self, blob: bytes, narrow: bool = False):
         """Linked device program of a blob as a list of (w0, w1, w2, w3) tuples (no device needed)."""

@@ -38,14 +38,17 @@ enum : uint32_t {
 	VVM_DOP_OUTPUT16 = 194, // up to 3 pairs of outputdata_half (float register -> half stream)
 	VVM_DOP_OUTPUT16_FROM16 = 195,
 	VVM_DOP_OUTPUT32_FROM16 = 196,
-	VVM_DOP_FLUSH = 197     // between two groups of output slots: write out what the output instructions before it have staged
+	VVM_DOP_FLUSH = 197,    // between two groups of output slots: write out what the output instructions before it have staged
+	VVM_DOP_UPDATE_ID = 198 // update_id (VectorVMRuntime.cpp:1129-1402): o0 = the ID register, w3 = its output-list entry; staged like an
+	                        // output (one slot, all instances of the tile), applied to the ID tables when the tile's position is known
 };
 
 // Output values wait in LDS staging slots until the tile's output position is known; one group of slots is written out at a time.
 #define VVM_STAGE_SLOTS 8
 // entry of VvmExecDesc::out_list: byte address in the low 48 bits (0 = nothing is written), flags above
 #define VVM_OUT_IS16 (1ull << 62)         // the destination stream has 16-bit elements
-#define VVM_OUT_GROUP16 (1ull << 61)      // on a group's first entry: some entry of the group has VVM_OUT_IS16
+#define VVM_OUT_GROUP16 (1ull << 61)      // on a group's first entry: some entry of the group has VVM_OUT_IS16 or VVM_OUT_UPDATE_ID
+#define VVM_OUT_UPDATE_ID (1ull << 60)    // the slot holds the ID register of an update_id; the address is the Exec's VvmIdDesc
 #define VVM_OUT_ADDR_MASK 0x0000FFFFFFFFFFFFull
 
 // Device instruction, 16 bytes:
@@ -57,6 +60,30 @@ struct VvmIns {
 };
 #define VVM_INS_W0(op, nin, nout, aux, aux2) \
 	((uint32_t)(op) | ((uint32_t)(nin) << 8) | ((uint32_t)(nout) << 11) | ((uint32_t)(aux) << 16) | ((uint32_t)(aux2) << 24))
+
+// Persistent-ID tables of the dataset an Exec's update_id / acquire_id works on.  Lives in device memory.
+// The reference runs an Exec chunk by chunk (VectorVMRuntime.cpp:2218-2261) and two results depend on where the chunks end:
+// update_id's MaxUsedID (the maximum over the first NumOutput entries of each chunk's ID register, :1141-1174) and the order of
+// acquire_id's spawned-ID list (each chunk's IDs are copied in front of the previous chunk's, :1425-1433).  chunk_instances is
+// that chunk size, so both come out the same here.
+struct VvmIdDesc {
+	int32_t*  id_table;          // IDTable->GetData()
+	int32_t*  free_table;        // FreeIDTable->GetData()
+	uint32_t* chunk_prefix;      // update_id: [chunk] survivors before the chunk's first instance (for the MaxUsedID pass)
+	int32_t*  id_scratch;        // update_id: [instance] the ID register, as the MaxUsedID pass reads it
+	int32_t*  max_id;            // update_id: device word that ends up holding MaxUsedID
+	const int32_t* survivors;    // update_id: the dataset's survivor count (written by the Exec's last tile)
+	uint32_t  id_table_num;      // IDTable->Num()
+	uint32_t  free_table_max;    // FreeIDTable->Max()
+	int32_t   instance_offset;
+	int32_t   num_free_start;    // *NumFreeIDs when the Exec starts
+	int32_t   num_spawned_start; // *NumSpawnedIDs when the Exec starts
+	int32_t   acquire_tag;       // IDAcquireTag
+	uint32_t  chunk_instances;   // MaxInstancesPerChunk of the reference's chunking for this Exec
+	uint32_t  num_instances;
+	uint32_t  num_chunks;
+	uint32_t  pad;
+};
 
 // One Exec (one emitter) as the kernel sees it.  Lives in device memory.
 struct VvmExecDesc {
@@ -77,7 +104,8 @@ struct VvmExecDesc {
 	int32_t  rand_instance_base;
 	uint32_t flags;
 	uint32_t num_unif;             // constants copied into the uniform register, a multiple of 4, at most VVM_MAX_UNIFORMS
-	uint32_t pad[3];
+	uint32_t pad;
+	const VvmIdDesc* ids;          // persistent-ID tables, when the script has update_id / acquire_id
 };
 
 enum : uint32_t {

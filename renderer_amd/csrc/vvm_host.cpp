@@ -6,7 +6,8 @@
 //   ext-fn table check, zero NumOutputPerDataSet   :2184-2195   -> host, before the launch
 //   VVMBuildMapTableCaches (first Exec)            :2198-2202   -> host, resolve_maps()
 //   constants broadcast                            :2204-2207   -> host packs one dword per constant, the kernel broadcasts
-//   chunking                                       :2210-2261   -> not needed (Internal.* is still filled in for callers that read it)
+//   chunking                                       :2210-2261   -> the kernel does not chunk; Internal.* is computed as the reference does, and the
+//                                                                   chunk size goes to the ID instructions, whose results depend on it
 //   SetupBatchStatePtrs                            :315-443     -> host packs stream addresses (InstanceOffset applied)
 //   chunk loop                                     :2276-2295   -> ONE kernel launch (vvm_kernels.hip)
 //   DataSetAccessIndex = count - 1                 :2305-2308   -> host, after the 4-byte-per-dataset read-back
@@ -139,6 +140,11 @@ struct vvm_state {
 	std::vector<hipEvent_t> ev_start, ev_stop;
 	size_t ev_used = 0;
 	uint32_t execs_since_status_reset = 0;
+
+	// persistent IDs (update_id / acquire_id): scratch of the MaxUsedID pass, and what the write-back after the Exec needs
+	uint32_t* d_chunk_prefix = nullptr; uint32_t chunk_capacity = 0;
+	int32_t*  d_id_scratch = nullptr;   uint32_t id_scratch_capacity = 0;
+	int32_t   id_num_free_start = 0, id_num_spawned_start = 0;
 };
 
 namespace {
@@ -193,8 +199,37 @@ struct PreparedExec {
 	const VvmIns* d_code = nullptr;
 	uint32_t tiles = 0;
 	size_t bytes = 0;           // parameter block: desc + consts + in_ptrs + out_ptrs
-	size_t off_consts = 0, off_in = 0, off_load = 0, off_out = 0;
+	size_t off_consts = 0, off_in = 0, off_load = 0, off_out = 0, off_ids = 0;
+	uint32_t chunk_instances = 0, num_chunks = 0;      // the reference's chunking of this Exec
 };
+
+int g_page_kb = 64;      // vm.PageSizeInKB, VectorVMRuntime.cpp:44-50
+
+// The reference's chunking (VectorVMRuntime.cpp:2210-2261), which also fills ctx->Internal.
+void reference_chunking(const vvm::ThawedScript& s, vvm_exec_context* ctx, uint32_t& chunk_instances, uint32_t& num_chunks)
+{
+	// fixed per-batch overhead, VectorVMRuntime.cpp:2391-2414 (sizeof(FVectorVMBatchState) = 224 on a 64-bit target, rounded up to 256)
+	const size_t num_ptr_regs = (size_t)s.num_temps + s.num_consts + 2u * (size_t)s.num_inputs + s.num_output_instructions;
+	const size_t overhead = 256 + 16u * (size_t)s.max_output_dataset + 9u * (size_t)s.max_ext_fn_registers + 16u * (size_t)s.num_dummy_regs +
+	                        9u * num_ptr_regs + 512u;
+	const size_t page = (size_t)g_page_kb << 10;
+	uint32_t total_loops = ((uint32_t)ctx->NumInstances + 3u) >> 2;
+	if (total_loops < 1) total_loops = 1;
+	const size_t per_loop = 16u * (size_t)s.num_temps + s.max_output_dataset;
+	const size_t avail = page - overhead;
+	const size_t need = (((size_t)total_loops + 3) & ~(size_t)3) * per_loop;
+	uint32_t chunks = 1, max_loops = total_loops;
+	if (avail < need) {
+		chunks = (uint32_t)((need + avail - 1) / avail);
+		max_loops = (total_loops + chunks - 1) / chunks;
+	}
+	ctx->Internal.PerBatchRegisterDataBytesRequired = (uint32_t)(max_loops * per_loop);
+	ctx->Internal.NumBytesRequiredPerBatch = (uint32_t)overhead + ctx->Internal.PerBatchRegisterDataBytesRequired;
+	ctx->Internal.MaxChunksPerBatch = chunks;
+	ctx->Internal.MaxInstancesPerChunk = max_loops << 2;
+	chunk_instances = max_loops << 2;
+	num_chunks = ((uint32_t)ctx->NumInstances + chunk_instances - 1) / chunk_instances;
+}
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) & ~(a - 1); }
 
@@ -237,8 +272,30 @@ int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, P
 	pe.off_in = align_up(pe.off_consts + 4u * (size_t)s.num_consts, 16);     // (so the table is padded to a multiple of 4 dwords)
 	pe.off_load = align_up(pe.off_in + 8u * (size_t)s.num_inputs, 64);
 	pe.off_out = align_up(pe.off_load + 8u * pe.lp->load_list.size(), 64) + 64;      // (the entry before the list is in use too)
-	pe.bytes = align_up(pe.off_out + 8u * align_up(pe.lp->out_list.size(), VVM_STAGE_SLOTS), 256);      // (the block itself is 256-byte aligned)
+	pe.off_ids = align_up(pe.off_out + 8u * align_up(pe.lp->out_list.size(), VVM_STAGE_SLOTS), 16);
+	pe.bytes = align_up(pe.off_ids + (pe.lp->uses_ids ? sizeof(VvmIdDesc) : 0), 256);      // (the block itself is 256-byte aligned)
 	(void)O;
+	reference_chunking(s, ctx, pe.chunk_instances, pe.num_chunks);
+	if (pe.lp->uses_ids) {
+		// update_id / acquire_id: the tables must be there, in device memory, and small enough for 32-bit byte offsets
+		if ((int)pe.lp->id_dataset >= ctx->DataSets.num) return fail(VVM_E_INVALID_ARG, "the script's ID instructions name a dataset the context does not provide");
+		const vvm_dataset_meta& ds = ctx->DataSets.data[pe.lp->id_dataset];
+		if (!ds.FreeIDTable || !ds.FreeIDTable->data || !ds.NumFreeIDs) return fail(VVM_E_INVALID_ARG, "the script has ID instructions but the dataset has no FreeIDTable / NumFreeIDs");
+		if (ds.FreeIDTable->max < 0 || ds.FreeIDTable->max > (1 << 29)) return fail(VVM_E_INVALID_ARG, "FreeIDTable->Max() out of range");
+		if (pe.lp->updates_ids) {
+			if (!ds.IDTable || !ds.IDTable->data || !ds.MaxUsedID) return fail(VVM_E_INVALID_ARG, "update_id needs the dataset's IDTable and MaxUsedID");
+			if (ds.IDTable->num < 0 || ds.IDTable->num > (1 << 29)) return fail(VVM_E_INVALID_ARG, "IDTable->Num() out of range");
+			if ((int64_t)*ds.NumFreeIDs + ctx->NumInstances > ds.FreeIDTable->max) return fail(VVM_E_INVALID_ARG, "FreeIDTable cannot take the IDs of every instance");
+		} else {
+			if (!ds.NumSpawnedIDs) return fail(VVM_E_INVALID_ARG, "acquire_id needs the dataset's NumSpawnedIDs");
+			if (*ds.NumFreeIDs < ctx->NumInstances) return fail(VVM_E_INVALID_ARG, "fewer free IDs than instances");              // check(), RT.cpp:1415
+			if ((int64_t)*ds.NumSpawnedIDs + ctx->NumInstances > ds.FreeIDTable->max) return fail(VVM_E_INVALID_ARG, "spawned IDs do not fit FreeIDTable");   // RT.cpp:1431
+			// the reference reads the free IDs chunk by chunk before it logs them at the end of the same table; with the two
+			// regions disjoint the order does not matter
+			if ((int64_t)*ds.NumFreeIDs > (int64_t)ds.FreeIDTable->max - *ds.NumSpawnedIDs - ctx->NumInstances)
+				return fail(VVM_E_INVALID_ARG, "the free IDs and the spawned-ID log overlap in FreeIDTable");
+		}
+	}
 	return VVM_OK;
 }
 
@@ -311,11 +368,33 @@ int fill_params(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* op
 	for (size_t k = 0; k < lp.out_list.size(); ++k) {
 		if (lp.out_is16[k]) out_list[k & ~(size_t)(VVM_STAGE_SLOTS - 1)] |= VVM_OUT_GROUP16;
 	}
-	// the reference's chunk bookkeeping has no meaning here; report one chunk that holds everything
-	ctx->Internal.NumBytesRequiredPerBatch = 0;
-	ctx->Internal.PerBatchRegisterDataBytesRequired = 0;
-	ctx->Internal.MaxChunksPerBatch = 1;
-	ctx->Internal.MaxInstancesPerChunk = ((uint32_t)ctx->NumInstances + 3u) & ~3u;
+	if (lp.uses_ids) {
+		const vvm_dataset_meta& ds = ctx->DataSets.data[lp.id_dataset];
+		VvmIdDesc* ids = (VvmIdDesc*)(host + pe.off_ids);
+		memset(ids, 0, sizeof(*ids));
+		ids->id_table = ds.IDTable ? ds.IDTable->data : nullptr;
+		ids->id_table_num = ds.IDTable ? (uint32_t)ds.IDTable->num : 0;
+		ids->free_table = ds.FreeIDTable->data;
+		ids->free_table_max = (uint32_t)ds.FreeIDTable->max;
+		ids->chunk_prefix = st->d_chunk_prefix;
+		ids->id_scratch = st->d_id_scratch;
+		const size_t ncounts = std::max<uint32_t>(s.max_output_dataset, 1);
+		ids->max_id = d->counts + ncounts;                      // the word after the survivor counts
+		ids->survivors = d->counts + lp.id_dataset;
+		ids->instance_offset = ds.InstanceOffset;
+		ids->num_free_start = *ds.NumFreeIDs;
+		ids->num_spawned_start = ds.NumSpawnedIDs ? *ds.NumSpawnedIDs : 0;
+		ids->acquire_tag = ds.IDAcquireTag;
+		ids->chunk_instances = pe.chunk_instances;
+		ids->num_instances = (uint32_t)ctx->NumInstances;
+		ids->num_chunks = pe.num_chunks;
+		d->ids = (const VvmIdDesc*)(dev + pe.off_ids);
+		for (size_t k = 0; k < lp.out_list.size(); ++k)
+			if (lp.out_list[k] == -2) {
+				out_list[k] = (uint64_t)(uintptr_t)d->ids | VVM_OUT_UPDATE_ID;
+				out_list[k & ~(size_t)(VVM_STAGE_SLOTS - 1)] |= VVM_OUT_GROUP16;
+			}
+	}
 	return VVM_OK;
 }
 
@@ -351,6 +430,8 @@ int write_back_counts(vvm_state* st, vvm_exec_context* ctx, bool ran_kernel)
 extern "C" {
 
 VVM_API const char* vvm_last_error(void) { return g_last_error.c_str(); }
+
+VVM_API void vvm_set_page_size_kb(int kb) { g_page_kb = (kb > 0 && kb <= 1 << 20) ? kb : 64; }
 
 VVM_API vvm_state* vvm_alloc_state(const uint8_t* blob, size_t num_bytes)
 {
@@ -390,6 +471,8 @@ VVM_API void vvm_free_state(vvm_state* st)
 	if (st->d_launch) (void)hipFree(st->d_launch);
 	if (st->d_status) (void)hipFree(st->d_status);
 	if (st->d_counts) (void)hipFree(st->d_counts);
+	if (st->d_chunk_prefix) (void)hipFree(st->d_chunk_prefix);
+	if (st->d_id_scratch) (void)hipFree(st->d_id_scratch);
 	if (st->h_counts) (void)hipHostFree(st->h_counts);
 	for (hipEvent_t e : st->ev_start) (void)hipEventDestroy(e);
 	for (hipEvent_t e : st->ev_stop) (void)hipEventDestroy(e);
@@ -417,6 +500,26 @@ VVM_API int vvm_exec_async(vvm_exec_context* ctx, const vvm_exec_options* opt)
 	if (rc != VVM_OK) return rc;
 	rc = st->ring.reserve(pe.bytes);
 	if (rc != VVM_OK) return rc;
+	const size_t ncounts = std::max<uint32_t>(st->script.max_output_dataset, 1);
+	if (pe.lp->uses_ids) {
+		const vvm_dataset_meta& ds = ctx->DataSets.data[pe.lp->id_dataset];
+		st->id_num_free_start = *ds.NumFreeIDs;
+		st->id_num_spawned_start = ds.NumSpawnedIDs ? *ds.NumSpawnedIDs : 0;
+		if (pe.lp->updates_ids) {
+			if (pe.num_chunks > st->chunk_capacity || (uint32_t)ctx->NumInstances > st->id_scratch_capacity) {
+				HIP_TRY(hipStreamSynchronize(stream));
+				if (st->d_chunk_prefix) HIP_TRY(hipFree(st->d_chunk_prefix));
+				if (st->d_id_scratch) HIP_TRY(hipFree(st->d_id_scratch));
+				st->chunk_capacity = pe.num_chunks + pe.num_chunks / 4 + 64;
+				st->id_scratch_capacity = (uint32_t)ctx->NumInstances + (uint32_t)ctx->NumInstances / 4 + 1024;
+				HIP_TRY(hipMalloc((void**)&st->d_chunk_prefix, (size_t)st->chunk_capacity * 4));
+				HIP_TRY(hipMalloc((void**)&st->d_id_scratch, (size_t)st->id_scratch_capacity * 4));
+			}
+			// MaxUsedID starts from the caller's value (the kernel only ever raises it, VectorVMRuntime.cpp:1383-1399)
+			st->h_counts[ncounts + 1] = *ds.MaxUsedID;
+			HIP_TRY(hipMemcpyAsync(st->d_counts + ncounts, st->h_counts + ncounts + 1, 4, hipMemcpyHostToDevice, stream));
+		}
+	}
 	int slot = 0;
 	rc = st->ring.acquire(slot);
 	if (rc != VVM_OK) return rc;
@@ -437,10 +540,13 @@ VVM_API int vvm_exec_async(vvm_exec_context* ctx, const vvm_exec_options* opt)
 	                                       pe.lp->lds_spill_slots, pe.lp->full_kernel ? 1 : 0, grid_for(pe.tiles), stream);
 	if (lrc != 0) return hip_fail((hipError_t)lrc, "kernel launch");
 	if (timed) { HIP_TRY(hipEventRecord(st->ev_stop[st->ev_used], stream)); st->ev_used++; }
+	if (pe.lp->uses_ids && pe.lp->updates_ids) {
+		const int mrc = vvm_launch_max_id_kernel((const VvmIdDesc*)(st->ring.dev[slot] + pe.off_ids), pe.num_chunks, stream);
+		if (mrc != 0) return hip_fail((hipError_t)mrc, "MaxUsedID kernel launch");
+	}
 	HIP_TRY(hipEventRecord(st->ring.done[slot], stream));
 	st->ring.pending[slot] = true;
-	const size_t ncounts = std::max<uint32_t>(st->script.max_output_dataset, 1);
-	HIP_TRY(hipMemcpyAsync(st->h_counts, st->d_counts, ncounts * 4, hipMemcpyDeviceToHost, stream));
+	HIP_TRY(hipMemcpyAsync(st->h_counts, st->d_counts, (ncounts + 1) * 4, hipMemcpyDeviceToHost, stream));     // (and the MaxUsedID word)
 	HIP_TRY(hipMemcpyAsync(st->h_counts + ncounts + 4, st->d_launch, 80, hipMemcpyDeviceToHost, stream));     // the words up to and including stats[]
 	return VVM_OK;
 }
@@ -461,6 +567,19 @@ VVM_API int vvm_exec_finish(vvm_exec_context* ctx)
 			(void)reset_launch_state(st->d_launch);
 			if (st->d_status) (void)hipMemset(st->d_status, 0, (size_t)st->status_capacity * 8);
 			return fail(VVM_E_HIP, "look-back timed out inside the kernel (a tile never published its count)");
+		}
+	}
+	if (ran && st->wide.uses_ids) {
+		// the dataset's ID counters, as the reference leaves them (VectorVMRuntime.cpp:1175, 1383-1399, 1411-1429)
+		const vvm::LinkedProgram& lp = st->wide;
+		vvm_dataset_meta& ds = ctx->DataSets.data[lp.id_dataset];
+		const size_t ncounts = std::max<uint32_t>(st->script.max_output_dataset, 1);
+		if (lp.updates_ids) {
+			*ds.NumFreeIDs = st->id_num_free_start + (ctx->NumInstances - st->h_counts[lp.id_dataset]);
+			*ds.MaxUsedID = st->h_counts[ncounts];
+		} else {
+			*ds.NumFreeIDs = st->id_num_free_start - ctx->NumInstances;
+			*ds.NumSpawnedIDs = st->id_num_spawned_start + ctx->NumInstances;
 		}
 	}
 	return write_back_counts(st, ctx, ran);
@@ -512,6 +631,7 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 		vvm_state* st = ctxs[i].VVMState;
 		if (st->in_flight && st->last_stream) { HIP_TRY(hipStreamSynchronize(st->last_stream)); st->in_flight = false; }
 		const vvm::LinkedProgram& lp = *pes[(size_t)i].lp;
+		if (lp.uses_ids) return fail(VVM_E_UNSUPPORTED_OP, "scripts with update_id / acquire_id cannot be part of a batched Exec");
 		const int key = (int)lp.instances_per_lane * 4 + (lp.lds_spill_slots ? 2 : 0) + (lp.full_kernel ? 1 : 0);
 		Group* g = nullptr;
 		for (Group& c : groups) if (c.key == key) g = &c;

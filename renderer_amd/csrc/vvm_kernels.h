@@ -9,6 +9,8 @@ extern "C" {
 // full != 0 selects the kernel that also implements the transcendental ops and the noise built-ins.
 int vvm_launch_exec_kernel(int instances_per_lane, const VvmExecDesc* descs, uint32_t num_execs, uint32_t total_tiles,
                            VvmLaunchState* ls, uint32_t lds_spill_slots, int full, uint32_t grid, hipStream_t stream);
+// update_id's MaxUsedID pass over an Exec that has run (same stream).
+int vvm_launch_max_id_kernel(const VvmIdDesc* ids, uint32_t num_chunks, hipStream_t stream);
 int vvm_kernel_max_dynamic_lds(void);
 uint32_t vvm_kernel_resident_registers(int instances_per_lane);
 uint32_t vvm_kernel_lds_fixed_bytes(int instances_per_lane);

@@ -88,12 +88,15 @@ template <typename VEC> __device__ __forceinline__ VEC vset(VEC v, uint32_t i, f
 //   [0, 256)      control words (uint32), see the LC_ constants
 //   [256, 768)    Perlin permutation table
 //   [768, 896)    unused
-//   [896, ...)    output staging: VVM_STAGE_SLOTS slots of one tile's worth of 32-bit values, then one sink dword per thread
+//   [896, ...)    output staging: VVM_STAGE_SLOTS slots of one tile's worth of 32-bit values, then one sink dword per thread,
+//                 then one dword per thread with the lane's acquireindex result (kept for update_id)
 //   then          register spill slots
 #define LDS_PERLIN_OFF      256
 #define LDS_STAGE_META_OFF  768
 #define LDS_STAGE_OFF       896
-#define LDS_STAGE_BYTES(V)  (VVM_STAGE_SLOTS * VVM_BLOCK_THREADS * (V) * 4u + VVM_BLOCK_THREADS * 4u)
+#define LDS_STAGE_SINK_OFF(V) (LDS_STAGE_OFF + VVM_STAGE_SLOTS * VVM_BLOCK_THREADS * (V) * 4u)
+#define LDS_STAGE_KEEP_OFF(V) (LDS_STAGE_SINK_OFF(V) + VVM_BLOCK_THREADS * 4u)
+#define LDS_STAGE_BYTES(V)  (VVM_STAGE_SLOTS * VVM_BLOCK_THREADS * (V) * 4u + 2u * VVM_BLOCK_THREADS * 4u)
 #define LDS_SPILL_OFF(V)    (LDS_STAGE_OFF + LDS_STAGE_BYTES(V))
 
 DEV uint32_t fbits(float f) { return __float_as_uint(f); }
@@ -720,9 +723,62 @@ template <int V> DEV void resolve_tile(Pending& p, const Ctx& c, uint32_t* lds_c
 // One staging slot to its destination: entry `e` of the output list, 32-bit values at src[0..V).  off4 = 4 * base and
 // rec4 = 4 * total come from the caller (the same for every slot).  Elements at and past `total` are dropped by the bounds
 // check; so is everything when the entry has no destination.
-template <int V, bool ANY16> DEV void store_slot(uint64_t e, const float* q, uint32_t i0, uint64_t off4, uint32_t rec4)
+#define VVM_RSRC_NOWHERE 0xFFFFFFF0u      // a byte offset past the end of every descriptor used here: the access is dropped
+
+// update_id for one tile (VectorVMRuntime.cpp:1175-1380), run when the tile's output position `base` is known.
+//   q[0..V)  the lane's ID-register values; kw = the lane's acquireindex result: rank[0:16) keep[16:24) exists[24:32)
+//   survivor:  IDTable[id] = InstanceOffset + its output index            (:1191-1193 and the per-mask cases)
+//   dead:      FreeIDTable[NumFreeIDs at start + number of dead instances before it] = id
+// The reference appends each chunk's freed IDs in instance order and the chunks in order (:1175, 1181), which is the order
+// of the dead instances of the whole Exec.  For the later MaxUsedID pass: the ID of every instance, and the number of
+// survivors before each instance that starts one of the reference's chunks.
+template <int V> DEV void apply_update_id(const void* idp, const float* q, uint32_t kw, uint32_t first_instance, uint32_t base)
 {
+#define IDF_U32(field) sload32(idp, offsetof(VvmIdDesc, field) / 4)
+#define IDF_PTR(field) sload64(idp, offsetof(VvmIdDesc, field) / 8)
+	const uint32_t id_table_num = IDF_U32(id_table_num);
+	const rsrc_t rs_ids = make_rsrc(IDF_PTR(id_table), 4u * id_table_num);
+	const rsrc_t rs_free = make_rsrc(IDF_PTR(free_table), 4u * IDF_U32(free_table_max));
+	const rsrc_t rs_prefix = make_rsrc(IDF_PTR(chunk_prefix), 4u * IDF_U32(num_chunks));
+	const rsrc_t rs_scratch = make_rsrc(IDF_PTR(id_scratch), 4u * IDF_U32(num_instances));
+	const uint32_t instance_offset = IDF_U32(instance_offset), num_free_start = IDF_U32(num_free_start), chunk = IDF_U32(chunk_instances);
+	const uint32_t rank = kw & 0xFFFFu, keep = (kw >> 16) & 0xFFu, exists = kw >> 24;
+#pragma unroll
+	for (int k = 0; k < V; ++k) {
+		const uint32_t id = fbits(q[k]);
+		const uint32_t g = first_instance + (uint32_t)k;
+		// (bitwise combinations of the per-lane conditions: a short-circuit would become a per-lane branch)
+		const uint32_t ok = (exists >> k) & 1u, alive = (keep >> k) & 1u;
+		const uint32_t before = base + rank + (uint32_t)__popc(keep & ((1u << k) - 1u));     // survivors before this instance
+		__builtin_amdgcn_raw_buffer_store_b32(instance_offset + before, rs_ids, (int)((ok & alive & (uint32_t)(id < id_table_num)) ? id * 4u : VVM_RSRC_NOWHERE), 0, 0);
+		__builtin_amdgcn_raw_buffer_store_b32(id, rs_free, (int)((ok & (alive ^ 1u)) ? (num_free_start + g - before) * 4u : VVM_RSRC_NOWHERE), 0, 0);
+		uint32_t ci = g / chunk;
+		asm volatile("" : "+v"(ci));          // computed for every lane, then selected: otherwise the division ends up behind a per-lane branch
+		__builtin_amdgcn_raw_buffer_store_b32(before, rs_prefix, (int)((ok & (uint32_t)(g == ci * chunk)) ? ci * 4u : VVM_RSRC_NOWHERE), 0, 0);
+		__builtin_amdgcn_raw_buffer_store_b32(id, rs_scratch, (int)(g * 4u), 0, 0);          // (past the last instance: dropped)
+	}
+#undef IDF_U32
+#undef IDF_PTR
+}
+
+struct StoreArgs {
+	uint32_t i0;               // the thread's first element within the tile
+	uint64_t off4;             // 4 * base
+	uint32_t rec4;             // 4 * total
+	uint32_t base, tile_first; // for update_id
+	const uint32_t* keep_word; // the thread's acquireindex result in LDS
+};
+// LAST: the group's last slot, the only one that can hold an update_id (only the FULL kernels run scripts with ID instructions)
+template <int V, bool ANY16, bool LAST> DEV void store_slot(uint64_t e, const float* q, const StoreArgs& a)
+{
+	const uint32_t i0 = a.i0;
+	const uint64_t off4 = a.off4;
+	const uint32_t rec4 = a.rec4;
 	const uint64_t ptr = e & VVM_OUT_ADDR_MASK;
+	if (ANY16 && LAST && (e & VVM_OUT_UPDATE_ID)) {
+		apply_update_id<V>((const void*)ptr, q, *a.keep_word, a.tile_first + i0, a.base);
+		return;
+	}
 	if (ANY16 && (e & VVM_OUT_IS16)) {       // 16-bit destination, the staged value holds the bits
 		const rsrc_t rs = make_rsrc(ptr + (off4 >> 1), ptr ? (rec4 >> 1) : 0u);
 #pragma unroll
@@ -739,10 +795,10 @@ template <int V, bool ANY16> DEV void store_slot(uint64_t e, const float* q, uin
 		__builtin_amdgcn_raw_buffer_store_b32(fbits(q[0]), rs, (int)(i0 * 4u), 0, AUX_STREAM);
 	}
 }
-template <int V, bool ANY16> DEV void store_slots(const uint64_t (&entry)[VVM_STAGE_SLOTS], uint32_t n, const float* src, uint32_t i0, uint64_t off4, uint32_t rec4)
+template <int V, bool ANY16, bool FULL> DEV void store_slots(const uint64_t (&entry)[VVM_STAGE_SLOTS], uint32_t n, const float* src, const StoreArgs& a)
 {
 	// the staged slots are 0 .. n-1: enter the chain at slot n-1 and fall through to slot 0 (no per-slot loop test)
-#define VVM_SLOT(s) store_slot<V, ANY16>(entry[s], src + (s) * (VVM_BLOCK_THREADS * V), i0, off4, rec4)
+#define VVM_SLOT(s) store_slot<V, ANY16, FULL && (s) == VVM_STAGE_SLOTS - 1>(entry[s], src + (s) * (VVM_BLOCK_THREADS * V), a)
 	switch (n) {
 	case 8: VVM_SLOT(7); [[fallthrough]];
 	case 7: VVM_SLOT(6); [[fallthrough]];
@@ -756,7 +812,7 @@ template <int V, bool ANY16> DEV void store_slots(const uint64_t (&entry)[VVM_ST
 	}
 #undef VVM_SLOT
 }
-template <int V> DEV void store_tile(Pending& p, const Ctx& c, unsigned char* lds, uint32_t dbg)
+template <int V, bool FULL> DEV void store_tile(Pending& p, const Ctx& c, unsigned char* lds, uint32_t dbg)
 {
 	static_assert(VVM_STAGE_SLOTS == 8, "store_slots is written for eight slots");
 	const uint32_t n_staged = STAGED_COUNT(p.stage_end);
@@ -764,12 +820,12 @@ template <int V> DEV void store_tile(Pending& p, const Ctx& c, unsigned char* ld
 		// slot s holds the values for entry first + s of the Exec's output list: all eight entries arrive with one scalar load
 		uint64_t entry[VVM_STAGE_SLOTS];
 		sload64x8(p.out_list, STAGED_FIRST(p.stage_end), entry);
-		const uint32_t i0 = c.tid * V;
-		const float* src = (const float*)(lds + LDS_STAGE_OFF) + i0;
-		const uint64_t off4 = 4ull * p.base;
-		const uint32_t rec4 = 4u * p.total;
-		if (entry[0] & VVM_OUT_GROUP16) store_slots<V, true>(entry, n_staged, src, i0, off4, rec4);
-		else store_slots<V, false>(entry, n_staged, src, i0, off4, rec4);
+		StoreArgs a;
+		a.i0 = c.tid * V; a.off4 = 4ull * p.base; a.rec4 = 4u * p.total; a.base = p.base; a.tile_first = p.tile_local * (VVM_BLOCK_THREADS * V);
+		a.keep_word = (const uint32_t*)(lds + LDS_STAGE_KEEP_OFF(V)) + c.tid;
+		const float* src = (const float*)(lds + LDS_STAGE_OFF) + a.i0;
+		if (entry[0] & VVM_OUT_GROUP16) store_slots<V, true, FULL>(entry, n_staged, src, a);
+		else store_slots<V, false, FULL>(entry, n_staged, src, a);
 	}
 	p.stage_end = 0;
 	p.active = false;
@@ -1078,6 +1134,33 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 			// aux2 = ordinal of the random op within the script
 			case VVM_OP_random: SETF(rand01(rand_u32(DESC_U32(c.dp, rand_seed_lo), DESC_U32(c.dp, rand_seed_hi), DESC_U32(c.dp, rand_instance_base) + inst_i + k, aux2)) * A);
 			case VVM_OP_randomi: SETI(cvtt(rand01(rand_u32(DESC_U32(c.dp, rand_seed_lo), DESC_U32(c.dp, rand_seed_hi), DESC_U32(c.dp, rand_instance_base) + inst_i + k, aux2)) * i2f(IA)));
+			case VVM_OP_acquire_id: if constexpr (FULL) {
+				// VectorVMRuntime.cpp:1404-1440.  Instance g of the Exec takes FreeIDTable[NumFreeIDs - 1 - g]: each chunk pops its
+				// IDs from the end of the free list, reversed (:1417-1421), and the chunks pop in order.  The IDs are also logged as
+				// spawned: chunk c's, in instance order, at FreeIDTable[Max - (NumSpawnedIDs + instances up to the end of chunk c)]
+				// (:1429-1432).  aux 1 is the instruction's second destination, the tag (:1435).
+				const void* idp = (const void*)DESC_PTR(c.dp, ids);
+				if (aux == 1) {
+					const uint32_t tag_value = sload32(idp, offsetof(VvmIdDesc, acquire_tag) / 4);
+					_Pragma("unroll") LANES r[k] = bitsf(tag_value);
+				} else {
+					const uint32_t table_max = sload32(idp, offsetof(VvmIdDesc, free_table_max) / 4);
+					const rsrc_t rs_free = make_rsrc(sload64(idp, offsetof(VvmIdDesc, free_table) / 8), 4u * table_max);
+					const uint32_t num_free = sload32(idp, offsetof(VvmIdDesc, num_free_start) / 4), num_spawned = sload32(idp, offsetof(VvmIdDesc, num_spawned_start) / 4);
+					const uint32_t chunk = sload32(idp, offsetof(VvmIdDesc, chunk_instances) / 4);
+					_Pragma("unroll") LANES {
+						const uint32_t g = inst_i + (uint32_t)k;
+						const uint32_t ok = (uint32_t)(g < c.num_instances) & (uint32_t)(g < num_free);
+						const uint32_t id = __builtin_amdgcn_raw_buffer_load_b32(rs_free, (int)(ok ? (num_free - 1u - g) * 4u : VVM_RSRC_NOWHERE), 0, 0);
+						const uint32_t ci = g / chunk;
+						const uint32_t chunk_end = min(c.num_instances, (ci + 1u) * chunk);
+						uint32_t pos = table_max - (num_spawned + chunk_end) + (g - ci * chunk);
+						asm volatile("" : "+v"(pos));      // computed for every lane, then selected: otherwise the division ends up behind a per-lane branch
+						__builtin_amdgcn_raw_buffer_store_b32(id, rs_free, (int)(ok ? pos * 4u : VVM_RSRC_NOWHERE), 0, 0);
+						r[k] = bitsf(id);
+					}
+				}
+			} break;
 			case VVM_OP_random_add: SETF(rand01(rand_u32(DESC_U32(c.dp, rand_seed_lo), DESC_U32(c.dp, rand_seed_hi), DESC_U32(c.dp, rand_instance_base) + inst_i + k, aux2)) * A + B);
 			case VVM_OP_external_func_call:
 				// aux = built-in id, aux2 = which output this device instruction produces (VectorVMRuntime.cpp:1450-1464 lists the
@@ -1124,7 +1207,7 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 		// tile's look-back has been in flight since this tile was claimed.
 		if (pend.active) {
 			resolve_tile<V>(pend, c, lds_ctrl, resolves, tag, ls, dbg, pre, have_pre);
-			store_tile<V>(pend, c, lds, dbg);
+			store_tile<V, FULL>(pend, c, lds, dbg);
 			__syncthreads();      // every thread has read its staged values: the slots may be written again
 		}
 		if (op == VVM_DOP_ACQUIRE) continue;
@@ -1138,9 +1221,26 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 			cur.stage_end = stage_end; cur.last = last_tile;
 			cur.tile_local = tile_local; cur.status = status; cur.out_list = c.out_list;
 			resolve_tile<V>(cur, c, lds_ctrl, resolves, tag, ls, dbg, pre, false);
-			store_tile<V>(cur, c, lds, dbg);
+			store_tile<V, FULL>(cur, c, lds, dbg);
 			__syncthreads();      // the slots are written again right away
 			t_base = cur.base; t_pending = false; stage_end = 0;
+			continue;
+		}
+
+		if (FULL && op == VVM_DOP_UPDATE_ID) {
+			// the ID register of every instance of the tile goes to a staging slot as it is, with the lane's acquireindex result
+			// next to it; apply_update_id does the rest once the tile's output position is known
+			const uint32_t slot_index = o4 | (o5 << 16);
+			float v[V];
+			fetch<V, SPILL>(RARGS, uni, c, o0, v);
+			float* slot = (float*)(lds + LDS_STAGE_OFF) + (slot_index & (VVM_STAGE_SLOTS - 1u)) * (VVM_BLOCK_THREADS * V) + c.tid * V;
+			if constexpr (V == 4) { f4a x; x.x = v[0]; x.y = v[1]; x.z = v[2]; x.w = v[3]; *(f4a*)slot = x; }
+			else slot[0] = v[0];
+			uint32_t exists = 0;
+#pragma unroll
+			for (int k = 0; k < V; ++k) exists |= ((c.inst0 + k < c.num_instances) ? 1u : 0u) << k;
+			((uint32_t*)(lds + LDS_STAGE_KEEP_OFF(V)))[c.tid] = t_rank | (t_keep << 16) | (exists << 24);
+			stage_end = max(stage_end, slot_index + 1u);      // (the group's last slot: outputs staged after this one lie below it)
 			continue;
 		}
 
@@ -1153,7 +1253,7 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 			const uint32_t kind = op - VVM_DOP_OUTPUT32;          // 0: 32-bit value  1: float -> half  2: low 16 bits as they are  3: half bits -> float
 			const uint32_t first_slot = o4 | (o5 << 16);
 			float* slot = (float*)(lds + LDS_STAGE_OFF) + (first_slot & (VVM_STAGE_SLOTS - 1u)) * (VVM_BLOCK_THREADS * V);
-			float* sink = (float*)(lds + LDS_STAGE_OFF) + VVM_STAGE_SLOTS * (VVM_BLOCK_THREADS * V) + c.tid;
+			float* sink = (float*)(lds + LDS_STAGE_SINK_OFF(V)) + c.tid;
 			uint64_t srcs = (uint64_t)o0 | ((uint64_t)o1 << 16) | ((uint64_t)o2 << 32);
 			for (uint32_t j = 0; j < aux; ++j, srcs >>= 16, slot += VVM_BLOCK_THREADS * V) {
 				float v[V];
@@ -1182,7 +1282,7 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 					}
 				}
 			}
-			stage_end = first_slot + aux;
+			stage_end = max(stage_end, first_slot + aux);
 		}
 	}
 	if ((dbg & 128u) && c.wave == 0) {
@@ -1198,7 +1298,7 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 
 // DBG: the bring-up switches of KernelEnv::debug_skip are compiled in (one instantiation only); otherwise they cost nothing.
 template <int V, bool SPILL, bool FULL, bool DBG = false>
-__global__ void __launch_bounds__(VVM_BLOCK_THREADS, (FULL ? 2 : (V == 4 ? 4 : 8))) vvm_exec_kernel(KernelEnv env)
+__global__ void __launch_bounds__(VVM_BLOCK_THREADS, (FULL ? 3 : (V == 4 ? 4 : 8))) vvm_exec_kernel(KernelEnv env)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	const uint32_t dbgw = DBG ? env.debug_skip : 0u;
@@ -1284,7 +1384,7 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (FULL ? 2 : (V == 4 ? 4 : 8
 		c.tid = tid; c.wave = wave; c.inst0 = 0; c.num_instances = 0; c.tile_first = 0; c.valid = 0; c.phase = 0;
 		const u64 none[VVM_LB_WORDS_PER_LANE] = {};
 		resolve_tile<V>(pend, c, lds_ctrl, resolves, tag, env.ls, dbgw, none, false);
-		store_tile<V>(pend, c, lds, dbgw);
+		store_tile<V, FULL>(pend, c, lds, dbgw);
 	}
 
 	// the last workgroup to leave re-arms the launch words for the next launch
@@ -1305,6 +1405,31 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (FULL ? 2 : (V == 4 ? 4 : 8
 				__hip_atomic_store((gu32*)&env.ls->tickets[x * (VVM_TICKET_STRIDE_BYTES / 4u)], 0u, RLX_AGENT);
 		}
 	}
+}
+
+// update_id's MaxUsedID (VectorVMRuntime.cpp:1141-1174, 1383-1399), run after the Exec: per chunk of the reference's chunking,
+// the maximum over the first NumOutput entries of the chunk's ID register, NumOutput = the chunk's survivors.  (Not the IDs of
+// the survivors: the register is not compacted.  Reproduced as it is.)
+__global__ void __launch_bounds__(256) vvm_max_id_kernel(const VvmIdDesc* idp)
+{
+	const VvmIdDesc d = *idp;
+	const uint32_t total = (uint32_t)*d.survivors;
+	int32_t m = -1;
+	for (uint32_t ci = blockIdx.x; ci < d.num_chunks; ci += gridDim.x) {
+		const uint32_t start = d.chunk_prefix[ci];
+		const uint32_t end = (ci + 1u < d.num_chunks) ? d.chunk_prefix[ci + 1u] : total;
+		const uint32_t first = ci * d.chunk_instances;
+		for (uint32_t j = threadIdx.x; j < end - start; j += blockDim.x) m = max(m, d.id_scratch[first + j]);
+	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+	if ((threadIdx.x & 63u) == 0 && m != -1) atomicMax(d.max_id, m);
+}
+extern "C" int vvm_launch_max_id_kernel(const VvmIdDesc* idp, uint32_t num_chunks, hipStream_t stream)
+{
+	const uint32_t grid = num_chunks < 1024u ? (num_chunks ? num_chunks : 1u) : 1024u;
+	hipLaunchKernelGGL(vvm_max_id_kernel, dim3(grid), dim3(256), 0, stream, idp);
+	return (int)hipGetLastError();
 }
 
 // ---- host-callable launcher --------------------------------------------------------------------------

@@ -264,7 +264,18 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 		for (uint16_t r : d.out) if (!reg_class_ok(r)) { err = "register index out of range"; return VVM_E_BAD_BLOB; }
 		if (g_ops[d.op].heavy) heavy = true;
 		if (d.kind == K_EXTFN) uses_perlin = true;
-		if (d.kind == K_IDS) lp.uses_ids = true;
+		if (d.kind == K_IDS) {
+			// One dataset's ID tables per script, and one direction: update_id returns IDs to the free list that acquire_id takes them
+			// from, chunk by chunk in the reference (VectorVMRuntime.cpp:1175, 1411-1423), so a script that does both to one dataset
+			// depends on the reference's chunk order.
+			const bool upd = d.op == VVM_OP_update_id;
+			if (lp.uses_ids && (lp.id_dataset != d.dataset || lp.updates_ids != upd)) {
+				err = "update_id and acquire_id in one script, or on more than one dataset, are not supported by the GPU executor";
+				return VVM_E_UNSUPPORTED_OP;
+			}
+			if (lp.uses_ids && upd) { err = "more than one update_id in a script is not supported by the GPU executor"; return VVM_E_UNSUPPORTED_OP; }
+			lp.uses_ids = true; lp.updates_ids = upd; lp.id_dataset = d.dataset;
+		}
 		if (d.kind == K_OUTPUT) {
 			for (auto& p : d.pairs) {
 				if (!reg_class_ok(p.first) || p.second < out0 || p.second >= out0 + O) { err = "output operand out of range"; return VVM_E_BAD_BLOB; }
@@ -302,7 +313,10 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 	}
 	const uint32_t scratch0 = nv;
 	for (uint32_t i = 0; i < max_scratch; ++i) { ++nv; vreg_uses.push_back(1); }
-	if (lp.uses_ids) { err = "update_id / acquire_id are not implemented by the GPU executor yet"; return VVM_E_UNSUPPORTED_OP; }
+	if (lp.uses_ids && lp.updates_ids && !(lp.id_dataset < lp.acquires_dataset.size() && lp.acquires_dataset[lp.id_dataset])) {
+		err = "update_id on a dataset the script has no acquireindex for";       // it walks that dataset's keep mask (VectorVMRuntime.cpp:1178)
+		return VVM_E_UNSUPPORTED_OP;
+	}
 	uint32_t acquired = 0;
 	for (uint8_t a : lp.acquires_dataset) acquired += a;
 	if (acquired > 1) { err = "acquireindex on more than one dataset in one script is not supported by the GPU executor"; return VVM_E_UNSUPPORTED_OP; }
@@ -356,7 +370,7 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 	lp.instances_per_lane = V;
 	lp.resident_regs = RV;
 	lp.lds_spill_slots = next_vreg > RV ? next_vreg - RV : 0;
-	lp.full_kernel = heavy;
+	lp.full_kernel = heavy || lp.uses_ids;      // (the ID instructions are compiled into the full kernels only)
 	lp.uses_perlin = uses_perlin;
 
 	auto operand = [&](uint16_t r) -> uint32_t {
@@ -421,6 +435,25 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 	emit_loads(prefetch16, VVM_DOP_LOADN16);
 	uint32_t rand_ordinal = 0;
 	int acquired_dataset = -1;       // dataset of the acquireindex seen so far (a script has at most one)
+	// The output list is cut into groups of VVM_STAGE_SLOTS entries (one staging slot each).  An output instruction never
+	// straddles two groups, and a flush instruction precedes the first instruction that stages into a new group.  When the
+	// script has an update_id, the last entry of every group is kept for it (-1 where it is not used).
+	const size_t group_capacity = lp.updates_ids ? VVM_STAGE_SLOTS - 1 : VVM_STAGE_SLOTS;
+	size_t out_cursor = 0;           // next free entry
+	size_t open_group = 0;           // group the instructions emitted so far stage into
+	auto open_slot = [&]() -> size_t {
+		if (out_cursor % VVM_STAGE_SLOTS == group_capacity) out_cursor = (out_cursor / VVM_STAGE_SLOTS + 1) * VVM_STAGE_SLOTS;
+		const size_t group = out_cursor / VVM_STAGE_SLOTS;
+		if (group != open_group) {
+			lp.code.push_back(VvmIns{VVM_INS_W0(VVM_DOP_FLUSH, 0, 0, 0, 0), 0, 0, 0});
+			open_group = group;
+		}
+		if (lp.out_list.size() < (group + 1) * VVM_STAGE_SLOTS) {
+			lp.out_list.resize((group + 1) * VVM_STAGE_SLOTS, -1);
+			lp.out_is16.resize((group + 1) * VVM_STAGE_SLOTS, 0);
+		}
+		return out_cursor;
+	};
 	for (const Decoded& d : ins) {
 		VvmIns k{0, 0, 0, 0};
 		switch (d.kind) {
@@ -457,23 +490,18 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 			// (VectorVMRuntime.cpp:565, 769): its list entry stays empty.
 			const bool live = acquired_dataset >= 0 && (uint32_t)acquired_dataset == d.dataset;
 			for (size_t i = 0; i < d.pairs.size();) {
-				// sources in o0..o2; the destinations are consecutive entries of the output list, first one in w3.  The list is
-				// cut into groups of VVM_STAGE_SLOTS entries (one staging slot each); an instruction never straddles two groups,
-				// and a flush instruction separates the groups.
-				const size_t at = lp.out_list.size();
-				if (at != 0 && at % VVM_STAGE_SLOTS == 0) {
-					VvmIns f{VVM_INS_W0(VVM_DOP_FLUSH, 0, 0, 0, 0), 0, 0, 0};
-					lp.code.push_back(f);
-				}
-				const size_t n = std::min<size_t>(std::min<size_t>(3, d.pairs.size() - i), VVM_STAGE_SLOTS - at % VVM_STAGE_SLOTS);
+				// sources in o0..o2; the destinations are consecutive entries of the output list, first one in w3
+				const size_t at = open_slot();
+				const size_t n = std::min<size_t>(std::min<size_t>(3, d.pairs.size() - i), group_capacity - at % VVM_STAGE_SLOTS);
 				uint32_t o[3] = {0, 0, 0};
 				if (at + n > 0xFFFFu) { err = "too many outputs"; return VVM_E_TOO_LARGE; }
 				k.w3 = (uint32_t)at;
 				for (size_t j = 0; j < n; ++j) {
 					o[j] = operand(d.pairs[i + j].first);
-					lp.out_list.push_back(live ? (int32_t)(d.pairs[i + j].second - out0) : -1);      // output serial index
-					lp.out_is16.push_back(dop == VVM_DOP_OUTPUT16 || dop == VVM_DOP_OUTPUT16_FROM16);
+					lp.out_list[at + j] = live ? (int32_t)(d.pairs[i + j].second - out0) : -1;      // output serial index
+					lp.out_is16[at + j] = (dop == VVM_DOP_OUTPUT16 || dop == VVM_DOP_OUTPUT16_FROM16);
 				}
+				out_cursor = at + n;
 				k.w0 = VVM_INS_W0(dop, 0, 0, n, d.dataset);
 				k.w1 = o[0] | (o[1] << 16); k.w2 = o[2];
 				lp.code.push_back(k);
@@ -500,6 +528,32 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 				outs.push_back(SplitOut{d.out[(size_t)i], VVM_INS_W0(VVM_OP_external_func_call, 3, 1, no == 1 ? VVM_EXTFN_PERLIN3 : VVM_EXTFN_CURL_NOISE3, i)});
 			}
 			emit_split(d, outs, o);
+			break;
+		}
+		case K_IDS: {
+			if (d.op == VVM_OP_update_id) {
+				// staged like an output: one entry of the output list, one staging slot (in[1], the tag register, is not read:
+				// VectorVMRuntime.cpp:1133 only loads its address)
+				if (acquired_dataset < 0 || (uint32_t)acquired_dataset != d.dataset) { err = "update_id before the dataset's acquireindex"; return VVM_E_UNSUPPORTED_OP; }
+				// its entry is always the last one of the group that is open (the kernel handles it in that slot only)
+				const size_t at = open_group * VVM_STAGE_SLOTS + (VVM_STAGE_SLOTS - 1);
+				if (at + 1 > 0xFFFFu) { err = "too many outputs"; return VVM_E_TOO_LARGE; }
+				if (lp.out_list.size() < at + 1) { lp.out_list.resize(at + 1, -1); lp.out_is16.resize(at + 1, 0); }
+				lp.out_list[at] = -2;
+				k.w0 = VVM_INS_W0(VVM_DOP_UPDATE_ID, 0, 0, 1, d.dataset);
+				k.w1 = operand(d.in[0]); k.w2 = 0; k.w3 = (uint32_t)at;
+				lp.code.push_back(k);
+			} else {
+				// acquire_id: two destinations (ID, tag), no inputs; aux selects which
+				uint32_t o[6] = {0, 0, 0, 0, 0, 0};
+				std::vector<SplitOut> outs;
+				for (size_t i = 0; i < 2; ++i) {
+					if (d.out[i] == VVM_INVALID_REG) continue;
+					if (VVM_OPND_CLS(operand(d.out[i])) != VVM_OPC_VREG) { err = "an acquire_id destination is not a temp or output register"; return VVM_E_BAD_BLOB; }
+					outs.push_back(SplitOut{d.out[i], VVM_INS_W0(VVM_OP_acquire_id, 0, 1, i, d.dataset)});
+				}
+				emit_split(d, outs, o);
+			}
 			break;
 		}
 		default: break;

@@ -42,12 +42,15 @@ struct LinkedProgram {
 	uint32_t lds_spill_slots = 0;
 	bool     full_kernel = false;      // needs the transcendental / noise kernel
 	bool     uses_perlin = false;
-	bool     uses_ids = false;
+	bool     uses_ids = false;         // update_id or acquire_id ...
+	bool     updates_ids = false;      // ... which of the two
+	uint32_t id_dataset = 0;           // ... and the dataset whose ID tables it works on
 	std::vector<uint8_t> acquires_dataset;   // per output dataset: the script runs acquireindex for it
 	uint32_t bytes_in_per_instance = 0, bytes_out_per_instance = 0;
 	uint32_t num_prefetched_inputs = 0;
 	std::vector<int32_t> load_list;    // remapped input index per load slot (8 per load instruction), -1 = unused slot
-	std::vector<int32_t> out_list;     // output serial index per output-list entry (staging order), -1 = nothing is written
+	std::vector<int32_t> out_list;     // output serial index per output-list entry (staging order), -1 = nothing is written,
+	                                   // -2 = the ID register of update_id
 	std::vector<uint8_t> out_is16;     // per entry: the destination stream has 16-bit elements
 };
 

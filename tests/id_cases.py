@@ -1,0 +1,84 @@
+"""Scripts with the persistent-ID instructions, and a second statement of what they do, in numpy
+(VectorVMRuntime.cpp:1129-1440), shared by the oracle tests (CPU) and the parity tests (GPU).
+
+Two results of these instructions depend on the reference's chunking (VectorVMRuntime.cpp:2218-2261), so the numpy
+statement takes the chunk size:
+  * update_id raises MaxUsedID to the maximum over the FIRST NumOutput entries of each chunk's ID register, NumOutput
+    being the chunk's survivor count -- not over the survivors' IDs (:1141-1174);
+  * acquire_id logs each chunk's IDs in front of the previous chunk's at the end of FreeIDTable (:1425-1433).
+"""
+import struct
+
+import numpy as np
+
+from renderer_amd.assembler import FLOAT, INT32, Script
+from vm_harness import IdState
+
+
+def update_script(extra_outputs: int = 0, id_from_temp: bool = False):
+    """keep = x < limit; acquireindex(keep); update_id(id); outputs x and id (and extra copies of x)."""
+    s = Script()
+    x = s.input(0, FLOAT, 0)
+    pid = s.input(0, INT32, 0)
+    keep = s.temp()
+    s.op("cmplt", x, s.const(0), keep)
+    s.acquireindex(keep, 0)
+    id_reg = pid
+    if id_from_temp:
+        id_reg = s.temp()
+        s.op("addi", pid, s.const(1), id_reg)          # constant 1 holds integer 0: the temp equals the input
+    s.update_id(id_reg, pid, 0)
+    pairs = [(x, s.output(0, FLOAT, 0))]
+    for i in range(extra_outputs):
+        t = s.temp()
+        s.op("add", x, s.const(2), t)
+        pairs.append((t, s.output(0, FLOAT, 1 + i)))
+    s.output_data(FLOAT, 0, pairs)
+    s.output_data(INT32, 0, [(pid, s.output(0, INT32, 0))])
+    return s.build()
+
+
+def update_constants(limit: float) -> bytes:
+    return struct.pack("<fif", limit, 0, 1.0) + bytes(4)
+
+
+def spawn_script():
+    """acquire_id -> (id, tag); keep everything; outputs id and tag."""
+    s = Script()
+    new_id, tag = s.temps(2)
+    s.acquire_id(new_id, tag, 0)
+    s.acquireindex(s.const(0), 0)
+    s.output_data(INT32, 0, [(new_id, s.output(0, INT32, 0)), (tag, s.output(0, INT32, 1))])
+    return s.build()
+
+
+def np_update_id(st: IdState, ids: np.ndarray, keep: np.ndarray, chunk: int, instance_offset: int = 0) -> IdState:
+    st = st.copy()
+    n = len(ids)
+    keep = keep.astype(bool)
+    rank = np.cumsum(keep) - keep                                   # survivors before each instance
+    st.id_table[ids[keep]] = instance_offset + rank[keep]           # :1191-1193 (and every case of the switch)
+    dead = ids[~keep]
+    st.free_table[st.num_free:st.num_free + len(dead)] = dead       # chunks in order, instance order within: :1175, 1181
+    st.num_free += len(dead)
+    for start in range(0, n, chunk):
+        nout = int(keep[start:start + chunk].sum())
+        if nout:
+            m = int(ids[start:start + nout].max())                  # :1141-1174, the uncompacted register
+            if m != -1 and m > st.max_used:
+                st.max_used = m
+    return st
+
+
+def np_acquire_id(st: IdState, n: int, chunk: int):
+    st = st.copy()
+    out = st.free_table[st.num_free - n:st.num_free][::-1].copy()   # :1417-1421, chunk after chunk from the end of the free list
+    table_max = len(st.free_table)
+    spawned = st.num_spawned
+    for start in range(0, n, chunk):
+        cnt = min(chunk, n - start)
+        spawned += cnt
+        st.free_table[table_max - spawned:table_max - spawned + cnt] = out[start:start + cnt]       # :1429-1432
+    st.num_free -= n
+    st.num_spawned += n
+    return st, out, np.full(n, st.tag, np.int32)

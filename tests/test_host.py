@@ -268,15 +268,59 @@ def test_more_than_64_constants_fall_back_to_the_table():
     assert classes.count(OPC_UNIF) == 63 and classes.count(OPC_CONST) == 6        # remapped constants 1..63 and 64..69
 
 
+def test_outputs_are_grouped_by_staging_slots():
+    """20 outputs: no output instruction straddles a group of eight list entries, and a flush separates the groups."""
+    s = Script()
+    s.acquireindex(s.const(0), 0)
+    x = s.input(0, FLOAT, 0)
+    ts = s.temps(20)
+    for i, t in enumerate(ts):
+        s.op("add", x if i == 0 else ts[i - 1], s.const(1), t)
+    s.output_data(FLOAT, 0, [(ts[i], s.output(0, FLOAT, i)) for i in range(20)])
+    code = [decode(i) for i in be().inspect_code(s.build().blob)]
+    tail = [c for c in code if c["op"] >= DOP_OUT32]
+    DOP_FLUSH = 197
+    assert [c["op"] for c in tail] == [DOP_OUT32] * 3 + [DOP_FLUSH] + [DOP_OUT32] * 3 + [DOP_FLUSH] + [DOP_OUT32] * 2
+    outs = [c for c in tail if c["op"] == DOP_OUT32]
+    assert [c["aux"] for c in outs] == [3, 3, 2, 3, 3, 2, 3, 1]                    # pairs per instruction
+    first = [c["o"][4] | (c["o"][5] << 16) for c in outs]
+    assert first == [0, 3, 6, 8, 11, 14, 16, 19]                                  # list index of each instruction's first pair
+    assert all(f // 8 == (f + c["aux"] - 1) // 8 for f, c in zip(first, outs))
+
+
+def test_id_instructions_link():
+    """update_id takes the last entry of its group of the output list; acquire_id becomes one instruction per destination."""
+    import id_cases
+    code = [decode(i) for i in be().inspect_code(id_cases.update_script(extra_outputs=9).blob)]
+    DOP_FLUSH, DOP_UPDATE_ID = 197, 198
+    tail = [c for c in code if c["op"] >= DOP_OUT32]
+    assert [c["op"] for c in tail] == [DOP_UPDATE_ID] + [DOP_OUT32] * 3 + [DOP_FLUSH] + [DOP_OUT32] * 2
+    assert tail[0]["o"][4] == 7                                                   # list entry 7 = last of group 0
+    assert [c["o"][4] for c in tail if c["op"] == DOP_OUT32] == [0, 3, 6, 8, 11]      # seven outputs in group 0, the rest in group 1
+    assert [c["aux"] for c in tail if c["op"] == DOP_OUT32] == [3, 3, 1, 3, 1]
+    info = be().inspect_blob(id_cases.update_script().blob)
+    assert info.InstancesPerLane == 4
+    code = [decode(i) for i in be().inspect_code(id_cases.spawn_script().blob)]
+    acq = [c for c in code if c["op"] == opcodes.CODE["acquire_id"]]
+    assert sorted(c["aux"] for c in acq) == [0, 1] and all(c["nin"] == 0 for c in acq)
+
+
 def test_unsupported_features_are_named():
     s = Script()
     t0, t1 = s.temps(2)
     s.acquire_id(t0, t1, 0)
     s.acquireindex(s.const(0), 0)
+    s.update_id(t0, t1, 0)
     s.output_data(INT32, 0, [(t0, s.output(0, INT32, 0))])
     with pytest.raises(abi.VVMError) as e:
         be().inspect_blob(s.build().blob)
     assert e.value.code == abi.VVM_E_UNSUPPORTED_OP and "acquire_id" in str(e.value)
+    s = Script()
+    pid = s.input(0, INT32, 0)
+    s.update_id(pid, pid, 0)                                                      # no acquireindex for the dataset
+    with pytest.raises(abi.VVMError) as e:
+        be().inspect_blob(s.build().blob)
+    assert e.value.code == abi.VVM_E_UNSUPPORTED_OP and "acquireindex" in str(e.value)
     s = Script()
     s.acquireindex(s.const(0), 0)
     f = s.ext_fn(2, 1)

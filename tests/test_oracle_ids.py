@@ -1,0 +1,64 @@
+"""CPU tests of the oracle's update_id / acquire_id against the numpy statement in id_cases.py."""
+import numpy as np
+import pytest
+
+import id_cases
+from vm_harness import IdState, run_oracle
+
+f32 = np.float32
+
+
+def _update_case(n, death, seed, table_slack=7):
+    rng = np.random.default_rng(seed)
+    x = rng.random(n).astype(f32)
+    ids = rng.permutation(n + table_slack)[:n].astype(np.int32)
+    st = IdState(np.full(n + table_slack, -1, np.int32), np.full(2 * n + 16, -7, np.int32), num_free=5, max_used=3)
+    st.free_table[:5] = [100001, 100002, 100003, 100004, 100005]
+    return x, ids, st, f32(1.0 - death)
+
+
+@pytest.mark.parametrize("n,death,page_kb", [(1, 0.0, 64), (1, 1.0, 64), (5, 0.5, 64), (1000, 0.3, 64), (1000, 0.3, 2), (4099, 0.9, 2), (4099, 0.02, 2),
+                                             (20000, 0.5, 64)])
+def test_update_id_matches_numpy(n, death, page_kb):
+    x, ids, st, limit = _update_case(n, death, 5 + n)
+    script = id_cases.update_script()
+    got = st.copy()
+    outs, surv, frame = run_oracle(script, [id_cases.update_constants(limit)], [x, ids], [f32, np.int32], n, ids=got, page_kb=page_kb)
+    keep = x < limit
+    chunk = int(frame.ctx.Internal.MaxInstancesPerChunk)
+    if page_kb == 2:
+        assert chunk < n                                            # the chunk-dependent part is exercised
+    want = id_cases.np_update_id(st, ids, keep, chunk)
+    assert surv == int(keep.sum())
+    assert np.array_equal(outs[1][:surv], ids[keep])
+    assert np.array_equal(got.id_table, want.id_table)
+    assert np.array_equal(got.free_table, want.free_table)
+    assert (got.num_free, got.max_used) == (want.num_free, want.max_used)
+
+
+def test_update_id_max_is_taken_over_the_uncompacted_register():
+    """Four instances, the first one dies: one survivor per... NumOutput = 3, so the maximum runs over ids[0:3] and misses ids[3]."""
+    x = np.array([2.0, 0.0, 0.0, 0.0], f32)
+    ids = np.array([1, 2, 3, 9], np.int32)
+    st = IdState(np.full(16, -1, np.int32), np.zeros(16, np.int32), num_free=0, max_used=-1)
+    run_oracle(id_cases.update_script(), [id_cases.update_constants(1.0)], [x, ids], [f32, np.int32], 4, ids=st)
+    assert st.max_used == 3 and st.num_free == 1 and st.free_table[0] == 1
+    assert list(st.id_table[[2, 3, 9]]) == [0, 1, 2]
+
+
+@pytest.mark.parametrize("n,page_kb", [(1, 64), (7, 64), (1000, 64), (1000, 2), (4099, 2)])
+def test_acquire_id_matches_numpy(n, page_kb):
+    rng = np.random.default_rng(n)
+    table_max = 3 * n + 40
+    st = IdState(np.zeros(0, np.int32), np.full(table_max, -3, np.int32), num_free=n + 11, max_used=0, num_spawned=6, tag=77)
+    st.free_table[:n + 11] = rng.permutation(10 * n + 100)[:n + 11]
+    got = st.copy()
+    outs, surv, frame = run_oracle(id_cases.spawn_script(), [bytes([255] * 4) + bytes(12)], [], [np.int32, np.int32], n, ids=got, page_kb=page_kb)
+    chunk = int(frame.ctx.Internal.MaxInstancesPerChunk)
+    if page_kb == 2:
+        assert chunk < n
+    want, want_ids, want_tags = id_cases.np_acquire_id(st, n, chunk)
+    assert surv == n
+    assert np.array_equal(outs[0][:n], want_ids) and np.array_equal(outs[1][:n], want_tags)
+    assert np.array_equal(got.free_table, want.free_table)
+    assert (got.num_free, got.num_spawned) == (want.num_free, want.num_spawned)

@@ -12,6 +12,30 @@ from renderer_amd.assembler import BuiltScript
 PAD = 16   # extra elements past N in every stream (the reference needs align4(N) + 16 bytes of slack)
 
 
+class IdState:
+    """The persistent-ID tables of a dataset, as numpy arrays and ints; run_oracle / run_hip update it in place."""
+
+    def __init__(self, id_table: np.ndarray, free_table: np.ndarray, num_free: int, max_used: int = -1, num_spawned: int = 0, tag: int = 0):
+        self.id_table = np.ascontiguousarray(id_table, dtype=np.int32)
+        self.free_table = np.ascontiguousarray(free_table, dtype=np.int32)      # its length is FreeIDTable->Max()
+        self.num_free, self.max_used, self.num_spawned, self.tag = int(num_free), int(max_used), int(num_spawned), int(tag)
+
+    def copy(self) -> "IdState":
+        return IdState(self.id_table.copy(), self.free_table.copy(), self.num_free, self.max_used, self.num_spawned, self.tag)
+
+    def attach(self, ds: abi.DataSet, id_ptr: int, free_ptr: int) -> None:
+        def table(ptr, n):
+            t = abi.IdTable()
+            t.data = ptr or None
+            t.num, t.max = n, n
+            return t
+        ds.set_id_tables(table(id_ptr, len(self.id_table)), table(free_ptr, len(self.free_table)), table(0, 0),
+                         self.num_free, self.max_used, self.num_spawned, self.tag)
+
+    def read_counters(self, ds: abi.DataSet) -> None:
+        self.num_free, self.max_used, self.num_spawned = ds.id_tables[3].value, ds.id_tables[4].value, ds.id_tables[5].value
+
+
 def _type_offsets(streams: Sequence[np.ndarray]) -> List[int]:
     """Streams are ordered float32 first, then int32, then float16 (half)."""
     nf = sum(1 for s in streams if s.dtype == np.float32)
@@ -22,7 +46,7 @@ def _type_offsets(streams: Sequence[np.ndarray]) -> List[int]:
 def run_oracle(script: BuiltScript, const_tables: Sequence[bytes], inputs: Sequence[np.ndarray],
                out_dtypes: Sequence, n: int, instance_offset: int = 0, ext_fns: Sequence = (),
                seed: int = 0, exec_index_base: int = 0, rand_instance_base: int = 0, strict: bool = False,
-               page_kb: int = 64, out_fill: int = 0xCD) -> Tuple[List[np.ndarray], int, abi.CallFrame]:
+               page_kb: int = 64, out_fill: int = 0xCD, ids: Optional[IdState] = None) -> Tuple[List[np.ndarray], int, abi.CallFrame]:
     from oracle_binding import load_oracle
     be = load_oracle()
     be.set_strict(strict)
@@ -37,6 +61,8 @@ def run_oracle(script: BuiltScript, const_tables: Sequence[bytes], inputs: Seque
     outs = [np.frombuffer(bytes([out_fill]) * (total * np.dtype(dt).itemsize), dtype=dt).copy() for dt in out_dtypes]
     ds = abi.DataSet([a.ctypes.data for a in ins], [a.ctypes.data for a in outs], instance_offset,
                      _type_offsets(ins), _type_offsets(outs))
+    if ids is not None:
+        ids.attach(ds, ids.id_table.ctypes.data, ids.free_table.ctypes.data)
     state = be.alloc_state(script.blob)
     try:
         frame = abi.CallFrame(state, [ds], n, const_tables, ext_fns)
@@ -44,6 +70,8 @@ def run_oracle(script: BuiltScript, const_tables: Sequence[bytes], inputs: Seque
         if rc != 0:
             raise abi.VVMError(rc, "vvm_oracle_exec")
         surv = frame.survivors(0)
+        if ids is not None:
+            ids.read_counters(frame.datasets[0])
     finally:
         be.free_state(state)
     return outs, surv, frame
@@ -52,12 +80,13 @@ def run_oracle(script: BuiltScript, const_tables: Sequence[bytes], inputs: Seque
 def run_hip(script: BuiltScript, const_tables: Sequence[bytes], inputs: Sequence[np.ndarray],
             out_dtypes: Sequence, n: int, instance_offset: int = 0, ext_fns: Sequence = (),
             seed: int = 0, exec_index_base: int = 0, rand_instance_base: int = 0, flags: int = 0,
-            out_fill: int = 0xCD, repeat: int = 1) -> Tuple[List[np.ndarray], int, abi.ProgramInfo]:
+            out_fill: int = 0xCD, repeat: int = 1, ids: Optional[IdState] = None, page_kb: int = 64) -> Tuple[List[np.ndarray], int, abi.ProgramInfo]:
     """Same contract as run_oracle, through the C ABI of libvvm_hip.so with streams in device memory."""
     be = abi.load_hip_backend()
     L = be.lib
     total = instance_offset + n + PAD
-    dev_in, dev_out, host_out = [], [], []
+    dev_in, dev_out, host_out, dev_ids = [], [], [], []
+    be.set_page_size_kb(page_kb)
     try:
         for a in inputs:
             buf = np.zeros(total, dtype=a.dtype)
@@ -75,6 +104,14 @@ def run_hip(script: BuiltScript, const_tables: Sequence[bytes], inputs: Sequence
         in_off = _type_offsets([np.empty(0, a.dtype) for a in inputs])
         out_off = _type_offsets([np.empty(0, dt) for dt in out_dtypes])
         ds = abi.DataSet(dev_in, dev_out, instance_offset, in_off, out_off)
+        if ids is not None:
+            for a in (ids.id_table, ids.free_table):
+                p = L.vvm_device_alloc(max(a.nbytes, 4))
+                assert p, be.error_text()
+                dev_ids.append(p)
+                if a.nbytes:
+                    be._check(L.vvm_device_upload(p, a.ctypes.data, a.nbytes), "upload")
+            ids.attach(ds, dev_ids[0], dev_ids[1])
         state = be.alloc_state(script.blob)
         try:
             frame = abi.CallFrame(state, [ds], n, const_tables, ext_fns)
@@ -83,6 +120,11 @@ def run_hip(script: BuiltScript, const_tables: Sequence[bytes], inputs: Sequence
                 be.exec_ex(frame, opt)
             surv = frame.survivors(0)
             info = be.info(state)
+            if ids is not None:
+                ids.read_counters(frame.datasets[0])
+                for a, p in zip((ids.id_table, ids.free_table), dev_ids):
+                    if a.nbytes:
+                        be._check(L.vvm_device_download(a.ctypes.data, p, a.nbytes), "download")
         finally:
             be.free_state(state)
         for p, dt in zip(dev_out, out_dtypes):
@@ -90,8 +132,9 @@ def run_hip(script: BuiltScript, const_tables: Sequence[bytes], inputs: Sequence
             be._check(L.vvm_device_download(h.ctypes.data, p, h.nbytes), "download")
             host_out.append(h)
     finally:
-        for p in dev_in + dev_out:
+        for p in dev_in + dev_out + dev_ids:
             L.vvm_device_free(p)
+        be.set_page_size_kb(64)
     return host_out, surv, info
 
 
