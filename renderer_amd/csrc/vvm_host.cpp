@@ -114,6 +114,9 @@ struct vvm_state {
 	vvm::ThawedScript script;
 	vvm::LinkedProgram wide, narrow;       // narrow is linked on demand (VVM_EXEC_NO_VGPR_WIDE)
 	bool narrow_ready = false;
+	// a script with acquireindex on several datasets runs one pass per dataset: the programs of passes 1.. (pass 0 = wide / narrow)
+	std::vector<vvm::LinkedProgram> wide_more, narrow_more;
+	std::vector<VvmIns*> d_code_wide_more, d_code_narrow_more;
 
 	VvmIns* d_code_wide = nullptr;
 	VvmIns* d_code_narrow = nullptr;
@@ -234,7 +237,21 @@ void reference_chunking(const vvm::ThawedScript& s, vvm_exec_context* ctx, uint3
 size_t align_up(size_t v, size_t a) { return (v + a - 1) & ~(a - 1); }
 
 // Validates the context and sizes its parameter block.
-int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, PreparedExec& pe)
+int link_more_passes(const vvm::ThawedScript& s, bool narrow, const vvm::LinkedProgram& first, std::vector<vvm::LinkedProgram>& more, std::vector<VvmIns*>& d_code)
+{
+	more.resize(first.num_passes - 1);
+	d_code.assign(first.num_passes - 1, nullptr);
+	for (uint32_t k = 1; k < first.num_passes; ++k) {
+		std::string err;
+		int rc = vvm::link_program(s, narrow, more[k - 1], err, k);
+		if (rc != VVM_OK) return fail(rc, err);
+		rc = upload_code(more[k - 1], &d_code[k - 1]);
+		if (rc != VVM_OK) return rc;
+	}
+	return VVM_OK;
+}
+
+int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, PreparedExec& pe, uint32_t pass = 0)
 {
 	const vvm::ThawedScript& s = st->script;
 	if ((uint32_t)ctx->ExtFunctionTable.num != s.num_ext_fns)                                         // RT.cpp:2184-2187
@@ -249,11 +266,13 @@ int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, P
 			if (rc != VVM_OK) return fail(rc, err);
 			rc = upload_code(st->narrow, &st->d_code_narrow);
 			if (rc != VVM_OK) return rc;
+			rc = link_more_passes(s, true, st->narrow, st->narrow_more, st->d_code_narrow_more);
+			if (rc != VVM_OK) return rc;
 			st->narrow_ready = true;
 		}
-		pe.lp = &st->narrow; pe.d_code = st->d_code_narrow;
+		pe.lp = pass ? &st->narrow_more[pass - 1] : &st->narrow; pe.d_code = pass ? st->d_code_narrow_more[pass - 1] : st->d_code_narrow;
 	} else {
-		pe.lp = &st->wide; pe.d_code = st->d_code_wide;
+		pe.lp = pass ? &st->wide_more[pass - 1] : &st->wide; pe.d_code = pass ? st->d_code_wide_more[pass - 1] : st->d_code_wide;
 	}
 	for (uint32_t i = 0; i < s.num_ext_fns; ++i) {
 		const vvm_ext_function* f = ctx->ExtFunctionTable.data[i];
@@ -346,9 +365,7 @@ int fill_params(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* op
 	uint64_t* out_list = (uint64_t*)(host + pe.off_out);                                                // RT.cpp:418-441
 	memset(out_list, 0, pe.bytes - pe.off_out);
 	{   // the entry before the list: where the Exec's last tile writes the survivor count of the acquired dataset
-		uint32_t acquired = 0;
-		for (size_t k = 0; k < lp.acquires_dataset.size(); ++k) if (lp.acquires_dataset[k]) acquired = (uint32_t)k;
-		out_list[-1] = (uint64_t)(uintptr_t)(d->counts + acquired);
+		out_list[-1] = (uint64_t)(uintptr_t)(d->counts + lp.pass_dataset);
 	}
 	for (size_t k = 0; k < lp.out_list.size(); ++k) {
 		const int32_t i = lp.out_list[k];
@@ -443,6 +460,7 @@ VVM_API vvm_state* vvm_alloc_state(const uint8_t* blob, size_t num_bytes)
 	auto bail = [&](hipError_t e, const char* where) -> vvm_state* { hip_fail(e, where); vvm_free_state(st); return nullptr; };
 	if (ensure_device_info() != VVM_OK) { vvm_free_state(st); return nullptr; }
 	if (upload_code(st->wide, &st->d_code_wide) != VVM_OK) { vvm_free_state(st); return nullptr; }
+	if (link_more_passes(st->script, false, st->wide, st->wide_more, st->d_code_wide_more) != VVM_OK) { vvm_free_state(st); return nullptr; }
 	hipError_t e;
 	if (st->wide.uses_perlin) {
 		if ((e = hipMalloc((void**)&st->d_perlin, 512)) != hipSuccess) return bail(e, "hipMalloc(perlin)");
@@ -467,6 +485,8 @@ VVM_API void vvm_free_state(vvm_state* st)
 	st->ring.release();
 	if (st->d_code_wide) (void)hipFree(st->d_code_wide);
 	if (st->d_code_narrow) (void)hipFree(st->d_code_narrow);
+	for (VvmIns* p : st->d_code_wide_more) if (p) (void)hipFree(p);
+	for (VvmIns* p : st->d_code_narrow_more) if (p) (void)hipFree(p);
 	if (st->d_perlin) (void)hipFree(st->d_perlin);
 	if (st->d_launch) (void)hipFree(st->d_launch);
 	if (st->d_status) (void)hipFree(st->d_status);
@@ -498,34 +518,7 @@ VVM_API int vvm_exec_async(vvm_exec_context* ctx, const vvm_exec_options* opt)
 	}
 	rc = ensure_status(st, pe.tiles);
 	if (rc != VVM_OK) return rc;
-	rc = st->ring.reserve(pe.bytes);
-	if (rc != VVM_OK) return rc;
 	const size_t ncounts = std::max<uint32_t>(st->script.max_output_dataset, 1);
-	if (pe.lp->uses_ids) {
-		const vvm_dataset_meta& ds = ctx->DataSets.data[pe.lp->id_dataset];
-		st->id_num_free_start = *ds.NumFreeIDs;
-		st->id_num_spawned_start = ds.NumSpawnedIDs ? *ds.NumSpawnedIDs : 0;
-		if (pe.lp->updates_ids) {
-			if (pe.num_chunks > st->chunk_capacity || (uint32_t)ctx->NumInstances > st->id_scratch_capacity) {
-				HIP_TRY(hipStreamSynchronize(stream));
-				if (st->d_chunk_prefix) HIP_TRY(hipFree(st->d_chunk_prefix));
-				if (st->d_id_scratch) HIP_TRY(hipFree(st->d_id_scratch));
-				st->chunk_capacity = pe.num_chunks + pe.num_chunks / 4 + 64;
-				st->id_scratch_capacity = (uint32_t)ctx->NumInstances + (uint32_t)ctx->NumInstances / 4 + 1024;
-				HIP_TRY(hipMalloc((void**)&st->d_chunk_prefix, (size_t)st->chunk_capacity * 4));
-				HIP_TRY(hipMalloc((void**)&st->d_id_scratch, (size_t)st->id_scratch_capacity * 4));
-			}
-			// MaxUsedID starts from the caller's value (the kernel only ever raises it, VectorVMRuntime.cpp:1383-1399)
-			st->h_counts[ncounts + 1] = *ds.MaxUsedID;
-			HIP_TRY(hipMemcpyAsync(st->d_counts + ncounts, st->h_counts + ncounts + 1, 4, hipMemcpyHostToDevice, stream));
-		}
-	}
-	int slot = 0;
-	rc = st->ring.acquire(slot);
-	if (rc != VVM_OK) return rc;
-	rc = fill_params(st, ctx, opt, pe, st->ring.host[slot], st->ring.dev[slot], st->d_status, 0);
-	if (rc != VVM_OK) return rc;
-	HIP_TRY(hipMemcpyAsync(st->ring.dev[slot], st->ring.host[slot], pe.bytes, hipMemcpyHostToDevice, stream));
 	const bool timed = st->timing && st->ev_used < 4096;
 	if (timed) {
 		if (st->ev_used == st->ev_start.size()) {
@@ -534,18 +527,54 @@ VVM_API int vvm_exec_async(vvm_exec_context* ctx, const vvm_exec_options* opt)
 			HIP_TRY(hipEventCreate(&b));
 			st->ev_start.push_back(a); st->ev_stop.push_back(b);
 		}
-		HIP_TRY(hipEventRecord(st->ev_start[st->ev_used], stream));
 	}
-	const int lrc = vvm_launch_exec_kernel((int)pe.lp->instances_per_lane, (const VvmExecDesc*)st->ring.dev[slot], 1, pe.tiles, st->d_launch,
-	                                       pe.lp->lds_spill_slots, pe.lp->full_kernel ? 1 : 0, grid_for(pe.tiles), stream);
-	if (lrc != 0) return hip_fail((hipError_t)lrc, "kernel launch");
-	if (timed) { HIP_TRY(hipEventRecord(st->ev_stop[st->ev_used], stream)); st->ev_used++; }
-	if (pe.lp->uses_ids && pe.lp->updates_ids) {
-		const int mrc = vvm_launch_max_id_kernel((const VvmIdDesc*)(st->ring.dev[slot] + pe.off_ids), pe.num_chunks, stream);
-		if (mrc != 0) return hip_fail((hipError_t)mrc, "MaxUsedID kernel launch");
+	// One launch per pass (one pass unless the script runs acquireindex for several datasets).  The passes share the look-back
+	// words: every launch leaves a new epoch behind, which invalidates the words of the one before.
+	const uint32_t num_passes = pe.lp->num_passes;
+	for (uint32_t pass = 0; pass < num_passes; ++pass) {
+		if (pass != 0) {
+			rc = prepare(st, ctx, opt, pe, pass);
+			if (rc != VVM_OK) return rc;
+		}
+		rc = st->ring.reserve(pe.bytes);
+		if (rc != VVM_OK) return rc;
+		if (pe.lp->uses_ids) {
+			const vvm_dataset_meta& ds = ctx->DataSets.data[pe.lp->id_dataset];
+			st->id_num_free_start = *ds.NumFreeIDs;
+			st->id_num_spawned_start = ds.NumSpawnedIDs ? *ds.NumSpawnedIDs : 0;
+			if (pe.lp->updates_ids) {
+				if (pe.num_chunks > st->chunk_capacity || (uint32_t)ctx->NumInstances > st->id_scratch_capacity) {
+					HIP_TRY(hipStreamSynchronize(stream));
+					if (st->d_chunk_prefix) HIP_TRY(hipFree(st->d_chunk_prefix));
+					if (st->d_id_scratch) HIP_TRY(hipFree(st->d_id_scratch));
+					st->chunk_capacity = pe.num_chunks + pe.num_chunks / 4 + 64;
+					st->id_scratch_capacity = (uint32_t)ctx->NumInstances + (uint32_t)ctx->NumInstances / 4 + 1024;
+					HIP_TRY(hipMalloc((void**)&st->d_chunk_prefix, (size_t)st->chunk_capacity * 4));
+					HIP_TRY(hipMalloc((void**)&st->d_id_scratch, (size_t)st->id_scratch_capacity * 4));
+				}
+				// MaxUsedID starts from the caller's value (the kernel only ever raises it, VectorVMRuntime.cpp:1383-1399)
+				st->h_counts[ncounts + 1] = *ds.MaxUsedID;
+				HIP_TRY(hipMemcpyAsync(st->d_counts + ncounts, st->h_counts + ncounts + 1, 4, hipMemcpyHostToDevice, stream));
+			}
+		}
+		int slot = 0;
+		rc = st->ring.acquire(slot);
+		if (rc != VVM_OK) return rc;
+		rc = fill_params(st, ctx, opt, pe, st->ring.host[slot], st->ring.dev[slot], st->d_status, 0);
+		if (rc != VVM_OK) return rc;
+		HIP_TRY(hipMemcpyAsync(st->ring.dev[slot], st->ring.host[slot], pe.bytes, hipMemcpyHostToDevice, stream));
+		if (timed && pass == 0) HIP_TRY(hipEventRecord(st->ev_start[st->ev_used], stream));
+		const int lrc = vvm_launch_exec_kernel((int)pe.lp->instances_per_lane, (const VvmExecDesc*)st->ring.dev[slot], 1, pe.tiles, st->d_launch,
+		                                       pe.lp->lds_spill_slots, pe.lp->full_kernel ? 1 : 0, grid_for(pe.tiles), stream);
+		if (lrc != 0) return hip_fail((hipError_t)lrc, "kernel launch");
+		if (timed && pass + 1 == num_passes) { HIP_TRY(hipEventRecord(st->ev_stop[st->ev_used], stream)); st->ev_used++; }
+		if (pe.lp->uses_ids && pe.lp->updates_ids) {
+			const int mrc = vvm_launch_max_id_kernel((const VvmIdDesc*)(st->ring.dev[slot] + pe.off_ids), pe.num_chunks, stream);
+			if (mrc != 0) return hip_fail((hipError_t)mrc, "MaxUsedID kernel launch");
+		}
+		HIP_TRY(hipEventRecord(st->ring.done[slot], stream));
+		st->ring.pending[slot] = true;
 	}
-	HIP_TRY(hipEventRecord(st->ring.done[slot], stream));
-	st->ring.pending[slot] = true;
 	HIP_TRY(hipMemcpyAsync(st->h_counts, st->d_counts, (ncounts + 1) * 4, hipMemcpyDeviceToHost, stream));     // (and the MaxUsedID word)
 	HIP_TRY(hipMemcpyAsync(st->h_counts + ncounts + 4, st->d_launch, 80, hipMemcpyDeviceToHost, stream));     // the words up to and including stats[]
 	return VVM_OK;
@@ -569,9 +598,11 @@ VVM_API int vvm_exec_finish(vvm_exec_context* ctx)
 			return fail(VVM_E_HIP, "look-back timed out inside the kernel (a tile never published its count)");
 		}
 	}
-	if (ran && st->wide.uses_ids) {
+	const vvm::LinkedProgram* id_lp = st->wide.uses_ids ? &st->wide : nullptr;      // (update_id sits in its dataset's pass)
+	for (const vvm::LinkedProgram& more : st->wide_more) if (!id_lp && more.uses_ids) id_lp = &more;
+	if (ran && id_lp) {
 		// the dataset's ID counters, as the reference leaves them (VectorVMRuntime.cpp:1175, 1383-1399, 1411-1429)
-		const vvm::LinkedProgram& lp = st->wide;
+		const vvm::LinkedProgram& lp = *id_lp;
 		vvm_dataset_meta& ds = ctx->DataSets.data[lp.id_dataset];
 		const size_t ncounts = std::max<uint32_t>(st->script.max_output_dataset, 1);
 		if (lp.updates_ids) {
@@ -632,6 +663,7 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 		if (st->in_flight && st->last_stream) { HIP_TRY(hipStreamSynchronize(st->last_stream)); st->in_flight = false; }
 		const vvm::LinkedProgram& lp = *pes[(size_t)i].lp;
 		if (lp.uses_ids) return fail(VVM_E_UNSUPPORTED_OP, "scripts with update_id / acquire_id cannot be part of a batched Exec");
+		if (lp.num_passes > 1) return fail(VVM_E_UNSUPPORTED_OP, "scripts with acquireindex on several datasets cannot be part of a batched Exec");
 		const int key = (int)lp.instances_per_lane * 4 + (lp.lds_spill_slots ? 2 : 0) + (lp.full_kernel ? 1 : 0);
 		Group* g = nullptr;
 		for (Group& c : groups) if (c.key == key) g = &c;

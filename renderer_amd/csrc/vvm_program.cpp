@@ -209,7 +209,7 @@ static int decode(const ThawedScript& s, std::vector<Decoded>& out, std::string&
 static const uint32_t kMaxSpillWide = 12;      // LDS register slots of the 4-instances-per-lane kernel (4 KB each per workgroup)
 static const uint32_t kMaxSpillNarrow = 128;   // 1 KB each
 
-int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, std::string& err)
+int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, std::string& err, uint32_t pass)
 {
 	std::vector<Decoded> ins;
 	int rc = decode(s, ins, err);
@@ -288,6 +288,7 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 			if (d.dataset >= lp.acquires_dataset.size()) { err = "acquireindex names a dataset past MaxOutputDataSet"; return VVM_E_BAD_BLOB; }
 			if (lp.acquires_dataset[d.dataset]) { err = "more than one acquireindex for a dataset"; return VVM_E_UNSUPPORTED_OP; }
 			lp.acquires_dataset[d.dataset] = 1;
+			lp.acquire_order.push_back(d.dataset);
 		}
 		for (uint16_t r : d.in) touch(r);
 		for (uint16_t r : d.out) {
@@ -317,9 +318,15 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 		err = "update_id on a dataset the script has no acquireindex for";       // it walks that dataset's keep mask (VectorVMRuntime.cpp:1178)
 		return VVM_E_UNSUPPORTED_OP;
 	}
-	uint32_t acquired = 0;
-	for (uint8_t a : lp.acquires_dataset) acquired += a;
-	if (acquired > 1) { err = "acquireindex on more than one dataset in one script is not supported by the GPU executor"; return VVM_E_UNSUPPORTED_OP; }
+	// A script that runs acquireindex for several datasets is executed in one pass per dataset: every pass runs the whole
+	// script, but only the pass's dataset is compacted and written (the others' acquireindex and outputs are left out of the
+	// pass's program).  The instructions are pure functions of the inputs, so every pass computes the same values.
+	lp.num_passes = std::max<uint32_t>(1, (uint32_t)lp.acquire_order.size());
+	if (pass >= lp.num_passes) { err = "pass index out of range"; return VVM_E_INVALID_ARG; }
+	const bool multi_pass = lp.num_passes > 1;
+	const uint32_t pass_dataset = lp.acquire_order.empty() ? 0 : lp.acquire_order[pass];
+	lp.pass_dataset = pass_dataset;
+	if (multi_pass && lp.updates_ids && lp.id_dataset != pass_dataset) { lp.uses_ids = false; lp.updates_ids = false; }     // update_id runs in its dataset's pass
 
 	// Every advancing input stream the script reads is loaded once, at the start of a tile, into a per-lane register of its own
 	// (VVM_DOP_LOADN / VVM_DOP_LOADN16, eight streams per instruction, in order of first use; 32-bit streams first).  The
@@ -476,6 +483,7 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 			break;
 		}
 		case K_ACQUIRE:
+			if (multi_pass && d.dataset != pass_dataset) break;       // another pass's dataset
 			acquired_dataset = (int)d.dataset;
 			k.w0 = VVM_INS_W0(VVM_DOP_ACQUIRE, 1, 0, d.dataset, 0);
 			k.w1 = operand(d.in[0]);
@@ -486,6 +494,7 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 			if (d.op == VVM_OP_outputdata_half) dop = VVM_DOP_OUTPUT16;
 			else if (d.op == VVM_OP_outputdata_half_from_half) dop = VVM_DOP_OUTPUT16_FROM16;
 			else if (d.op == VVM_OP_outputdata_float_from_half) dop = VVM_DOP_OUTPUT32_FROM16;
+			if (multi_pass && d.dataset != pass_dataset) break;       // another pass's dataset
 			// An output that no acquireindex precedes, or whose dataset is not the acquired one, writes nothing
 			// (VectorVMRuntime.cpp:565, 769): its list entry stays empty.
 			const bool live = acquired_dataset >= 0 && (uint32_t)acquired_dataset == d.dataset;
@@ -531,6 +540,7 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 			break;
 		}
 		case K_IDS: {
+			if (d.op == VVM_OP_update_id && multi_pass && d.dataset != pass_dataset) break;       // another pass's dataset
 			if (d.op == VVM_OP_update_id) {
 				// staged like an output: one entry of the output list, one staging slot (in[1], the tag register, is not read:
 				// VectorVMRuntime.cpp:1133 only loads its address)

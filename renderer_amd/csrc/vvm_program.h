@@ -46,6 +46,9 @@ struct LinkedProgram {
 	bool     updates_ids = false;      // ... which of the two
 	uint32_t id_dataset = 0;           // ... and the dataset whose ID tables it works on
 	std::vector<uint8_t> acquires_dataset;   // per output dataset: the script runs acquireindex for it
+	std::vector<uint32_t> acquire_order;     // those datasets in program order
+	uint32_t num_passes = 1;                 // one pass per acquired dataset (see link_program)
+	uint32_t pass_dataset = 0;               // the dataset this program compacts and writes
 	uint32_t bytes_in_per_instance = 0, bytes_out_per_instance = 0;
 	uint32_t num_prefetched_inputs = 0;
 	std::vector<int32_t> load_list;    // remapped input index per load slot (8 per load instruction), -1 = unused slot
@@ -56,6 +59,7 @@ struct LinkedProgram {
 
 // Returns VVM_OK or an error code with `err` filled.
 int thaw_blob(const uint8_t* blob, size_t n, ThawedScript& out, std::string& err);
-int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& out, std::string& err);
+// `pass` selects the dataset of a script with several acquireindex datasets (0 .. out.num_passes - 1 of a first link).
+int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& out, std::string& err, uint32_t pass = 0);
 
 }  // namespace vvm

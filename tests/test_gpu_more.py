@@ -258,3 +258,28 @@ def test_full_size_against_torch(kill_half):
             assert torch.equal(first[k].view(torch.int32), outs[k][:surv].view(torch.int32))
     finally:
         st.close()
+
+
+# ---- two datasets ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,secondary_first,many", [(1, False, False), (1000, False, False), (5003, True, False), (300007, False, True), (300007, True, False)])
+def test_two_datasets_match_the_oracle(n, secondary_first, many):
+    """acquireindex on two datasets: one pass of the kernel per dataset, each with its own mask, count and output positions."""
+    import dataset_cases
+    rng = np.random.default_rng(n)
+    x, y = rng.random(n).astype(f32), rng.random(n).astype(f32)
+    script = dataset_cases.two_dataset_script(secondary_first, many)
+    consts = [dataset_cases.constants(0.5, 0.7)]
+    dt0 = [f32] * (11 if many else 2)
+    ref_more, got_more = [], []
+    ref, ref_n, _ = run_oracle(script, consts, [x, y], dt0, n, more_datasets=[[f32, np.int32]], more_results=ref_more)
+    got, got_n, _ = run_hip(script, consts, [x, y], dt0, n, more_datasets=[[f32, np.int32]], more_results=got_more)
+    assert got_n == ref_n and got_more[0][1] == ref_more[0][1]
+    for a, b in zip(got, ref):
+        assert np.array_equal(_bits(a[:got_n]), _bits(b[:ref_n]))
+        assert np.all(_bits(a[got_n:]) == 0xCDCDCDCD)
+    m = got_more[0][1]
+    for a, b in zip(got_more[0][0], ref_more[0][0]):
+        assert np.array_equal(a[:m].view(np.uint32), b[:m].view(np.uint32))
+        assert np.all(a[m:].view(np.uint32) == 0xCDCDCDCD)
+    d0, d1 = dataset_cases.expected(x, y, 0.5, 0.7, many)
+    assert got_n == len(d0[0]) and m == len(d1[0])

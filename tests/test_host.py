@@ -305,6 +305,18 @@ def test_id_instructions_link():
     assert sorted(c["aux"] for c in acq) == [0, 1] and all(c["nin"] == 0 for c in acq)
 
 
+def test_two_acquire_datasets_link_to_one_program_per_dataset():
+    import dataset_cases
+    blob = dataset_cases.two_dataset_script().blob
+    info = be().inspect_blob(blob)
+    code = [decode(i) for i in be().inspect_code(blob)]                           # the first pass: dataset 0 only
+    acq = [c for c in code if c["op"] == DOP_ACQUIRE]
+    outs = [c for c in code if c["op"] == DOP_OUT32]
+    assert len(acq) == 1 and acq[0]["aux"] == 0
+    assert len(outs) == 1 and outs[0]["aux"] == 2 and outs[0]["aux2"] == 0
+    assert info.InstancesPerLane == 4
+
+
 def test_unsupported_features_are_named():
     s = Script()
     t0, t1 = s.temps(2)

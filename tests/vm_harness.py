@@ -46,7 +46,9 @@ def _type_offsets(streams: Sequence[np.ndarray]) -> List[int]:
 def run_oracle(script: BuiltScript, const_tables: Sequence[bytes], inputs: Sequence[np.ndarray],
                out_dtypes: Sequence, n: int, instance_offset: int = 0, ext_fns: Sequence = (),
                seed: int = 0, exec_index_base: int = 0, rand_instance_base: int = 0, strict: bool = False,
-               page_kb: int = 64, out_fill: int = 0xCD, ids: Optional[IdState] = None) -> Tuple[List[np.ndarray], int, abi.CallFrame]:
+               page_kb: int = 64, out_fill: int = 0xCD, ids: Optional[IdState] = None,
+               more_datasets: Sequence[Sequence] = (), more_results: Optional[list] = None) -> Tuple[List[np.ndarray], int, abi.CallFrame]:
+    """more_datasets: output dtypes of datasets 1, 2, ... (outputs only); their (streams, survivors) are appended to more_results."""
     from oracle_binding import load_oracle
     be = load_oracle()
     be.set_strict(strict)
@@ -63,13 +65,17 @@ def run_oracle(script: BuiltScript, const_tables: Sequence[bytes], inputs: Seque
                      _type_offsets(ins), _type_offsets(outs))
     if ids is not None:
         ids.attach(ds, ids.id_table.ctypes.data, ids.free_table.ctypes.data)
+    more_outs = [[np.frombuffer(bytes([out_fill]) * (total * np.dtype(dt).itemsize), dtype=dt).copy() for dt in dts] for dts in more_datasets]
+    more_ds = [abi.DataSet([], [a.ctypes.data for a in o], instance_offset, [0, 0, 0], _type_offsets(o)) for o in more_outs]
     state = be.alloc_state(script.blob)
     try:
-        frame = abi.CallFrame(state, [ds], n, const_tables, ext_fns)
+        frame = abi.CallFrame(state, [ds] + more_ds, n, const_tables, ext_fns)
         rc = be.exec(frame)
         if rc != 0:
             raise abi.VVMError(rc, "vvm_oracle_exec")
         surv = frame.survivors(0)
+        if more_results is not None:
+            more_results.extend((o, frame.survivors(1 + i)) for i, o in enumerate(more_outs))
         if ids is not None:
             ids.read_counters(frame.datasets[0])
     finally:
@@ -80,7 +86,8 @@ def run_oracle(script: BuiltScript, const_tables: Sequence[bytes], inputs: Seque
 def run_hip(script: BuiltScript, const_tables: Sequence[bytes], inputs: Sequence[np.ndarray],
             out_dtypes: Sequence, n: int, instance_offset: int = 0, ext_fns: Sequence = (),
             seed: int = 0, exec_index_base: int = 0, rand_instance_base: int = 0, flags: int = 0,
-            out_fill: int = 0xCD, repeat: int = 1, ids: Optional[IdState] = None, page_kb: int = 64) -> Tuple[List[np.ndarray], int, abi.ProgramInfo]:
+            out_fill: int = 0xCD, repeat: int = 1, ids: Optional[IdState] = None, page_kb: int = 64,
+            more_datasets: Sequence[Sequence] = (), more_results: Optional[list] = None) -> Tuple[List[np.ndarray], int, abi.ProgramInfo]:
     """Same contract as run_oracle, through the C ABI of libvvm_hip.so with streams in device memory."""
     be = abi.load_hip_backend()
     L = be.lib
@@ -112,14 +119,34 @@ def run_hip(script: BuiltScript, const_tables: Sequence[bytes], inputs: Sequence
                 if a.nbytes:
                     be._check(L.vvm_device_upload(p, a.ctypes.data, a.nbytes), "upload")
             ids.attach(ds, dev_ids[0], dev_ids[1])
+        more_dev = []
+        for dts in more_datasets:
+            ptrs = []
+            for dt in dts:
+                nbytes = total * np.dtype(dt).itemsize
+                p = L.vvm_device_alloc(nbytes)
+                assert p, be.error_text()
+                dev_ids.append(p)          # (freed with the other extra allocations)
+                ptrs.append(p)
+                be._check(L.vvm_device_memset(p, out_fill, nbytes), "memset")
+            more_dev.append(ptrs)
+        more_ds = [abi.DataSet([], ptrs, instance_offset, [0, 0, 0], _type_offsets([np.empty(0, dt) for dt in dts])) for ptrs, dts in zip(more_dev, more_datasets)]
         state = be.alloc_state(script.blob)
         try:
-            frame = abi.CallFrame(state, [ds], n, const_tables, ext_fns)
+            frame = abi.CallFrame(state, [ds] + more_ds, n, const_tables, ext_fns)
             opt = abi.ExecOptions(seed, exec_index_base, rand_instance_base, None, flags)
             for _ in range(repeat):
                 be.exec_ex(frame, opt)
             surv = frame.survivors(0)
             info = be.info(state)
+            if more_results is not None:
+                for i, (ptrs, dts) in enumerate(zip(more_dev, more_datasets)):
+                    hs = []
+                    for p, dt in zip(ptrs, dts):
+                        h = np.empty(total, dtype=dt)
+                        be._check(L.vvm_device_download(h.ctypes.data, p, h.nbytes), "download")
+                        hs.append(h)
+                    more_results.append((hs, frame.survivors(1 + i)))
             if ids is not None:
                 ids.read_counters(frame.datasets[0])
                 for a, p in zip((ids.id_table, ids.free_table), dev_ids):
