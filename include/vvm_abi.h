@@ -200,8 +200,14 @@ typedef struct vvm_exec_options {
 } vvm_exec_options;
 
 enum {
-	VVM_EXEC_NO_VGPR_WIDE = 1u << 0   /* force the one-instance-per-lane kernel (debug / comparison) */
+	VVM_EXEC_NO_VGPR_WIDE = 1u << 0,  /* force the one-instance-per-lane kernel (debug / comparison) */
+	/* A plain script (no transcendental / noise / ID instructions, all registers resident) over at least
+	 * VVM_EIGHT_WIDE_MIN_INSTANCES instances runs with eight instances per lane instead of four: half the interpreter
+	 * overhead per instance.  The results are the same either way. */
+	VVM_EXEC_NO_EIGHT_WIDE = 1u << 1,    /* never */
+	VVM_EXEC_FORCE_EIGHT_WIDE = 1u << 2  /* whenever the script allows it, whatever the size (tests) */
 };
+#define VVM_EIGHT_WIDE_MIN_INSTANCES (4 * 1024 * 1024)
 
 /* ---- entry points ---- */
 

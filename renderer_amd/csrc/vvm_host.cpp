@@ -204,6 +204,7 @@ struct PreparedExec {
 	size_t bytes = 0;           // parameter block: desc + consts + in_ptrs + out_ptrs
 	size_t off_consts = 0, off_in = 0, off_load = 0, off_out = 0, off_ids = 0;
 	uint32_t chunk_instances = 0, num_chunks = 0;      // the reference's chunking of this Exec
+	uint32_t instances_per_lane = 4;                   // of the kernel this Exec runs on (8, 4 or 1)
 };
 
 int g_page_kb = 64;      // vm.PageSizeInKB, VectorVMRuntime.cpp:44-50
@@ -284,7 +285,15 @@ int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, P
 		int rc = resolve_maps(st, ctx);
 		if (rc != VVM_OK) return rc;
 	}
-	const uint32_t tile = VVM_BLOCK_THREADS * pe.lp->instances_per_lane;
+	pe.instances_per_lane = pe.lp->instances_per_lane;
+	{
+		// eight instances per lane: the same program, twice the work per interpreted instruction; only worth it when there are
+		// enough tiles left to keep every CU busy for several rounds
+		const uint32_t flags = opt ? opt->Flags : 0;
+		const bool can = pe.lp->instances_per_lane == 4 && !pe.lp->full_kernel && pe.lp->lds_spill_slots == 0 && !(flags & VVM_EXEC_NO_EIGHT_WIDE);
+		if (can && (ctx->NumInstances >= VVM_EIGHT_WIDE_MIN_INSTANCES || (flags & VVM_EXEC_FORCE_EIGHT_WIDE))) pe.instances_per_lane = 8;
+	}
+	const uint32_t tile = VVM_BLOCK_THREADS * pe.instances_per_lane;
 	pe.tiles = ((uint32_t)ctx->NumInstances + tile - 1) / tile;
 	const uint32_t O = std::max<uint32_t>(s.num_outputs_remapped, s.num_output_instructions);
 	pe.off_consts = align_up(sizeof(VvmExecDesc), 16);
@@ -564,7 +573,7 @@ VVM_API int vvm_exec_async(vvm_exec_context* ctx, const vvm_exec_options* opt)
 		if (rc != VVM_OK) return rc;
 		HIP_TRY(hipMemcpyAsync(st->ring.dev[slot], st->ring.host[slot], pe.bytes, hipMemcpyHostToDevice, stream));
 		if (timed && pass == 0) HIP_TRY(hipEventRecord(st->ev_start[st->ev_used], stream));
-		const int lrc = vvm_launch_exec_kernel((int)pe.lp->instances_per_lane, (const VvmExecDesc*)st->ring.dev[slot], 1, pe.tiles, st->d_launch,
+		const int lrc = vvm_launch_exec_kernel((int)pe.instances_per_lane, (const VvmExecDesc*)st->ring.dev[slot], 1, pe.tiles, st->d_launch,
 		                                       pe.lp->lds_spill_slots, pe.lp->full_kernel ? 1 : 0, grid_for(pe.tiles), stream);
 		if (lrc != 0) return hip_fail((hipError_t)lrc, "kernel launch");
 		if (timed && pass + 1 == num_passes) { HIP_TRY(hipEventRecord(st->ev_stop[st->ev_used], stream)); st->ev_used++; }
@@ -664,7 +673,7 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 		const vvm::LinkedProgram& lp = *pes[(size_t)i].lp;
 		if (lp.uses_ids) return fail(VVM_E_UNSUPPORTED_OP, "scripts with update_id / acquire_id cannot be part of a batched Exec");
 		if (lp.num_passes > 1) return fail(VVM_E_UNSUPPORTED_OP, "scripts with acquireindex on several datasets cannot be part of a batched Exec");
-		const int key = (int)lp.instances_per_lane * 4 + (lp.lds_spill_slots ? 2 : 0) + (lp.full_kernel ? 1 : 0);
+		const int key = (int)pes[(size_t)i].instances_per_lane * 4 + (lp.lds_spill_slots ? 2 : 0) + (lp.full_kernel ? 1 : 0);
 		Group* g = nullptr;
 		for (Group& c : groups) if (c.key == key) g = &c;
 		if (!g) { groups.push_back(Group{key, {}, 0, 0}); g = &groups.back(); }
@@ -742,7 +751,7 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 	for (size_t g = 0; g < groups.size(); ++g) {
 		if (groups[g].tiles == 0) continue;
 		const vvm::LinkedProgram& lp = *pes[(size_t)groups[g].members[0]].lp;
-		const int lrc = vvm_launch_exec_kernel((int)lp.instances_per_lane, (const VvmExecDesc*)(g_batch.dev + group_desc_off[g]),
+		const int lrc = vvm_launch_exec_kernel((int)pes[(size_t)groups[g].members[0]].instances_per_lane, (const VvmExecDesc*)(g_batch.dev + group_desc_off[g]),
 		                                       (uint32_t)groups[g].members.size(), groups[g].tiles, g_batch.d_launch[g], groups[g].spill,
 		                                       lp.full_kernel ? 1 : 0, grid_for(groups[g].tiles), g_batch.stream);
 		if (lrc != 0) return hip_fail((hipError_t)lrc, "batched kernel launch");

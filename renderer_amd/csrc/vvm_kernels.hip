@@ -80,6 +80,15 @@ typedef float vec16f __attribute__((ext_vector_type(16)));
 typedef float vec32f __attribute__((ext_vector_type(32)));
 template <int V> struct RegTraits;
 template <> struct RegTraits<4> { typedef vec16f vec; static constexpr uint32_t RV = 16; };
+template <> struct RegTraits<8> { typedef vec16f vec; static constexpr uint32_t RV = 16; };
+
+// Instance slots of a lane.  V = 1: the lane's one instance.  V = 4: four consecutive instances, [4 tid, 4 tid + 4) of the
+// tile.  V = 8: two such groups, the second one VVM_HALF_TILE instances after the first: the tile is two halves of 1024
+// instances, and slots 0..3 / 4..7 of lane `tid` are instances [4 tid, 4 tid + 4) of the first / second half.  Every memory
+// access stays a 128-bit access of four consecutive instances per lane, and instance order is (half, lane, slot).
+#define VVM_HALF_TILE (VVM_BLOCK_THREADS * 4u)
+template <int V> __device__ __forceinline__ constexpr uint32_t lane_stride() { return V == 8 ? 4u : (uint32_t)V; }     // instances between neighbouring lanes
+template <int V> __device__ __forceinline__ constexpr uint32_t slot_offset(int k) { return (V == 8 && k >= 4) ? VVM_HALF_TILE - 4u + (uint32_t)k : (uint32_t)k; }
 template <> struct RegTraits<1> { typedef vec32f vec; static constexpr uint32_t RV = 32; };
 template <typename VEC> __device__ __forceinline__ float vget(VEC v, uint32_t i) { return v[i]; }
 template <typename VEC> __device__ __forceinline__ VEC vset(VEC v, uint32_t i, float x) { v[i] = x; return v; }
@@ -450,8 +459,9 @@ DEV uint32_t wave_sum(uint32_t v)
 
 // ---- per-tile interpreter state ----------------------------------------------------------------------
 #define RVEC typename RegTraits<V>::vec
-#define CREGS RVEC R0, RVEC R1, RVEC R2, RVEC R3
-#define RARGS R0, R1, R2, R3
+// (eight vectors are handed around whatever V is; the ones past V are never touched and cost nothing)
+#define CREGS RVEC R0, RVEC R1, RVEC R2, RVEC R3, RVEC R4, RVEC R5, RVEC R6, RVEC R7
+#define RARGS R0, R1, R2, R3, R4, R5, R6, R7
 
 // (Fields of the Exec descriptor that an instruction needs rarely are read from the descriptor where they are used, with a
 // scalar load: a value kept in a scalar register for the whole tile costs more than the occasional load.)
@@ -480,7 +490,9 @@ template <int V, bool SPILL> DEV void reg_read(CREGS, const Ctx& c, uint32_t idx
 	constexpr uint32_t RV = RegTraits<V>::RV;
 	const uint32_t i = idx & (RV - 1);
 	out[0] = vget(R0, i);
-	if constexpr (V == 4) { out[1] = vget(R1, i); out[2] = vget(R2, i); out[3] = vget(R3, i); }
+	if constexpr (V >= 4) { out[1] = vget(R1, i); out[2] = vget(R2, i); out[3] = vget(R3, i); }
+	if constexpr (V == 8) { out[4] = vget(R4, i); out[5] = vget(R5, i); out[6] = vget(R6, i); out[7] = vget(R7, i); }
+	static_assert(!(SPILL && V == 8), "the eight-instance kernel has no LDS register slots");
 	if constexpr (SPILL) {
 		if (idx >= RV) {
 			const float* p = c.spill + ((idx - RV) * VVM_BLOCK_THREADS + c.tid) * V;
@@ -512,7 +524,8 @@ template <int V, bool SPILL> DEV void reg_spill(const Ctx& c, bool enable, uint3
 #define REG_WRITE_IF(enable, idx, arr) do { \
 		const bool en_ = (enable); const uint32_t idx_ = (idx); \
 		R0 = reg_put<V, SPILL>(R0, en_, idx_, (arr)[0]); \
-		if constexpr (V == 4) { R1 = reg_put<V, SPILL>(R1, en_, idx_, (arr)[1]); R2 = reg_put<V, SPILL>(R2, en_, idx_, (arr)[2]); R3 = reg_put<V, SPILL>(R3, en_, idx_, (arr)[3]); } \
+		if constexpr (V >= 4) { R1 = reg_put<V, SPILL>(R1, en_, idx_, (arr)[1]); R2 = reg_put<V, SPILL>(R2, en_, idx_, (arr)[2]); R3 = reg_put<V, SPILL>(R3, en_, idx_, (arr)[3]); } \
+		if constexpr (V == 8) { R4 = reg_put<V, SPILL>(R4, en_, idx_, (arr)[4]); R5 = reg_put<V, SPILL>(R5, en_, idx_, (arr)[5]); R6 = reg_put<V, SPILL>(R6, en_, idx_, (arr)[6]); R7 = reg_put<V, SPILL>(R7, en_, idx_, (arr)[7]); } \
 		reg_spill<V, SPILL>(c, en_, idx_, (arr)); \
 	} while (0)
 #define REG_WRITE(idx, arr) REG_WRITE_IF(true, idx, arr)
@@ -532,13 +545,17 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #define AUX_AGENT  16                  // sc1: device-scope visibility, what a relaxed agent-scope atomic access uses here
 DEV rsrc_t make_rsrc(uint64_t base, uint32_t num_bytes) { return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)num_bytes, VVM_RSRC_FLAGS); }
 
-// The tile's part of an input stream: lane t reads elements [V*t, V*t + V) of the tile; elements past the Exec's end read 0.
+// The tile's part of an input stream: the lane reads the elements of its instance slots; elements past the Exec's end read 0.
 template <int V> DEV void load_stream32(const Ctx& c, uint64_t base, float (&out)[V])
 {
 	const rsrc_t rs = make_rsrc(base + 4ull * c.tile_first, 4u * c.valid);
-	if constexpr (V == 4) {
+	if constexpr (V >= 4) {
 		const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(c.tid * 16u), 0, AUX_STREAM);
 		out[0] = bitsf(v.x); out[1] = bitsf(v.y); out[2] = bitsf(v.z); out[3] = bitsf(v.w);
+		if constexpr (V == 8) {
+			const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(VVM_HALF_TILE * 4u + c.tid * 16u), 0, AUX_STREAM);
+			out[4] = bitsf(u.x); out[5] = bitsf(u.y); out[6] = bitsf(u.z); out[7] = bitsf(u.w);
+		}
 	} else {
 		out[0] = bitsf(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(c.tid * 4u), 0, AUX_STREAM));
 	}
@@ -548,7 +565,7 @@ template <int V> DEV void load_stream16(const Ctx& c, uint64_t base, float (&out
 	const rsrc_t rs = make_rsrc(base + 2ull * c.tile_first, 2u * c.valid);
 #pragma unroll
 	for (int k = 0; k < V; ++k)
-		out[k] = bitsf((uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)((c.tid * V + k) * 2u), 0, AUX_STREAM));
+		out[k] = bitsf((uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)((c.tid * lane_stride<V>() + slot_offset<V>(k)) * 2u), 0, AUX_STREAM));
 }
 // 64-bit device-scope store by the first lane of the calling wave
 DEV void store_u64_first_lane(gu64* addr, u64 value, uint32_t lane)
@@ -628,42 +645,51 @@ DEV uint32_t look_back(gu64* status, uint32_t tile, uint32_t tag, uint32_t lane,
 }
 
 // LDS control words
-#define LC_WAVE_TOTALS 0      // [2][4]  survivor count of each wave, by parity of the tile
-#define LC_PREFIX      8      // [2]     resolved prefix, by parity of the resolve
-#define LC_TICKET      10     // [2]     claimed ticket, by parity of the tile
-#define LC_STATS       16     // [8]     profiling sums
+#define LC_WAVE_TOTALS 0      // [2][2][4]  survivor count of each wave (per half of the tile), by parity of the tile
+#define LC_PREFIX      16     // [2]     resolved prefix, by parity of the resolve
+#define LC_TICKET      18     // [2]     claimed ticket, by parity of the tile
+#define LC_STATS       24     // [8]     profiling sums
 
 // acquireindex, first half: rank the tile's survivors and publish the tile's count.
 // keep_bits: bit k = instance k of the lane survives.  Returns (rank of the lane's first survivor within the tile, survivors
 // in the tile).  Survivors keep instance order (VectorVMRuntime.cpp:786-804, 824-878): a lane's instances are consecutive,
 // lanes are in instance order, so the rank is the number of surviving instances of all lower lanes and waves.
-DEV uint2 acquire_rank_and_publish(uint32_t keep_bits, const Ctx& c, uint32_t* lds_ctrl, gu64* status, uint32_t tile_local, uint32_t tag, uint32_t dbg)
+// With eight instances per lane the tile's two halves are ranked one after the other (all of the first half's survivors come
+// first): HALVES = 2, bits 0..3 / 4..7 of keep_bits, and .y of the result is the rank of the lane's first survivor of the
+// second half.
+template <int HALVES> DEV uint3 acquire_rank_and_publish(uint32_t keep_bits, const Ctx& c, uint32_t* lds_ctrl, gu64* status, uint32_t tile_local, uint32_t tag, uint32_t dbg)
 {
 	const uint32_t lane = c.tid & 63u;
-	uint32_t below = 0, wave_total = 0;
+	uint32_t below[2] = {0, 0}, wave_total[2] = {0, 0};
 #pragma unroll
-	for (int k = 0; k < 4; ++k) {
-		const u64 b = __ballot((keep_bits >> k) & 1u);
-		below += lanes_below(b);
-		wave_total += (uint32_t)__popcll(b);
-	}
-	uint32_t* totals = lds_ctrl + LC_WAVE_TOTALS + 4u * (c.phase & 1u);
-	totals[c.wave] = wave_total;            // every lane writes the wave's value
+	for (int h = 0; h < HALVES; ++h)
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const u64 b = __ballot((keep_bits >> (4 * h + k)) & 1u);
+			below[h] += lanes_below(b);
+			wave_total[h] += (uint32_t)__popcll(b);
+		}
+	uint32_t* totals = lds_ctrl + LC_WAVE_TOTALS + 8u * (c.phase & 1u);
+	totals[c.wave] = wave_total[0];            // every lane writes the wave's value
+	if constexpr (HALVES == 2) totals[4u + c.wave] = wave_total[1];
 	__syncthreads();                        // (the words alternate between tiles, so one barrier is enough)
-	uint32_t wave_off = 0, total = 0;
+	uint32_t wave_off[2] = {0, 0}, total[2] = {0, 0};
 #pragma unroll
-	for (uint32_t w = 0; w < VVM_BLOCK_THREADS / 64; ++w) {
-		const uint32_t x = totals[w];
-		wave_off += (w < c.wave) ? x : 0u;
-		total += x;
-	}
-	total = SCALAR(total);
+	for (int h = 0; h < HALVES; ++h)
+#pragma unroll
+		for (uint32_t w = 0; w < VVM_BLOCK_THREADS / 64; ++w) {
+			const uint32_t x = totals[4u * h + w];
+			wave_off[h] += (w < c.wave) ? x : 0u;
+			total[h] += x;
+		}
+	const uint32_t total0 = SCALAR(total[0]);
+	const uint32_t all = (HALVES == 2) ? total0 + SCALAR(total[1]) : total0;
 	if (c.wave == 0 && !(tile_local == 0 && (dbg & 4u))) {
 		// the first tile's count is its inclusive prefix already
 		const u64 flag = (tile_local == 0) ? VVM_LB_INCLUSIVE : VVM_LB_AGGREGATE;
-		store_u64_first_lane(status + tile_local, ((u64)tag << 34) | (flag << 32) | total, lane);
+		store_u64_first_lane(status + tile_local, ((u64)tag << 34) | (flag << 32) | all, lane);
 	}
-	return make_uint2(wave_off + below, total);
+	return make_uint3(wave_off[0] + below[0], total0 + wave_off[1] + below[1], all);
 }
 
 // What is left to do for a tile whose program has run: its outputs sit compacted in the LDS staging slots, and its prefix
@@ -775,22 +801,29 @@ template <int V, bool ANY16, bool LAST> DEV void store_slot(uint64_t e, const fl
 	const uint64_t off4 = a.off4;
 	const uint32_t rec4 = a.rec4;
 	const uint64_t ptr = e & VVM_OUT_ADDR_MASK;
-	if (ANY16 && LAST && (e & VVM_OUT_UPDATE_ID)) {
-		apply_update_id<V>((const void*)ptr, q, *a.keep_word, a.tile_first + i0, a.base);
-		return;
+	if constexpr (ANY16 && LAST && V != 8) {
+		if (e & VVM_OUT_UPDATE_ID) {
+			apply_update_id<V>((const void*)ptr, q, *a.keep_word, a.tile_first + i0, a.base);
+			return;
+		}
 	}
 	if (ANY16 && (e & VVM_OUT_IS16)) {       // 16-bit destination, the staged value holds the bits
 		const rsrc_t rs = make_rsrc(ptr + (off4 >> 1), ptr ? (rec4 >> 1) : 0u);
 #pragma unroll
 		for (int k = 0; k < V; ++k)
-			__builtin_amdgcn_raw_buffer_store_b16((uint16_t)fbits(q[k]), rs, (int)((i0 + k) * 2u), 0, AUX_STREAM);
+			__builtin_amdgcn_raw_buffer_store_b16((uint16_t)fbits(q[slot_offset<V>(k)]), rs, (int)((i0 + slot_offset<V>(k)) * 2u), 0, AUX_STREAM);
 		return;
 	}
 	const rsrc_t rs = make_rsrc(ptr + off4, ptr ? rec4 : 0u);
-	if constexpr (V == 4) {
+	if constexpr (V >= 4) {
 		const f4a x = *(const f4a*)q;
 		u32x4 y; y.x = fbits(x.x); y.y = fbits(x.y); y.z = fbits(x.z); y.w = fbits(x.w);
 		__builtin_amdgcn_raw_buffer_store_b128(y, rs, (int)(i0 * 4u), 0, AUX_STREAM);
+		if constexpr (V == 8) {
+			const f4a x2 = *(const f4a*)(q + VVM_HALF_TILE);
+			u32x4 y2; y2.x = fbits(x2.x); y2.y = fbits(x2.y); y2.z = fbits(x2.z); y2.w = fbits(x2.w);
+			__builtin_amdgcn_raw_buffer_store_b128(y2, rs, (int)((VVM_HALF_TILE + i0) * 4u), 0, AUX_STREAM);
+		}
 	} else {
 		__builtin_amdgcn_raw_buffer_store_b32(fbits(q[0]), rs, (int)(i0 * 4u), 0, AUX_STREAM);
 	}
@@ -821,7 +854,7 @@ template <int V, bool FULL> DEV void store_tile(Pending& p, const Ctx& c, unsign
 		uint64_t entry[VVM_STAGE_SLOTS];
 		sload64x8(p.out_list, STAGED_FIRST(p.stage_end), entry);
 		StoreArgs a;
-		a.i0 = c.tid * V; a.off4 = 4ull * p.base; a.rec4 = 4u * p.total; a.base = p.base; a.tile_first = p.tile_local * (VVM_BLOCK_THREADS * V);
+		a.i0 = c.tid * lane_stride<V>(); a.off4 = 4ull * p.base; a.rec4 = 4u * p.total; a.base = p.base; a.tile_first = p.tile_local * (VVM_BLOCK_THREADS * V);
 		a.keep_word = (const uint32_t*)(lds + LDS_STAGE_KEEP_OFF(V)) + c.tid;
 		const float* src = (const float*)(lds + LDS_STAGE_OFF) + a.i0;
 		if (entry[0] & VVM_OUT_GROUP16) store_slots<V, true, FULL>(entry, n_staged, src, a);
@@ -878,10 +911,10 @@ template <int V, bool SPILL, bool FULL>
 DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c, unsigned char* lds, uint32_t tile_local, uint32_t tag, VvmLaunchState* ls, uint32_t dbg, Pending& pend,
                   uint32_t& resolves, const u64 (&pre)[VVM_LB_WORDS_PER_LANE], bool have_pre)
 {
-	RVEC R0 = 0.0f, R1 = 0.0f, R2 = 0.0f, R3 = 0.0f;
+	RVEC R0 = 0.0f, R1 = 0.0f, R2 = 0.0f, R3 = 0.0f, R4 = 0.0f, R5 = 0.0f, R6 = 0.0f, R7 = 0.0f;
 	uint32_t* lds_ctrl = (uint32_t*)lds;
 	// acquireindex state of the tile: all wave-uniform except keep and rank
-	uint32_t t_keep = 0, t_rank = 0;
+	uint32_t t_keep = 0, t_rank = 0, t_rank_b = 0;      // (t_rank_b: the second half of an eight-instance tile)
 	uint32_t t_total = 0, t_base = 0;
 	bool t_pending = false;          // the tile's count is published, its prefix not yet resolved
 	uint32_t stage_end = 0;          // output-list index one past the last slot this tile has staged (0: nothing staged)
@@ -1128,12 +1161,12 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 			case VVM_OP_select_add: SETF(f_sel(A, B, C) + D);
 			case VVM_OP_sin_cos: if constexpr (FULL) { _Pragma("unroll") LANES { float sn, cs; f_sincos(A, sn, cs); r[k] = aux ? cs : sn; } } break;   // aux: 0 sine, 1 cosine
 			case VVM_OP_half_to_float: SETF(load_half(UA));             // RT.cpp:1113-1127
-			case VVM_OP_exec_index: SETI(DESC_U32(c.dp, exec_index_base) + inst_i + k);                       // RT.cpp:880-900
-			case VVM_OP_exec_indexf: SETF(i2f((int32_t)(DESC_U32(c.dp, exec_index_base) + inst_i + k)));      // RT.cpp:902-923
-			case VVM_OP_exec_index_addi: SETI(DESC_U32(c.dp, exec_index_base) + inst_i + k + UA);             // RT.cpp:925-951
+			case VVM_OP_exec_index: SETI(DESC_U32(c.dp, exec_index_base) + inst_i + slot_offset<V>(k));                       // RT.cpp:880-900
+			case VVM_OP_exec_indexf: SETF(i2f((int32_t)(DESC_U32(c.dp, exec_index_base) + inst_i + slot_offset<V>(k))));      // RT.cpp:902-923
+			case VVM_OP_exec_index_addi: SETI(DESC_U32(c.dp, exec_index_base) + inst_i + slot_offset<V>(k) + UA);             // RT.cpp:925-951
 			// aux2 = ordinal of the random op within the script
-			case VVM_OP_random: SETF(rand01(rand_u32(DESC_U32(c.dp, rand_seed_lo), DESC_U32(c.dp, rand_seed_hi), DESC_U32(c.dp, rand_instance_base) + inst_i + k, aux2)) * A);
-			case VVM_OP_randomi: SETI(cvtt(rand01(rand_u32(DESC_U32(c.dp, rand_seed_lo), DESC_U32(c.dp, rand_seed_hi), DESC_U32(c.dp, rand_instance_base) + inst_i + k, aux2)) * i2f(IA)));
+			case VVM_OP_random: SETF(rand01(rand_u32(DESC_U32(c.dp, rand_seed_lo), DESC_U32(c.dp, rand_seed_hi), DESC_U32(c.dp, rand_instance_base) + inst_i + slot_offset<V>(k), aux2)) * A);
+			case VVM_OP_randomi: SETI(cvtt(rand01(rand_u32(DESC_U32(c.dp, rand_seed_lo), DESC_U32(c.dp, rand_seed_hi), DESC_U32(c.dp, rand_instance_base) + inst_i + slot_offset<V>(k), aux2)) * i2f(IA)));
 			case VVM_OP_acquire_id: if constexpr (FULL) {
 				// VectorVMRuntime.cpp:1404-1440.  Instance g of the Exec takes FreeIDTable[NumFreeIDs - 1 - g]: each chunk pops its
 				// IDs from the end of the free list, reversed (:1417-1421), and the chunks pop in order.  The IDs are also logged as
@@ -1149,7 +1182,7 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 					const uint32_t num_free = sload32(idp, offsetof(VvmIdDesc, num_free_start) / 4), num_spawned = sload32(idp, offsetof(VvmIdDesc, num_spawned_start) / 4);
 					const uint32_t chunk = sload32(idp, offsetof(VvmIdDesc, chunk_instances) / 4);
 					_Pragma("unroll") LANES {
-						const uint32_t g = inst_i + (uint32_t)k;
+						const uint32_t g = inst_i + slot_offset<V>(k);
 						const uint32_t ok = (uint32_t)(g < c.num_instances) & (uint32_t)(g < num_free);
 						const uint32_t id = __builtin_amdgcn_raw_buffer_load_b32(rs_free, (int)(ok ? (num_free - 1u - g) * 4u : VVM_RSRC_NOWHERE), 0, 0);
 						const uint32_t ci = g / chunk;
@@ -1161,7 +1194,7 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 					}
 				}
 			} break;
-			case VVM_OP_random_add: SETF(rand01(rand_u32(DESC_U32(c.dp, rand_seed_lo), DESC_U32(c.dp, rand_seed_hi), DESC_U32(c.dp, rand_instance_base) + inst_i + k, aux2)) * A + B);
+			case VVM_OP_random_add: SETF(rand01(rand_u32(DESC_U32(c.dp, rand_seed_lo), DESC_U32(c.dp, rand_seed_hi), DESC_U32(c.dp, rand_instance_base) + inst_i + slot_offset<V>(k), aux2)) * A + B);
 			case VVM_OP_external_func_call:
 				// aux = built-in id, aux2 = which output this device instruction produces (VectorVMRuntime.cpp:1450-1464 lists the
 				// operands as inputs then outputs; the linker emits one instruction per output in use)
@@ -1198,9 +1231,9 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 			uint32_t kb = 0;
 #pragma unroll
 			for (int k = 0; k < V; ++k)
-				kb |= ((fbits(p[k]) >> 31) & ((c.inst0 + k < c.num_instances) ? 1u : 0u)) << k;
-			const uint2 rt = acquire_rank_and_publish(kb, c, lds_ctrl, status, tile_local, tag, dbg);
-			t_keep = kb; t_rank = rt.x; t_total = SCALAR(rt.y); t_pending = true;
+				kb |= ((fbits(p[k]) >> 31) & ((c.inst0 + slot_offset<V>(k) < c.num_instances) ? 1u : 0u)) << k;
+			const uint3 rt = acquire_rank_and_publish<(V == 8 ? 2 : 1)>(kb, c, lds_ctrl, status, tile_local, tag, dbg);
+			t_keep = kb; t_rank = rt.x; t_rank_b = rt.y; t_total = SCALAR(rt.z); t_pending = true;
 		}
 		// The previous tile is finished here: after this tile has published its own count (every later tile's look-back waits
 		// for that word, so it goes out first), and before this tile needs the staging slots.  The first poll of the previous
@@ -1227,18 +1260,18 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 			continue;
 		}
 
-		if (FULL && op == VVM_DOP_UPDATE_ID) {
+		if (FULL && V != 8 && op == VVM_DOP_UPDATE_ID) {
 			// the ID register of every instance of the tile goes to a staging slot as it is, with the lane's acquireindex result
 			// next to it; apply_update_id does the rest once the tile's output position is known
 			const uint32_t slot_index = o4 | (o5 << 16);
 			float v[V];
 			fetch<V, SPILL>(RARGS, uni, c, o0, v);
 			float* slot = (float*)(lds + LDS_STAGE_OFF) + (slot_index & (VVM_STAGE_SLOTS - 1u)) * (VVM_BLOCK_THREADS * V) + c.tid * V;
-			if constexpr (V == 4) { f4a x; x.x = v[0]; x.y = v[1]; x.z = v[2]; x.w = v[3]; *(f4a*)slot = x; }
+			if constexpr (V >= 4) { f4a x; x.x = v[0]; x.y = v[1]; x.z = v[2]; x.w = v[3]; *(f4a*)slot = x; }
 			else slot[0] = v[0];
 			uint32_t exists = 0;
 #pragma unroll
-			for (int k = 0; k < V; ++k) exists |= ((c.inst0 + k < c.num_instances) ? 1u : 0u) << k;
+			for (int k = 0; k < V; ++k) exists |= ((c.inst0 + slot_offset<V>(k) < c.num_instances) ? 1u : 0u) << k;
 			((uint32_t*)(lds + LDS_STAGE_KEEP_OFF(V)))[c.tid] = t_rank | (t_keep << 16) | (exists << 24);
 			stage_end = max(stage_end, slot_index + 1u);      // (the group's last slot: outputs staged after this one lie below it)
 			continue;
@@ -1268,13 +1301,15 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 					}
 				}
 				if (all_alive) {
-					if constexpr (V == 4) { f4a x; x.x = v[0]; x.y = v[1]; x.z = v[2]; x.w = v[3]; *(f4a*)(slot + c.tid * 4) = x; }
+					if constexpr (V >= 4) { f4a x; x.x = v[0]; x.y = v[1]; x.z = v[2]; x.w = v[3]; *(f4a*)(slot + c.tid * 4) = x; }
 					else slot[c.tid] = v[0];
+					if constexpr (V == 8) { f4a x; x.x = v[4]; x.y = v[5]; x.z = v[6]; x.w = v[7]; *(f4a*)(slot + VVM_HALF_TILE + c.tid * 4) = x; }
 				} else {
 					// survivor j of the lane goes to rank + j; a dead instance's value goes to the thread's sink dword (no per-lane branch)
 					uint32_t r = t_rank;
 #pragma unroll
 					for (int k = 0; k < V; ++k) {
+						if (V == 8 && k == 4) r = t_rank_b;
 						const bool keep = (t_keep >> k) & 1u;
 						float* q = keep ? (slot + r) : sink;
 						*q = v[k];
@@ -1298,7 +1333,7 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 
 // DBG: the bring-up switches of KernelEnv::debug_skip are compiled in (one instantiation only); otherwise they cost nothing.
 template <int V, bool SPILL, bool FULL, bool DBG = false>
-__global__ void __launch_bounds__(VVM_BLOCK_THREADS, (FULL ? 3 : (V == 4 ? 4 : 8))) vvm_exec_kernel(KernelEnv env)
+__global__ void __launch_bounds__(VVM_BLOCK_THREADS, (V == 8 ? 2 : FULL ? 3 : (V == 4 ? 4 : 8))) vvm_exec_kernel(KernelEnv env)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	const uint32_t dbgw = DBG ? env.debug_skip : 0u;
@@ -1370,7 +1405,7 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (FULL ? 3 : (V == 4 ? 4 : 8
 		Ctx c;
 		c.dp = dp; c.consts = (const uint32_t*)DESC_PTR(dp, consts); c.out_list = (const uint64_t*)DESC_PTR(dp, out_list);
 		c.perlin_lds = lds_perlin; c.spill = lds_spill; c.tid = tid; c.wave = wave;
-		c.inst0 = tile_first + tid * V;
+		c.inst0 = tile_first + tid * lane_stride<V>();
 		c.num_instances = num_instances;
 		c.tile_first = tile_first;
 		c.valid = min(num_instances - tile_first, (uint32_t)(VVM_BLOCK_THREADS * V));
@@ -1439,14 +1474,19 @@ extern "C" int vvm_launch_exec_kernel(int instances_per_lane, const VvmExecDesc*
 	KernelEnv env;
 	env.descs = descs; env.num_execs = num_execs; env.total_tiles = total_tiles; env.ls = ls; env.lds_spill_slots = lds_spill_slots;
 	{ const char* dbg = getenv("VVM_DEBUG_SKIP"); env.debug_skip = dbg ? (uint32_t)strtoul(dbg, nullptr, 0) : 0u; }
-	const size_t lds_bytes = (instances_per_lane == 4 ? LDS_SPILL_OFF(4) : LDS_SPILL_OFF(1)) + (size_t)lds_spill_slots * VVM_BLOCK_THREADS * 4u * (size_t)instances_per_lane;
+	const size_t lds_bytes = (instances_per_lane == 8 ? LDS_SPILL_OFF(8) : instances_per_lane == 4 ? LDS_SPILL_OFF(4) : LDS_SPILL_OFF(1)) +
+	                         (size_t)lds_spill_slots * VVM_BLOCK_THREADS * 4u * (size_t)instances_per_lane;
 	const bool spill = lds_spill_slots > 0;
 #ifdef VVM_EXPERIMENT_ONE_KERNEL
 	(void)spill; (void)full; hipLaunchKernelGGL((vvm_exec_kernel<VVM_EXPERIMENT_ONE_KERNEL>), dim3(grid), dim3(VVM_BLOCK_THREADS), lds_bytes, stream, env);
 	return (int)hipGetLastError();
 #else
 #define VVM_LAUNCH(V, S, F) hipLaunchKernelGGL((vvm_exec_kernel<V, S, F>), dim3(grid), dim3(VVM_BLOCK_THREADS), lds_bytes, stream, env)
-	if (instances_per_lane == 4) {
+	if (instances_per_lane == 8) {
+		if (full || spill) return (int)hipErrorInvalidValue;      // (eight instances per lane: plain scripts only)
+		if (env.debug_skip) hipLaunchKernelGGL((vvm_exec_kernel<8, false, false, true>), dim3(grid), dim3(VVM_BLOCK_THREADS), lds_bytes, stream, env);
+		else VVM_LAUNCH(8, false, false);
+	} else if (instances_per_lane == 4) {
 		if (full) { if (spill) VVM_LAUNCH(4, true, true); else VVM_LAUNCH(4, false, true); }
 		else if (spill) VVM_LAUNCH(4, true, false);
 		else if (env.debug_skip) hipLaunchKernelGGL((vvm_exec_kernel<4, false, false, true>), dim3(grid), dim3(VVM_BLOCK_THREADS), lds_bytes, stream, env);
@@ -1469,6 +1509,8 @@ extern "C" int vvm_kernel_max_dynamic_lds(void)
 		(void)hipFuncSetAttribute((const void*)vvm_exec_kernel<1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
 		(void)hipFuncSetAttribute((const void*)vvm_exec_kernel<4, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
 		(void)hipFuncSetAttribute((const void*)vvm_exec_kernel<1, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+		(void)hipFuncSetAttribute((const void*)vvm_exec_kernel<8, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+		(void)hipFuncSetAttribute((const void*)vvm_exec_kernel<8, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
 		done = 1;
 	}
 #endif
