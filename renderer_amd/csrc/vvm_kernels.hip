@@ -991,16 +991,6 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 			const uint32_t dst = o5;
 			uint32_t inst_i = c.inst0;
 			asm volatile("" : "+v"(inst_i));
-			// operands an instruction does not have hold an arbitrary value; saying so explicitly keeps them from becoming values
-			// carried around the interpreter loop
-			float a[V], b[V], cc[V], dd[V], ee[V];
-#pragma unroll
-			for (int k = 0; k < V; ++k) { a[k] = __builtin_nondeterministic_value(0.0f); b[k] = a[k]; cc[k] = a[k]; dd[k] = a[k]; ee[k] = a[k]; }
-			if (nin > 0) fetch<V, SPILL>(RARGS, uni, c, o0, a);
-			if (nin > 1) fetch<V, SPILL>(RARGS, uni, c, o1, b);
-			if (nin > 2) fetch<V, SPILL>(RARGS, uni, c, o2, cc);
-			if (nin > 3) { fetch<V, SPILL>(RARGS, uni, c, o3, dd); if (nin > 4) fetch<V, SPILL>(RARGS, uni, c, o4, ee); }
-
 #define LANES for (int k = 0; k < V; ++k)
 #define A a[k]
 #define B b[k]
@@ -1016,194 +1006,245 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 #define SETF(expr) { _Pragma("unroll") LANES r[k] = (expr); } break
 #define SETI(expr) { _Pragma("unroll") LANES r[k] = bitsf((uint32_t)(expr)); } break
 #define SETM(expr) { _Pragma("unroll") LANES r[k] = mask(expr); } break
-			switch (op) {
-			case VVM_OP_add: SETF(A + B);
-			case VVM_OP_sub: SETF(A - B);
-			case VVM_OP_mul: SETF(A * B);
-			case VVM_OP_div: SETF(f_div(A, B));
-			case VVM_OP_mad: SETF(f_mad(A, B, C));
-			case VVM_OP_lerp: SETF(f_lerp(A, B, C));
-			case VVM_OP_rcp: SETF(f_rcp(A));
-			case VVM_OP_rsq: SETF(f_rsq(A));
-			case VVM_OP_sqrt: SETF(f_sqrtg(A));
-			case VVM_OP_neg: SETF(f_neg(A));
-			case VVM_OP_abs: SETF(f_abs(A));
-			case VVM_OP_exp: if constexpr (FULL) SETF(mf_exp(A));
-			case VVM_OP_exp2: if constexpr (FULL) SETF(lib_exp2(A));
-			case VVM_OP_log: if constexpr (FULL) SETF(f_log(A));
-			case VVM_OP_log2: if constexpr (FULL) SETF(lib_log2(A));
-			case VVM_OP_sin: if constexpr (FULL) SETF(mf_sin(A));
-			case VVM_OP_cos: if constexpr (FULL) SETF(mf_cos(A));
-			case VVM_OP_tan: if constexpr (FULL) SETF(lib_tan(A));
-			case VVM_OP_asin: if constexpr (FULL) SETF(f_asin(A));
-			case VVM_OP_acos: if constexpr (FULL) SETF(f_acos(A));
-			case VVM_OP_atan: if constexpr (FULL) SETF(lib_atan(A));
-			case VVM_OP_atan2: if constexpr (FULL) SETF(ue_atan2(A, B));
-			case VVM_OP_ceil: SETF(ceilf(A));
-			case VVM_OP_floor: SETF(floorf(A));
-			case VVM_OP_fmod: if constexpr (FULL) SETF(f_fmod(A, B));
-			case VVM_OP_frac: SETF(f_frac(A));
-			case VVM_OP_trunc: SETF(truncf(A));
-			case VVM_OP_clamp: SETF(f_clamp(A, B, C));
-			case VVM_OP_min: SETF(f_min(A, B));
-			case VVM_OP_max: SETF(f_max(A, B));
-			case VVM_OP_pow: if constexpr (FULL) SETF(f_pow(A, B));
-			case VVM_OP_round: SETF(rintf(A));                         // SSE.h:2819-2822 (nearest even)
-			case VVM_OP_sign: SETF(f_sign(A));
-			case VVM_OP_step: SETF(f_step(B - A));                     // RT.cpp:1939
-			case VVM_OP_cmplt: SETM(A < B);
-			case VVM_OP_cmple: SETM(A <= B);
-			case VVM_OP_cmpgt: SETM(A > B);
-			case VVM_OP_cmpge: SETM(A >= B);
-			case VVM_OP_cmpeq: SETM(A == B);
-			case VVM_OP_cmpneq: SETM(A != B);
-			case VVM_OP_select: SETF(f_sel(A, B, C));
-			case VVM_OP_addi: SETI(UA + UB);
-			case VVM_OP_subi: SETI(UA - UB);
-			case VVM_OP_muli: SETI(UA * UB);
-			case VVM_OP_divi: SETI(i_div(IA, IB));
-			case VVM_OP_clampi: SETI(i_min(i_max(IA, IB), IC));
-			case VVM_OP_mini: SETI(i_min(IA, IB));
-			case VVM_OP_maxi: SETI(i_max(IA, IB));
-			case VVM_OP_absi: SETI(i_abs(IA));
-			case VVM_OP_negi: SETI(0u - UA);
-			case VVM_OP_signi: SETI(IA >= 0 ? 1 : -1);
-			case VVM_OP_cmplti: SETM(IA < IB);
-			case VVM_OP_cmplei: SETM(IA <= IB);
-			case VVM_OP_cmpgti: SETM(IA > IB);
-			case VVM_OP_cmpgei: SETM(IA >= IB);
-			case VVM_OP_cmpeqi: SETM(IA == IB);
-			case VVM_OP_cmpneqi: SETM(IA != IB);
-			case VVM_OP_bit_and: case VVM_OP_logic_and: SETI(UA & UB);
-			case VVM_OP_bit_or: case VVM_OP_logic_or: SETI(UA | UB);
-			case VVM_OP_bit_xor: case VVM_OP_logic_xor: SETI(UA ^ UB);
-			case VVM_OP_bit_not: case VVM_OP_logic_not: SETI(~UA);
-			case VVM_OP_bit_lshift: SETI(i_shl(UA, UB));
-			case VVM_OP_bit_rshift: SETI(i_shr(UA, UB));
-			case VVM_OP_f2i: SETI(cvtt(A));
-			case VVM_OP_i2f: SETF(i2f(IA));
-			case VVM_OP_f2b: SETM(A > 0.0f);
-			case VVM_OP_b2f: SETF(f_sel(A, 1.0f, 0.0f));
-			case VVM_OP_i2b: SETM(IA > 0);
-			case VVM_OP_b2i: SETI(UA & 1u);
-			// merged ops, VectorVMRuntime.cpp:1999-2074
-			case VVM_OP_cmplt_select: SETF(f_sel(mask(A < B), C, D));
-			case VVM_OP_cmple_select: SETF(f_sel(mask(A <= B), C, D));
-			case VVM_OP_cmpeq_select: SETF(f_sel(mask(A == B), C, D));
-			case VVM_OP_cmplti_select: SETF(f_sel(mask(IA < IB), C, D));
-			case VVM_OP_cmplei_select: SETF(f_sel(mask(IA <= IB), C, D));
-			case VVM_OP_cmpeqi_select: SETF(f_sel(mask(IA == IB), C, D));
-			case VVM_OP_cmplt_logic_and: SETI((A < B ? ~0u : 0u) & UC);
-			case VVM_OP_cmple_logic_and: SETI((A <= B ? ~0u : 0u) & UC);
-			case VVM_OP_cmpgt_logic_and: SETI((A > B ? ~0u : 0u) & UC);
-			case VVM_OP_cmpge_logic_and: SETI((A >= B ? ~0u : 0u) & UC);
-			case VVM_OP_cmpeq_logic_and: SETI((A == B ? ~0u : 0u) & UC);
-			case VVM_OP_cmpne_logic_and: SETI((A != B ? ~0u : 0u) & UC);
-			case VVM_OP_cmplti_logic_and: SETI((IA < IB ? ~0u : 0u) & UC);
-			case VVM_OP_cmplei_logic_and: SETI((IA <= IB ? ~0u : 0u) & UC);
-			case VVM_OP_cmpgti_logic_and: SETI((IA > IB ? ~0u : 0u) & UC);
-			case VVM_OP_cmpgei_logic_and: SETI((IA >= IB ? ~0u : 0u) & UC);
-			case VVM_OP_cmpeqi_logic_and: SETI((IA == IB ? ~0u : 0u) & UC);
-			case VVM_OP_cmpnei_logic_and: SETI((IA != IB ? ~0u : 0u) & UC);
-			case VVM_OP_cmplt_logic_or: SETI((A < B ? ~0u : 0u) | UC);
-			case VVM_OP_cmple_logic_or: SETI((A <= B ? ~0u : 0u) | UC);
-			case VVM_OP_cmpgt_logic_or: SETI((A > B ? ~0u : 0u) | UC);
-			case VVM_OP_cmpge_logic_or: SETI((A >= B ? ~0u : 0u) | UC);
-			case VVM_OP_cmpeq_logic_or: SETI((A == B ? ~0u : 0u) | UC);
-			case VVM_OP_cmpne_logic_or: SETI((A != B ? ~0u : 0u) | UC);
-			case VVM_OP_cmplti_logic_or: SETI((IA < IB ? ~0u : 0u) | UC);
-			case VVM_OP_cmplei_logic_or: SETI((IA <= IB ? ~0u : 0u) | UC);
-			case VVM_OP_cmpgti_logic_or: SETI((IA > IB ? ~0u : 0u) | UC);
-			case VVM_OP_cmpgei_logic_or: SETI((IA >= IB ? ~0u : 0u) | UC);
-			case VVM_OP_cmpeqi_logic_or: SETI((IA == IB ? ~0u : 0u) | UC);
-			case VVM_OP_cmpnei_logic_or: SETI((IA != IB ? ~0u : 0u) | UC);
-			case VVM_OP_mad_add: SETF(f_mad(A, B, C) + D);
-			case VVM_OP_mad_sub0: SETF(f_mad(A, B, C) - D);
-			case VVM_OP_mad_sub1: SETF(D - f_mad(A, B, C));
-			case VVM_OP_mad_mul: SETF(f_mad(A, B, C) * D);
-			case VVM_OP_mad_sqrt: SETF(ieee_sqrt(f_mad(A, B, C)));      // unguarded, RT.cpp:2033
-			case VVM_OP_mad_mad0: SETF(f_mad(D, E, f_mad(A, B, C)));
-			case VVM_OP_mad_mad1: SETF(f_mad(f_mad(A, B, C), D, E));
-			case VVM_OP_mul_mad0: SETF(f_mad(A * B, C, D));
-			case VVM_OP_mul_mad1: SETF(f_mad(C, D, A * B));
-			case VVM_OP_mul_add: SETF((A * B) + C);
-			case VVM_OP_mul_sub0: SETF((A * B) - C);
-			case VVM_OP_mul_sub1: SETF(C - (A * B));
-			case VVM_OP_mul_mul: SETF((A * B) * C);
-			case VVM_OP_mul_max: SETF(f_max(A * B, C));
-			case VVM_OP_add_mad1: SETF(f_mad(C, D, A + B));
-			case VVM_OP_add_add: SETF((A + B) + C);
-			case VVM_OP_sub_cmplt1: SETM(C < (A - B));
-			case VVM_OP_sub_neg: SETF(f_neg(A - B));
-			case VVM_OP_sub_mul: SETF((A - B) * C);
-			case VVM_OP_div_mad0: SETF(f_mad(f_div(A, B), C, D));
-			case VVM_OP_div_f2i: SETI(cvtt(f_div(A, B)));
-			case VVM_OP_div_mul: SETF(f_div(A, B) * C);
-			case VVM_OP_muli_addi: SETI(UA * UB + UC);
-			case VVM_OP_addi_bit_rshift: SETI(i_shr(UA + UB, UC));
-			case VVM_OP_addi_muli: SETI((UA + UB) * UC);
-			case VVM_OP_i2f_div0: SETF(f_div(i2f(IA), B));
-			case VVM_OP_i2f_div1: SETF(f_div(B, i2f(IA)));
-			case VVM_OP_i2f_mul: SETF(i2f(IA) * B);
-			case VVM_OP_i2f_mad0: SETF(f_mad(i2f(IA), B, C));
-			case VVM_OP_i2f_mad1: SETF(f_mad(A, B, i2f(IC)));
-			case VVM_OP_f2i_select1: SETI((UA & (uint32_t)cvtt(B)) | (~UA & UC));
-			case VVM_OP_f2i_maxi: SETI(i_max(cvtt(A), IB));
-			case VVM_OP_f2i_addi: SETI((uint32_t)cvtt(A) + UB);
-			case VVM_OP_fmod_add: if constexpr (FULL) SETF(f_fmod(A, B) + C);
-			case VVM_OP_bit_and_i2f: SETF(i2f((int32_t)(UA & UB)));
-			case VVM_OP_bit_rshift_bit_and: SETI(i_shr(UA, UB) & UC);
-			case VVM_OP_neg_cmplt: SETM(f_neg(A) < B);
-			case VVM_OP_bit_or_muli: SETI((UA | UB) * UC);
-			case VVM_OP_bit_lshift_bit_or: SETI(i_shl(UA, UB) | UC);
-			case VVM_OP_max_f2i: SETI(cvtt(f_max(A, B)));
-			case VVM_OP_select_mul: SETF(f_sel(A, B, C) * D);
-			case VVM_OP_select_add: SETF(f_sel(A, B, C) + D);
-			case VVM_OP_sin_cos: if constexpr (FULL) { _Pragma("unroll") LANES { float sn, cs; f_sincos(A, sn, cs); r[k] = aux ? cs : sn; } } break;   // aux: 0 sine, 1 cosine
-			case VVM_OP_half_to_float: SETF(load_half(UA));             // RT.cpp:1113-1127
-			case VVM_OP_exec_index: SETI(DESC_U32(c.dp, exec_index_base) + inst_i + slot_offset<V>(k));                       // RT.cpp:880-900
-			case VVM_OP_exec_indexf: SETF(i2f((int32_t)(DESC_U32(c.dp, exec_index_base) + inst_i + slot_offset<V>(k))));      // RT.cpp:902-923
-			case VVM_OP_exec_index_addi: SETI(DESC_U32(c.dp, exec_index_base) + inst_i + slot_offset<V>(k) + UA);             // RT.cpp:925-951
-			// aux2 = ordinal of the random op within the script
-			case VVM_OP_random: SETF(rand01(rand_u32(DESC_U32(c.dp, rand_seed_lo), DESC_U32(c.dp, rand_seed_hi), DESC_U32(c.dp, rand_instance_base) + inst_i + slot_offset<V>(k), aux2)) * A);
-			case VVM_OP_randomi: SETI(cvtt(rand01(rand_u32(DESC_U32(c.dp, rand_seed_lo), DESC_U32(c.dp, rand_seed_hi), DESC_U32(c.dp, rand_instance_base) + inst_i + slot_offset<V>(k), aux2)) * i2f(IA)));
-			case VVM_OP_acquire_id: if constexpr (FULL) {
-				// VectorVMRuntime.cpp:1404-1440.  Instance g of the Exec takes FreeIDTable[NumFreeIDs - 1 - g]: each chunk pops its
-				// IDs from the end of the free list, reversed (:1417-1421), and the chunks pop in order.  The IDs are also logged as
-				// spawned: chunk c's, in instance order, at FreeIDTable[Max - (NumSpawnedIDs + instances up to the end of chunk c)]
-				// (:1429-1432).  aux 1 is the instruction's second destination, the tag (:1435).
-				const void* idp = (const void*)DESC_PTR(c.dp, ids);
-				if (aux == 1) {
-					const uint32_t tag_value = sload32(idp, offsetof(VvmIdDesc, acquire_tag) / 4);
-					_Pragma("unroll") LANES r[k] = bitsf(tag_value);
-				} else {
-					const uint32_t table_max = sload32(idp, offsetof(VvmIdDesc, free_table_max) / 4);
-					const rsrc_t rs_free = make_rsrc(sload64(idp, offsetof(VvmIdDesc, free_table) / 8), 4u * table_max);
-					const uint32_t num_free = sload32(idp, offsetof(VvmIdDesc, num_free_start) / 4), num_spawned = sload32(idp, offsetof(VvmIdDesc, num_spawned_start) / 4);
-					const uint32_t chunk = sload32(idp, offsetof(VvmIdDesc, chunk_instances) / 4);
-					_Pragma("unroll") LANES {
-						const uint32_t g = inst_i + slot_offset<V>(k);
-						const uint32_t ok = (uint32_t)(g < c.num_instances) & (uint32_t)(g < num_free);
-						const uint32_t id = __builtin_amdgcn_raw_buffer_load_b32(rs_free, (int)(ok ? (num_free - 1u - g) * 4u : VVM_RSRC_NOWHERE), 0, 0);
-						const uint32_t ci = g / chunk;
-						const uint32_t chunk_end = min(c.num_instances, (ci + 1u) * chunk);
-						uint32_t pos = table_max - (num_spawned + chunk_end) + (g - ci * chunk);
-						asm volatile("" : "+v"(pos));      // computed for every lane, then selected: otherwise the division ends up behind a per-lane branch
-						__builtin_amdgcn_raw_buffer_store_b32(id, rs_free, (int)(ok ? pos * 4u : VVM_RSRC_NOWHERE), 0, 0);
-						r[k] = bitsf(id);
+			// One group of cases per operand count: the operands an instruction has are fetched, no others exist (a common fetch
+			// sequence in front of one big switch leaves the compiler with placeholder values to materialize for the missing ones).
+			switch (nin) {
+			case 0: {
+				switch (op) {
+				case VVM_OP_exec_index: SETI(DESC_U32(c.dp, exec_index_base) + inst_i + slot_offset<V>(k));                       // RT.cpp:880-900
+				case VVM_OP_exec_indexf: SETF(i2f((int32_t)(DESC_U32(c.dp, exec_index_base) + inst_i + slot_offset<V>(k))));      // RT.cpp:902-923
+				case VVM_OP_acquire_id: if constexpr (FULL) {
+					// VectorVMRuntime.cpp:1404-1440.  Instance g of the Exec takes FreeIDTable[NumFreeIDs - 1 - g]: each chunk pops its
+					// IDs from the end of the free list, reversed (:1417-1421), and the chunks pop in order.  The IDs are also logged as
+					// spawned: chunk c's, in instance order, at FreeIDTable[Max - (NumSpawnedIDs + instances up to the end of chunk c)]
+					// (:1429-1432).  aux 1 is the instruction's second destination, the tag (:1435).
+					const void* idp = (const void*)DESC_PTR(c.dp, ids);
+					if (aux == 1) {
+						const uint32_t tag_value = sload32(idp, offsetof(VvmIdDesc, acquire_tag) / 4);
+						_Pragma("unroll") LANES r[k] = bitsf(tag_value);
+					} else {
+						const uint32_t table_max = sload32(idp, offsetof(VvmIdDesc, free_table_max) / 4);
+						const rsrc_t rs_free = make_rsrc(sload64(idp, offsetof(VvmIdDesc, free_table) / 8), 4u * table_max);
+						const uint32_t num_free = sload32(idp, offsetof(VvmIdDesc, num_free_start) / 4), num_spawned = sload32(idp, offsetof(VvmIdDesc, num_spawned_start) / 4);
+						const uint32_t chunk = sload32(idp, offsetof(VvmIdDesc, chunk_instances) / 4);
+						_Pragma("unroll") LANES {
+							const uint32_t g = inst_i + slot_offset<V>(k);
+							const uint32_t ok = (uint32_t)(g < c.num_instances) & (uint32_t)(g < num_free);
+							const uint32_t id = __builtin_amdgcn_raw_buffer_load_b32(rs_free, (int)(ok ? (num_free - 1u - g) * 4u : VVM_RSRC_NOWHERE), 0, 0);
+							const uint32_t ci = g / chunk;
+							const uint32_t chunk_end = min(c.num_instances, (ci + 1u) * chunk);
+							uint32_t pos = table_max - (num_spawned + chunk_end) + (g - ci * chunk);
+							asm volatile("" : "+v"(pos));      // computed for every lane, then selected: otherwise the division ends up behind a per-lane branch
+							__builtin_amdgcn_raw_buffer_store_b32(id, rs_free, (int)(ok ? pos * 4u : VVM_RSRC_NOWHERE), 0, 0);
+							r[k] = bitsf(id);
+						}
 					}
+				} break;
+				default: { _Pragma("unroll") LANES r[k] = 0.0f; } break;
 				}
 			} break;
-			case VVM_OP_random_add: SETF(rand01(rand_u32(DESC_U32(c.dp, rand_seed_lo), DESC_U32(c.dp, rand_seed_hi), DESC_U32(c.dp, rand_instance_base) + inst_i + slot_offset<V>(k), aux2)) * A + B);
-			case VVM_OP_external_func_call:
-				// aux = built-in id, aux2 = which output this device instruction produces (VectorVMRuntime.cpp:1450-1464 lists the
-				// operands as inputs then outputs; the linker emits one instruction per output in use)
-				if constexpr (FULL) {
-					if (aux == VVM_EXTFN_PERLIN3) { _Pragma("unroll") LANES r[k] = perlin3(c.perlin_lds, A, B, C); }
-					else { _Pragma("unroll") LANES r[k] = curl_noise3_component(c.perlin_lds, A, B, C, aux2); }
+			case 1: {
+				float a[V];
+				fetch<V, SPILL>(RARGS, uni, c, o0, a);
+				switch (op) {
+				case VVM_OP_rcp: SETF(f_rcp(A));
+				case VVM_OP_rsq: SETF(f_rsq(A));
+				case VVM_OP_sqrt: SETF(f_sqrtg(A));
+				case VVM_OP_neg: SETF(f_neg(A));
+				case VVM_OP_abs: SETF(f_abs(A));
+				case VVM_OP_exp: if constexpr (FULL) SETF(mf_exp(A));
+				case VVM_OP_exp2: if constexpr (FULL) SETF(lib_exp2(A));
+				case VVM_OP_log: if constexpr (FULL) SETF(f_log(A));
+				case VVM_OP_log2: if constexpr (FULL) SETF(lib_log2(A));
+				case VVM_OP_sin: if constexpr (FULL) SETF(mf_sin(A));
+				case VVM_OP_cos: if constexpr (FULL) SETF(mf_cos(A));
+				case VVM_OP_tan: if constexpr (FULL) SETF(lib_tan(A));
+				case VVM_OP_asin: if constexpr (FULL) SETF(f_asin(A));
+				case VVM_OP_acos: if constexpr (FULL) SETF(f_acos(A));
+				case VVM_OP_atan: if constexpr (FULL) SETF(lib_atan(A));
+				case VVM_OP_ceil: SETF(ceilf(A));
+				case VVM_OP_floor: SETF(floorf(A));
+				case VVM_OP_frac: SETF(f_frac(A));
+				case VVM_OP_trunc: SETF(truncf(A));
+				case VVM_OP_round: SETF(rintf(A));                         // SSE.h:2819-2822 (nearest even)
+				case VVM_OP_sign: SETF(f_sign(A));
+				case VVM_OP_absi: SETI(i_abs(IA));
+				case VVM_OP_negi: SETI(0u - UA);
+				case VVM_OP_signi: SETI(IA >= 0 ? 1 : -1);
+				case VVM_OP_bit_not: case VVM_OP_logic_not: SETI(~UA);
+				case VVM_OP_f2i: SETI(cvtt(A));
+				case VVM_OP_i2f: SETF(i2f(IA));
+				case VVM_OP_f2b: SETM(A > 0.0f);
+				case VVM_OP_b2f: SETF(f_sel(A, 1.0f, 0.0f));
+				case VVM_OP_i2b: SETM(IA > 0);
+				case VVM_OP_b2i: SETI(UA & 1u);
+				case VVM_OP_sin_cos: if constexpr (FULL) { _Pragma("unroll") LANES { float sn, cs; f_sincos(A, sn, cs); r[k] = aux ? cs : sn; } } break;   // aux: 0 sine, 1 cosine
+				case VVM_OP_half_to_float: SETF(load_half(UA));             // RT.cpp:1113-1127
+				case VVM_OP_exec_index_addi: SETI(DESC_U32(c.dp, exec_index_base) + inst_i + slot_offset<V>(k) + UA);             // RT.cpp:925-951
+				// aux2 = ordinal of the random op within the script
+				case VVM_OP_random: SETF(rand01(rand_u32(DESC_U32(c.dp, rand_seed_lo), DESC_U32(c.dp, rand_seed_hi), DESC_U32(c.dp, rand_instance_base) + inst_i + slot_offset<V>(k), aux2)) * A);
+				case VVM_OP_randomi: SETI(cvtt(rand01(rand_u32(DESC_U32(c.dp, rand_seed_lo), DESC_U32(c.dp, rand_seed_hi), DESC_U32(c.dp, rand_instance_base) + inst_i + slot_offset<V>(k), aux2)) * i2f(IA)));
+				default: { _Pragma("unroll") LANES r[k] = 0.0f; } break;
 				}
-				break;
-			default: { _Pragma("unroll") LANES r[k] = 0.0f; } break;
+			} break;
+			case 2: {
+				float a[V], b[V];
+				fetch<V, SPILL>(RARGS, uni, c, o0, a);
+				fetch<V, SPILL>(RARGS, uni, c, o1, b);
+				switch (op) {
+				case VVM_OP_add: SETF(A + B);
+				case VVM_OP_sub: SETF(A - B);
+				case VVM_OP_mul: SETF(A * B);
+				case VVM_OP_div: SETF(f_div(A, B));
+				case VVM_OP_atan2: if constexpr (FULL) SETF(ue_atan2(A, B));
+				case VVM_OP_fmod: if constexpr (FULL) SETF(f_fmod(A, B));
+				case VVM_OP_min: SETF(f_min(A, B));
+				case VVM_OP_max: SETF(f_max(A, B));
+				case VVM_OP_pow: if constexpr (FULL) SETF(f_pow(A, B));
+				case VVM_OP_step: SETF(f_step(B - A));                     // RT.cpp:1939
+				case VVM_OP_cmplt: SETM(A < B);
+				case VVM_OP_cmple: SETM(A <= B);
+				case VVM_OP_cmpgt: SETM(A > B);
+				case VVM_OP_cmpge: SETM(A >= B);
+				case VVM_OP_cmpeq: SETM(A == B);
+				case VVM_OP_cmpneq: SETM(A != B);
+				case VVM_OP_addi: SETI(UA + UB);
+				case VVM_OP_subi: SETI(UA - UB);
+				case VVM_OP_muli: SETI(UA * UB);
+				case VVM_OP_divi: SETI(i_div(IA, IB));
+				case VVM_OP_mini: SETI(i_min(IA, IB));
+				case VVM_OP_maxi: SETI(i_max(IA, IB));
+				case VVM_OP_cmplti: SETM(IA < IB);
+				case VVM_OP_cmplei: SETM(IA <= IB);
+				case VVM_OP_cmpgti: SETM(IA > IB);
+				case VVM_OP_cmpgei: SETM(IA >= IB);
+				case VVM_OP_cmpeqi: SETM(IA == IB);
+				case VVM_OP_cmpneqi: SETM(IA != IB);
+				case VVM_OP_bit_and: case VVM_OP_logic_and: SETI(UA & UB);
+				case VVM_OP_bit_or: case VVM_OP_logic_or: SETI(UA | UB);
+				case VVM_OP_bit_xor: case VVM_OP_logic_xor: SETI(UA ^ UB);
+				case VVM_OP_bit_lshift: SETI(i_shl(UA, UB));
+				case VVM_OP_bit_rshift: SETI(i_shr(UA, UB));
+				case VVM_OP_sub_neg: SETF(f_neg(A - B));
+				case VVM_OP_div_f2i: SETI(cvtt(f_div(A, B)));
+				case VVM_OP_i2f_div0: SETF(f_div(i2f(IA), B));
+				case VVM_OP_i2f_div1: SETF(f_div(B, i2f(IA)));
+				case VVM_OP_i2f_mul: SETF(i2f(IA) * B);
+				case VVM_OP_f2i_maxi: SETI(i_max(cvtt(A), IB));
+				case VVM_OP_f2i_addi: SETI((uint32_t)cvtt(A) + UB);
+				case VVM_OP_bit_and_i2f: SETF(i2f((int32_t)(UA & UB)));
+				case VVM_OP_neg_cmplt: SETM(f_neg(A) < B);
+				case VVM_OP_max_f2i: SETI(cvtt(f_max(A, B)));
+				case VVM_OP_random_add: SETF(rand01(rand_u32(DESC_U32(c.dp, rand_seed_lo), DESC_U32(c.dp, rand_seed_hi), DESC_U32(c.dp, rand_instance_base) + inst_i + slot_offset<V>(k), aux2)) * A + B);
+				default: { _Pragma("unroll") LANES r[k] = 0.0f; } break;
+				}
+			} break;
+			case 3: {
+				float a[V], b[V], cc[V];
+				fetch<V, SPILL>(RARGS, uni, c, o0, a);
+				fetch<V, SPILL>(RARGS, uni, c, o1, b);
+				fetch<V, SPILL>(RARGS, uni, c, o2, cc);
+				switch (op) {
+				case VVM_OP_mad: SETF(f_mad(A, B, C));
+				case VVM_OP_lerp: SETF(f_lerp(A, B, C));
+				case VVM_OP_clamp: SETF(f_clamp(A, B, C));
+				case VVM_OP_select: SETF(f_sel(A, B, C));
+				case VVM_OP_clampi: SETI(i_min(i_max(IA, IB), IC));
+				case VVM_OP_cmplt_logic_and: SETI((A < B ? ~0u : 0u) & UC);
+				case VVM_OP_cmple_logic_and: SETI((A <= B ? ~0u : 0u) & UC);
+				case VVM_OP_cmpgt_logic_and: SETI((A > B ? ~0u : 0u) & UC);
+				case VVM_OP_cmpge_logic_and: SETI((A >= B ? ~0u : 0u) & UC);
+				case VVM_OP_cmpeq_logic_and: SETI((A == B ? ~0u : 0u) & UC);
+				case VVM_OP_cmpne_logic_and: SETI((A != B ? ~0u : 0u) & UC);
+				case VVM_OP_cmplti_logic_and: SETI((IA < IB ? ~0u : 0u) & UC);
+				case VVM_OP_cmplei_logic_and: SETI((IA <= IB ? ~0u : 0u) & UC);
+				case VVM_OP_cmpgti_logic_and: SETI((IA > IB ? ~0u : 0u) & UC);
+				case VVM_OP_cmpgei_logic_and: SETI((IA >= IB ? ~0u : 0u) & UC);
+				case VVM_OP_cmpeqi_logic_and: SETI((IA == IB ? ~0u : 0u) & UC);
+				case VVM_OP_cmpnei_logic_and: SETI((IA != IB ? ~0u : 0u) & UC);
+				case VVM_OP_cmplt_logic_or: SETI((A < B ? ~0u : 0u) | UC);
+				case VVM_OP_cmple_logic_or: SETI((A <= B ? ~0u : 0u) | UC);
+				case VVM_OP_cmpgt_logic_or: SETI((A > B ? ~0u : 0u) | UC);
+				case VVM_OP_cmpge_logic_or: SETI((A >= B ? ~0u : 0u) | UC);
+				case VVM_OP_cmpeq_logic_or: SETI((A == B ? ~0u : 0u) | UC);
+				case VVM_OP_cmpne_logic_or: SETI((A != B ? ~0u : 0u) | UC);
+				case VVM_OP_cmplti_logic_or: SETI((IA < IB ? ~0u : 0u) | UC);
+				case VVM_OP_cmplei_logic_or: SETI((IA <= IB ? ~0u : 0u) | UC);
+				case VVM_OP_cmpgti_logic_or: SETI((IA > IB ? ~0u : 0u) | UC);
+				case VVM_OP_cmpgei_logic_or: SETI((IA >= IB ? ~0u : 0u) | UC);
+				case VVM_OP_cmpeqi_logic_or: SETI((IA == IB ? ~0u : 0u) | UC);
+				case VVM_OP_cmpnei_logic_or: SETI((IA != IB ? ~0u : 0u) | UC);
+				case VVM_OP_mad_sqrt: SETF(ieee_sqrt(f_mad(A, B, C)));      // unguarded, RT.cpp:2033
+				case VVM_OP_mul_add: SETF((A * B) + C);
+				case VVM_OP_mul_sub0: SETF((A * B) - C);
+				case VVM_OP_mul_sub1: SETF(C - (A * B));
+				case VVM_OP_mul_mul: SETF((A * B) * C);
+				case VVM_OP_mul_max: SETF(f_max(A * B, C));
+				case VVM_OP_add_add: SETF((A + B) + C);
+				case VVM_OP_sub_cmplt1: SETM(C < (A - B));
+				case VVM_OP_sub_mul: SETF((A - B) * C);
+				case VVM_OP_div_mul: SETF(f_div(A, B) * C);
+				case VVM_OP_muli_addi: SETI(UA * UB + UC);
+				case VVM_OP_addi_bit_rshift: SETI(i_shr(UA + UB, UC));
+				case VVM_OP_addi_muli: SETI((UA + UB) * UC);
+				case VVM_OP_i2f_mad0: SETF(f_mad(i2f(IA), B, C));
+				case VVM_OP_i2f_mad1: SETF(f_mad(A, B, i2f(IC)));
+				case VVM_OP_f2i_select1: SETI((UA & (uint32_t)cvtt(B)) | (~UA & UC));
+				case VVM_OP_fmod_add: if constexpr (FULL) SETF(f_fmod(A, B) + C);
+				case VVM_OP_bit_rshift_bit_and: SETI(i_shr(UA, UB) & UC);
+				case VVM_OP_bit_or_muli: SETI((UA | UB) * UC);
+				case VVM_OP_bit_lshift_bit_or: SETI(i_shl(UA, UB) | UC);
+				case VVM_OP_external_func_call:
+					// aux = built-in id, aux2 = which output this device instruction produces (VectorVMRuntime.cpp:1450-1464 lists the
+					// operands as inputs then outputs; the linker emits one instruction per output in use)
+					if constexpr (FULL) {
+						if (aux == VVM_EXTFN_PERLIN3) { _Pragma("unroll") LANES r[k] = perlin3(c.perlin_lds, A, B, C); }
+						else { _Pragma("unroll") LANES r[k] = curl_noise3_component(c.perlin_lds, A, B, C, aux2); }
+					}
+					break;
+				default: { _Pragma("unroll") LANES r[k] = 0.0f; } break;
+				}
+			} break;
+			case 4: {
+				float a[V], b[V], cc[V], dd[V];
+				fetch<V, SPILL>(RARGS, uni, c, o0, a);
+				fetch<V, SPILL>(RARGS, uni, c, o1, b);
+				fetch<V, SPILL>(RARGS, uni, c, o2, cc);
+				fetch<V, SPILL>(RARGS, uni, c, o3, dd);
+				switch (op) {
+				// merged ops, VectorVMRuntime.cpp:1999-2074
+				case VVM_OP_cmplt_select: SETF(f_sel(mask(A < B), C, D));
+				case VVM_OP_cmple_select: SETF(f_sel(mask(A <= B), C, D));
+				case VVM_OP_cmpeq_select: SETF(f_sel(mask(A == B), C, D));
+				case VVM_OP_cmplti_select: SETF(f_sel(mask(IA < IB), C, D));
+				case VVM_OP_cmplei_select: SETF(f_sel(mask(IA <= IB), C, D));
+				case VVM_OP_cmpeqi_select: SETF(f_sel(mask(IA == IB), C, D));
+				case VVM_OP_mad_add: SETF(f_mad(A, B, C) + D);
+				case VVM_OP_mad_sub0: SETF(f_mad(A, B, C) - D);
+				case VVM_OP_mad_sub1: SETF(D - f_mad(A, B, C));
+				case VVM_OP_mad_mul: SETF(f_mad(A, B, C) * D);
+				case VVM_OP_mul_mad0: SETF(f_mad(A * B, C, D));
+				case VVM_OP_mul_mad1: SETF(f_mad(C, D, A * B));
+				case VVM_OP_add_mad1: SETF(f_mad(C, D, A + B));
+				case VVM_OP_div_mad0: SETF(f_mad(f_div(A, B), C, D));
+				case VVM_OP_select_mul: SETF(f_sel(A, B, C) * D);
+				case VVM_OP_select_add: SETF(f_sel(A, B, C) + D);
+				default: { _Pragma("unroll") LANES r[k] = 0.0f; } break;
+				}
+			} break;
+			default: {
+				float a[V], b[V], cc[V], dd[V], ee[V];
+				fetch<V, SPILL>(RARGS, uni, c, o0, a);
+				fetch<V, SPILL>(RARGS, uni, c, o1, b);
+				fetch<V, SPILL>(RARGS, uni, c, o2, cc);
+				fetch<V, SPILL>(RARGS, uni, c, o3, dd);
+				fetch<V, SPILL>(RARGS, uni, c, o4, ee);
+				switch (op) {
+				case VVM_OP_mad_mad0: SETF(f_mad(D, E, f_mad(A, B, C)));
+				case VVM_OP_mad_mad1: SETF(f_mad(f_mad(A, B, C), D, E));
+				default: { _Pragma("unroll") LANES r[k] = 0.0f; } break;
+				}
+			} break;
 			}
 #undef LANES
 #undef A

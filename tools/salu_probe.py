@@ -54,6 +54,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--particles", type=int, default=16 * 1024 * 1024)
     ap.add_argument("--variants", default="base,add_vv,add_vu,mad_vuv,madmul,in1,out1")
+    ap.add_argument("--width", type=int, default=4, choices=[4, 8], help="instances per lane of the kernel to probe")
     args = ap.parse_args()
     import torch
     from renderer_amd import abi
@@ -71,11 +72,12 @@ def main():
         st = VectorVMState(built.blob, be)
         frame = st.frame([abi.DataSet([t.data_ptr() for t in src[:n_in]], [t.data_ptr() for t in dst[:n_out]], 0)], n, [consts])
         st.enable_timing(True)
+        opt = abi.ExecOptions(0, 0, 0, None, abi.VVM_EXEC_FORCE_EIGHT_WIDE if args.width == 8 else abi.VVM_EXEC_NO_EIGHT_WIDE)
         for _ in range(2):
-            surv = st.exec(frame)
+            surv = st.exec(frame, opt)
         ms, launches = st.collect_kernel_ms()
         assert surv == n
-        print("variant %s launches 2 kernel_ms %.4f" % (v, ms / max(launches, 1)), flush=True)
+        print("variant %s width %d launches 2 kernel_ms %.4f" % (v, args.width, ms / max(launches, 1)), flush=True)
         st.close()
 
 

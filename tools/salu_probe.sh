@@ -1,9 +1,10 @@
 #!/bin/bash
-# usage: tools/salu_probe.sh <tag>   (on the GPU box)  per-wave instruction counts of the probe ladder -> gpurun_out/<tag>/
+# usage: tools/salu_probe.sh <tag> [4|8]   (on the GPU box)  per-wave instruction counts of the probe ladder -> gpurun_out/<tag>/
 tag=$1
+width=${2:-4}
 root=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 180 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVES SQ_INSTS_BRANCH -d $root/gpurun_out/$tag -o pmc --output-format csv -- python3 $root/tools/salu_probe.py > $root/gpurun_out/$tag.log 2>&1 || { tail -5 $root/gpurun_out/$tag.log; exit 1; }
+timeout -s KILL 180 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVES SQ_INSTS_BRANCH -d $root/gpurun_out/$tag -o pmc --output-format csv -- python3 $root/tools/salu_probe.py --width $width > $root/gpurun_out/$tag.log 2>&1 || { tail -5 $root/gpurun_out/$tag.log; exit 1; }
 python3 - <<PY
 import csv, collections, re
 names = [l.split()[1] for l in open("$root/gpurun_out/$tag.log") if l.startswith("variant ")]
@@ -13,7 +14,7 @@ by = collections.defaultdict(dict)
 for r in rows:
     by[int(r["Dispatch_Id"])][r["Counter_Name"]] = float(r["Counter_Value"])
 ids = sorted(by)
-tiles = 16 * 1024 * 1024 // 1024 * 4       # wave-tiles per launch (4 waves per 1024-instance tile)
+tiles = 16 * 1024 * 1024 // (256 * $width) * 4       # wave-tiles per launch (4 waves per tile of 256 x width instances)
 tab = {}
 for i, name in enumerate(names):
     d = by[ids[2 * i + 1]]
