@@ -226,7 +226,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s script (8 f32 streams in, 8 out, kill via acquireindex), %d particles per GPU, "
                                    "%.1f%% survive" % (args.workload, n, 100.0 * survivors / max(n, 1)),
-                       "particles_per_gpu": n, "survivors_rank0": survivors, "instances_per_lane": int(info.InstancesPerLane),
+                       "particles_per_gpu": n, "survivors_rank0": survivors, "instances_per_lane": state.last_exec_width(),
                        "parallelism": "instance ranges sharded over %d GPU(s); all-gather of survivor counts" % world if distributed
                        else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,

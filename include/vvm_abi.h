@@ -261,6 +261,9 @@ VVM_API int vvm_inspect_blob(const uint8_t* blob, size_t num_bytes, vvm_program_
 /* Thaw and link a blob without touching a device and copy out the linked device program: 4 dwords per instruction
  * (renderer_amd/csrc/vvm_device.h gives the encoding), at most `capacity_instructions` of them.  Returns the number of
  * instructions of the program (negative status code on failure).  narrow != 0 links for the 1-instance-per-lane kernel. */
+/* Instances per lane (8, 4 or 1) of the kernel the state's last vvm_exec* ran on; 0 before the first.  No counterpart in the
+ * reference (its loop is always four wide, VectorVMRuntime.cpp:2135-2175). */
+VVM_API int32_t vvm_state_last_exec_width(const vvm_state* state);
 /* vm.PageSizeInKB (VectorVMRuntime.cpp:44-50, default 64): the page the reference sizes its chunks by (:2210-2261).  The
  * executor does not chunk, but Internal.* and the chunk-dependent results of update_id / acquire_id follow it.  Process-wide. */
 VVM_API void vvm_set_page_size_kb(int kb);

@@ -271,6 +271,8 @@ class HipBackend(Backend):
         L.vvm_inspect_blob.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(ProgramInfo)]
         L.vvm_inspect_code.restype = C.c_int
         L.vvm_inspect_code.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_uint32), C.c_int32]
+        L.vvm_state_last_exec_width.restype = C.c_int32
+        L.vvm_state_last_exec_width.argtypes = [C.c_void_p]
         L.vvm_set_page_size_kb.restype = None
         L.vvm_set_page_size_kb.argtypes = [C.c_int]
         L.vvm_device_alloc.restype = C.c_void_p

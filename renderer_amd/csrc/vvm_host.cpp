@@ -148,6 +148,7 @@ struct vvm_state {
 	uint32_t* d_chunk_prefix = nullptr; uint32_t chunk_capacity = 0;
 	int32_t*  d_id_scratch = nullptr;   uint32_t id_scratch_capacity = 0;
 	int32_t   id_num_free_start = 0, id_num_spawned_start = 0;
+	uint32_t  last_width = 0;          // instances per lane of the kernel the last Exec ran on
 };
 
 namespace {
@@ -520,6 +521,7 @@ VVM_API int vvm_exec_async(vvm_exec_context* ctx, const vvm_exec_options* opt)
 	if (st->last_stream && st->last_stream != stream) HIP_TRY(hipStreamSynchronize(st->last_stream));
 	st->last_stream = stream;
 	st->in_flight = true;
+	st->last_width = pe.instances_per_lane;
 	if (pe.tiles == 0) {     // nothing to run: zero chunks in the reference too (RT.cpp:2277)
 		st->h_counts[0] = 0;
 		for (uint32_t i = 0; i < st->script.max_output_dataset; ++i) st->h_counts[i] = 0;
@@ -775,6 +777,7 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 }
 
 // --- introspection / helpers ------------------------------------------------------------------------
+VVM_API int32_t vvm_state_last_exec_width(const vvm_state* st) { return st ? (int32_t)st->last_width : 0; }
 VVM_API const int32_t* vvm_state_device_counts(const vvm_state* st) { return st ? st->d_counts : nullptr; }
 VVM_API int32_t vvm_state_max_output_dataset(const vvm_state* st) { return st ? (int32_t)st->script.max_output_dataset : 0; }
 

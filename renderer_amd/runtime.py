@@ -53,6 +53,10 @@ class VectorVMState:
         self.backend.exec_finish(frame)
         return frame.survivors(0)
 
+    def last_exec_width(self) -> int:
+        """Instances per lane of the kernel the last Exec ran on (8, 4 or 1)."""
+        return int(self.backend.lib.vvm_state_last_exec_width(self.ptr))
+
     def enable_timing(self, on: bool = True) -> None:
         self.backend._check(self.backend.lib.vvm_state_enable_timing(self.ptr, 1 if on else 0), "vvm_state_enable_timing")
 

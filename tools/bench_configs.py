@@ -46,12 +46,13 @@ def main():
         el = time.perf_counter() - t0
         ms, launches = st.collect_kernel_ms()
         info = st.info()
+        width = st.last_exec_width()
         st.close()
         kernel_ms = ms / max(launches, 1)
         alg = info.BytesInPerInstance * n + info.BytesOutPerInstance * surv
         print(json.dumps({"config": name, "particles": n, "survivors": surv, "steps": args.steps, "ms_per_step": el / args.steps * 1e3,
                           "kernel_ms": kernel_ms, "updates_per_s": n * args.steps / el, "algorithmic_GBps": alg / kernel_ms / 1e6,
-                          "frac_of_8TBps": alg / kernel_ms / 1e6 / 8000.0, "instances_per_lane": int(info.InstancesPerLane)}), flush=True)
+                          "frac_of_8TBps": alg / kernel_ms / 1e6 / 8000.0, "instances_per_lane": width}), flush=True)
 
     which = args.which.split(",")
     if "transcendental" in which:
