@@ -434,10 +434,11 @@ hipError_t reset_launch_state(VvmLaunchState* d)
 	return hipMemcpy(&d->epoch, &one, 4, hipMemcpyHostToDevice);
 }
 
-uint32_t grid_for(uint32_t tiles)
+// Persistent workgroups: as many as can be resident (workgroups per CU by the kernel's register budget), never more than tiles.
+uint32_t grid_for(uint32_t tiles, uint32_t instances_per_lane, bool full)
 {
-	const uint32_t resident = (uint32_t)g_dev.num_cus * 8u;
-	return std::max<uint32_t>(1, std::min<uint32_t>(tiles, resident));
+	const uint32_t per_cu = instances_per_lane == 8 ? 2u : full ? 3u : instances_per_lane == 4 ? 4u : 8u;
+	return std::max<uint32_t>(1, std::min<uint32_t>(tiles, (uint32_t)g_dev.num_cus * per_cu));
 }
 
 int write_back_counts(vvm_state* st, vvm_exec_context* ctx, bool ran_kernel)
@@ -576,7 +577,7 @@ VVM_API int vvm_exec_async(vvm_exec_context* ctx, const vvm_exec_options* opt)
 		HIP_TRY(hipMemcpyAsync(st->ring.dev[slot], st->ring.host[slot], pe.bytes, hipMemcpyHostToDevice, stream));
 		if (timed && pass == 0) HIP_TRY(hipEventRecord(st->ev_start[st->ev_used], stream));
 		const int lrc = vvm_launch_exec_kernel((int)pe.instances_per_lane, (const VvmExecDesc*)st->ring.dev[slot], 1, pe.tiles, st->d_launch,
-		                                       pe.lp->lds_spill_slots, pe.lp->full_kernel ? 1 : 0, grid_for(pe.tiles), stream);
+		                                       pe.lp->lds_spill_slots, pe.lp->full_kernel ? 1 : 0, grid_for(pe.tiles, pe.instances_per_lane, pe.lp->full_kernel), stream);
 		if (lrc != 0) return hip_fail((hipError_t)lrc, "kernel launch");
 		if (timed && pass + 1 == num_passes) { HIP_TRY(hipEventRecord(st->ev_stop[st->ev_used], stream)); st->ev_used++; }
 		if (pe.lp->uses_ids && pe.lp->updates_ids) {
@@ -755,7 +756,7 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 		const vvm::LinkedProgram& lp = *pes[(size_t)groups[g].members[0]].lp;
 		const int lrc = vvm_launch_exec_kernel((int)pes[(size_t)groups[g].members[0]].instances_per_lane, (const VvmExecDesc*)(g_batch.dev + group_desc_off[g]),
 		                                       (uint32_t)groups[g].members.size(), groups[g].tiles, g_batch.d_launch[g], groups[g].spill,
-		                                       lp.full_kernel ? 1 : 0, grid_for(groups[g].tiles), g_batch.stream);
+		                                       lp.full_kernel ? 1 : 0, grid_for(groups[g].tiles, pes[(size_t)groups[g].members[0]].instances_per_lane, lp.full_kernel), g_batch.stream);
 		if (lrc != 0) return hip_fail((hipError_t)lrc, "batched kernel launch");
 		HIP_TRY(hipMemcpyAsync(&g_batch.h_launch[g], g_batch.d_launch[g], 80, hipMemcpyDeviceToHost, g_batch.stream));
 	}
