@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="fountain", choices=["fountain", "fountain_kill_half"])
     ap.add_argument("--particles", type=int, default=64 * 1024 * 1024, help="instances per GPU")
+    ap.add_argument("--width", default="auto", choices=["auto", "4", "8"], help="instances per lane of the kernel (auto: the library's choice)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -157,7 +158,8 @@ def main():
     ds = abi.DataSet([t.data_ptr() for t in ins], [t.data_ptr() for t in outs], 0)
     frame = state.frame([ds], n, [w.constants])
     stream = torch.cuda.current_stream().cuda_stream
-    opt = abi.ExecOptions(0, first if first < 2 ** 31 else 0, first if first < 2 ** 31 else 0, stream, 0)
+    flags = {"auto": 0, "4": abi.VVM_EXEC_NO_EIGHT_WIDE, "8": abi.VVM_EXEC_FORCE_EIGHT_WIDE}[args.width]
+    opt = abi.ExecOptions(0, first if first < 2 ** 31 else 0, first if first < 2 ** 31 else 0, stream, flags)
     counts_dev = torch.zeros(1, dtype=torch.int32, device=dev)
     gathered = torch.zeros(world, dtype=torch.int32, device=dev)
 

@@ -207,7 +207,7 @@ enum {
 	VVM_EXEC_NO_EIGHT_WIDE = 1u << 1,    /* never */
 	VVM_EXEC_FORCE_EIGHT_WIDE = 1u << 2  /* whenever the script allows it, whatever the size (tests) */
 };
-#define VVM_EIGHT_WIDE_MIN_INSTANCES (4 * 1024 * 1024)
+#define VVM_EIGHT_WIDE_MIN_INSTANCES (256 * 1024)
 
 /* ---- entry points ---- */
 
