@@ -283,3 +283,32 @@ def test_two_datasets_match_the_oracle(n, secondary_first, many):
         assert np.all(a[m:].view(np.uint32) == 0xCDCDCDCD)
     d0, d1 = dataset_cases.expected(x, y, 0.5, 0.7, many)
     assert got_n == len(d0[0]) and m == len(d1[0])
+
+
+def test_internal_fields_follow_the_reference_chunking():
+    """ctx->Internal.* is what the reference's chunking computes for the Exec (VectorVMRuntime.cpp:2210-2261), at any page size."""
+    w = scripts.fountain(alias_outputs=False)
+    n = 50_000
+    ins = scripts.fountain_streams_np(0, n, kill_half=True)
+    for page_kb in (64, 4):
+        _, _, ref_frame = run_oracle(w.script, [w.constants], ins, [f32] * 8, n, page_kb=page_kb)
+        be = abi.load_hip_backend()
+        be.set_page_size_kb(page_kb)
+        try:
+            st = VectorVMState(w.script.blob, be)
+            ptrs = [be.lib.vvm_device_alloc(4 * (n + PAD)) for _ in range(16)]
+            frame = st.frame([abi.DataSet(ptrs[:8], ptrs[8:], 0)], n, [w.constants])
+            for p, a in zip(ptrs[:8], ins):
+                buf = np.zeros(n + PAD, f32); buf[:n] = a
+                be._check(be.lib.vvm_device_upload(p, buf.ctypes.data, buf.nbytes), "upload")
+            st.exec(frame)
+            a, b = frame.ctx.Internal, ref_frame.ctx.Internal
+            assert (a.MaxChunksPerBatch, a.MaxInstancesPerChunk, a.PerBatchRegisterDataBytesRequired, a.NumBytesRequiredPerBatch) == \
+                   (b.MaxChunksPerBatch, b.MaxInstancesPerChunk, b.PerBatchRegisterDataBytesRequired, b.NumBytesRequiredPerBatch)
+            if page_kb == 4:
+                assert a.MaxChunksPerBatch > 1
+            st.close()
+            for p in ptrs:
+                be.lib.vvm_device_free(p)
+        finally:
+            be.set_page_size_kb(64)
