@@ -55,6 +55,8 @@ enum : uint32_t {
 //   w0: op[0:8) nin[8:11) nout[11:13) aux[16:24) aux2[24:32)
 //   w1: o0 | o1 << 16      w2: o2 | o3 << 16      w3: o4 | o5 << 16
 // Ordinary ops have exactly one destination: the inputs are o0.. in order and the destination is o5.
+// nin = VVM_NIN_SPECIAL marks `done` and the device-only instructions (the interpreter's inner loop dispatches on nin first).
+#define VVM_NIN_SPECIAL 7u
 struct VvmIns {
 	uint32_t w0, w1, w2, w3;
 };

@@ -459,6 +459,10 @@ DEV uint32_t wave_sum(uint32_t v)
 	return v;
 }
 
+// An equality test the compiler cannot merge with its neighbours: a chain of such tests stays a chain, in the order written
+// (plain comparisons of one value are turned into a switch and lowered as a balanced tree).
+DEV bool nin_is(uint32_t nin, uint32_t n) { asm volatile("" : "+s"(nin)); return nin == n; }
+
 // ---- per-tile interpreter state ----------------------------------------------------------------------
 #define RVEC typename RegTraits<V>::vec
 // (eight vectors are handed around whatever V is; the ones past V are never touched and cost nothing)
@@ -987,7 +991,6 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 			op = w0 & 0xFFu; aux = (w0 >> 16) & 0xFFu; aux2 = w0 >> 24;
 			const uint32_t nin = (w0 >> 8) & 7u;
 			o0 = ins.w1 & 0xFFFFu; o1 = ins.w1 >> 16; o2 = ins.w2 & 0xFFFFu; o3 = ins.w2 >> 16; o4 = ins.w3 & 0xFFFFu; o5 = ins.w3 >> 16;
-			if (op - 1u >= VVM_DOP_LOADN16 - 1u) break;        // done (0) or a special instruction
 
 			float r[V];
 			const uint32_t dst = o5;
@@ -1010,86 +1013,8 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 #define SETM(expr) { _Pragma("unroll") LANES r[k] = mask(expr); } break
 			// One group of cases per operand count: the operands an instruction has are fetched, no others exist (a common fetch
 			// sequence in front of one big switch leaves the compiler with placeholder values to materialize for the missing ones).
-			switch (nin) {
-			case 0: {
-				switch (op) {
-				case VVM_OP_exec_index: SETI(DESC_U32(c.dp, exec_index_base) + inst_i + slot_offset<V>(k));                       // RT.cpp:880-900
-				case VVM_OP_exec_indexf: SETF(i2f((int32_t)(DESC_U32(c.dp, exec_index_base) + inst_i + slot_offset<V>(k))));      // RT.cpp:902-923
-				case VVM_OP_acquire_id: if constexpr (FULL) {
-					// VectorVMRuntime.cpp:1404-1440.  Instance g of the Exec takes FreeIDTable[NumFreeIDs - 1 - g]: each chunk pops its
-					// IDs from the end of the free list, reversed (:1417-1421), and the chunks pop in order.  The IDs are also logged as
-					// spawned: chunk c's, in instance order, at FreeIDTable[Max - (NumSpawnedIDs + instances up to the end of chunk c)]
-					// (:1429-1432).  aux 1 is the instruction's second destination, the tag (:1435).
-					const void* idp = (const void*)DESC_PTR(c.dp, ids);
-					if (aux == 1) {
-						const uint32_t tag_value = sload32(idp, offsetof(VvmIdDesc, acquire_tag) / 4);
-						_Pragma("unroll") LANES r[k] = bitsf(tag_value);
-					} else {
-						const uint32_t table_max = sload32(idp, offsetof(VvmIdDesc, free_table_max) / 4);
-						const rsrc_t rs_free = make_rsrc(sload64(idp, offsetof(VvmIdDesc, free_table) / 8), 4u * table_max);
-						const uint32_t num_free = sload32(idp, offsetof(VvmIdDesc, num_free_start) / 4), num_spawned = sload32(idp, offsetof(VvmIdDesc, num_spawned_start) / 4);
-						const uint32_t chunk = sload32(idp, offsetof(VvmIdDesc, chunk_instances) / 4);
-						_Pragma("unroll") LANES {
-							const uint32_t g = inst_i + slot_offset<V>(k);
-							const uint32_t ok = (uint32_t)(g < c.num_instances) & (uint32_t)(g < num_free);
-							const uint32_t id = __builtin_amdgcn_raw_buffer_load_b32(rs_free, (int)(ok ? (num_free - 1u - g) * 4u : VVM_RSRC_NOWHERE), 0, 0);
-							const uint32_t ci = g / chunk;
-							const uint32_t chunk_end = min(c.num_instances, (ci + 1u) * chunk);
-							uint32_t pos = table_max - (num_spawned + chunk_end) + (g - ci * chunk);
-							asm volatile("" : "+v"(pos));      // computed for every lane, then selected: otherwise the division ends up behind a per-lane branch
-							__builtin_amdgcn_raw_buffer_store_b32(id, rs_free, (int)(ok ? pos * 4u : VVM_RSRC_NOWHERE), 0, 0);
-							r[k] = bitsf(id);
-						}
-					}
-				} break;
-				default: { _Pragma("unroll") LANES r[k] = 0.0f; } break;
-				}
-			} break;
-			case 1: {
-				float a[V];
-				fetch<V, SPILL>(RARGS, uni, c, o0, a);
-				switch (op) {
-				case VVM_OP_rcp: SETF(f_rcp(A));
-				case VVM_OP_rsq: SETF(f_rsq(A));
-				case VVM_OP_sqrt: SETF(f_sqrtg(A));
-				case VVM_OP_neg: SETF(f_neg(A));
-				case VVM_OP_abs: SETF(f_abs(A));
-				case VVM_OP_exp: if constexpr (FULL) SETF(mf_exp(A));
-				case VVM_OP_exp2: if constexpr (FULL) SETF(lib_exp2(A));
-				case VVM_OP_log: if constexpr (FULL) SETF(f_log(A));
-				case VVM_OP_log2: if constexpr (FULL) SETF(lib_log2(A));
-				case VVM_OP_sin: if constexpr (FULL) SETF(mf_sin(A));
-				case VVM_OP_cos: if constexpr (FULL) SETF(mf_cos(A));
-				case VVM_OP_tan: if constexpr (FULL) SETF(lib_tan(A));
-				case VVM_OP_asin: if constexpr (FULL) SETF(f_asin(A));
-				case VVM_OP_acos: if constexpr (FULL) SETF(f_acos(A));
-				case VVM_OP_atan: if constexpr (FULL) SETF(lib_atan(A));
-				case VVM_OP_ceil: SETF(ceilf(A));
-				case VVM_OP_floor: SETF(floorf(A));
-				case VVM_OP_frac: SETF(f_frac(A));
-				case VVM_OP_trunc: SETF(truncf(A));
-				case VVM_OP_round: SETF(rintf(A));                         // SSE.h:2819-2822 (nearest even)
-				case VVM_OP_sign: SETF(f_sign(A));
-				case VVM_OP_absi: SETI(i_abs(IA));
-				case VVM_OP_negi: SETI(0u - UA);
-				case VVM_OP_signi: SETI(IA >= 0 ? 1 : -1);
-				case VVM_OP_bit_not: case VVM_OP_logic_not: SETI(~UA);
-				case VVM_OP_f2i: SETI(cvtt(A));
-				case VVM_OP_i2f: SETF(i2f(IA));
-				case VVM_OP_f2b: SETM(A > 0.0f);
-				case VVM_OP_b2f: SETF(f_sel(A, 1.0f, 0.0f));
-				case VVM_OP_i2b: SETM(IA > 0);
-				case VVM_OP_b2i: SETI(UA & 1u);
-				case VVM_OP_sin_cos: if constexpr (FULL) { _Pragma("unroll") LANES { float sn, cs; f_sincos(A, sn, cs); r[k] = aux ? cs : sn; } } break;   // aux: 0 sine, 1 cosine
-				case VVM_OP_half_to_float: SETF(load_half(UA));             // RT.cpp:1113-1127
-				case VVM_OP_exec_index_addi: SETI(DESC_U32(c.dp, exec_index_base) + inst_i + slot_offset<V>(k) + UA);             // RT.cpp:925-951
-				// aux2 = ordinal of the random op within the script
-				case VVM_OP_random: SETF(rand01(rand_u32(DESC_U32(c.dp, rand_seed_lo), DESC_U32(c.dp, rand_seed_hi), DESC_U32(c.dp, rand_instance_base) + inst_i + slot_offset<V>(k), aux2)) * A);
-				case VVM_OP_randomi: SETI(cvtt(rand01(rand_u32(DESC_U32(c.dp, rand_seed_lo), DESC_U32(c.dp, rand_seed_hi), DESC_U32(c.dp, rand_instance_base) + inst_i + slot_offset<V>(k), aux2)) * i2f(IA)));
-				default: { _Pragma("unroll") LANES r[k] = 0.0f; } break;
-				}
-			} break;
-			case 2: {
+			// (tested in order of how common the operand counts are: a chain of equality tests, not a balanced tree)
+			if (nin_is(nin, 2u)) {
 				float a[V], b[V];
 				fetch<V, SPILL>(RARGS, uni, c, o0, a);
 				fetch<V, SPILL>(RARGS, uni, c, o1, b);
@@ -1140,8 +1065,8 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 				case VVM_OP_random_add: SETF(rand01(rand_u32(DESC_U32(c.dp, rand_seed_lo), DESC_U32(c.dp, rand_seed_hi), DESC_U32(c.dp, rand_instance_base) + inst_i + slot_offset<V>(k), aux2)) * A + B);
 				default: { _Pragma("unroll") LANES r[k] = 0.0f; } break;
 				}
-			} break;
-			case 3: {
+			}
+			else if (nin_is(nin, 3u)) {
 				float a[V], b[V], cc[V];
 				fetch<V, SPILL>(RARGS, uni, c, o0, a);
 				fetch<V, SPILL>(RARGS, uni, c, o1, b);
@@ -1206,8 +1131,52 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 					break;
 				default: { _Pragma("unroll") LANES r[k] = 0.0f; } break;
 				}
-			} break;
-			case 4: {
+			}
+			else if (nin_is(nin, 1u)) {
+				float a[V];
+				fetch<V, SPILL>(RARGS, uni, c, o0, a);
+				switch (op) {
+				case VVM_OP_rcp: SETF(f_rcp(A));
+				case VVM_OP_rsq: SETF(f_rsq(A));
+				case VVM_OP_sqrt: SETF(f_sqrtg(A));
+				case VVM_OP_neg: SETF(f_neg(A));
+				case VVM_OP_abs: SETF(f_abs(A));
+				case VVM_OP_exp: if constexpr (FULL) SETF(mf_exp(A));
+				case VVM_OP_exp2: if constexpr (FULL) SETF(lib_exp2(A));
+				case VVM_OP_log: if constexpr (FULL) SETF(f_log(A));
+				case VVM_OP_log2: if constexpr (FULL) SETF(lib_log2(A));
+				case VVM_OP_sin: if constexpr (FULL) SETF(mf_sin(A));
+				case VVM_OP_cos: if constexpr (FULL) SETF(mf_cos(A));
+				case VVM_OP_tan: if constexpr (FULL) SETF(lib_tan(A));
+				case VVM_OP_asin: if constexpr (FULL) SETF(f_asin(A));
+				case VVM_OP_acos: if constexpr (FULL) SETF(f_acos(A));
+				case VVM_OP_atan: if constexpr (FULL) SETF(lib_atan(A));
+				case VVM_OP_ceil: SETF(ceilf(A));
+				case VVM_OP_floor: SETF(floorf(A));
+				case VVM_OP_frac: SETF(f_frac(A));
+				case VVM_OP_trunc: SETF(truncf(A));
+				case VVM_OP_round: SETF(rintf(A));                         // SSE.h:2819-2822 (nearest even)
+				case VVM_OP_sign: SETF(f_sign(A));
+				case VVM_OP_absi: SETI(i_abs(IA));
+				case VVM_OP_negi: SETI(0u - UA);
+				case VVM_OP_signi: SETI(IA >= 0 ? 1 : -1);
+				case VVM_OP_bit_not: case VVM_OP_logic_not: SETI(~UA);
+				case VVM_OP_f2i: SETI(cvtt(A));
+				case VVM_OP_i2f: SETF(i2f(IA));
+				case VVM_OP_f2b: SETM(A > 0.0f);
+				case VVM_OP_b2f: SETF(f_sel(A, 1.0f, 0.0f));
+				case VVM_OP_i2b: SETM(IA > 0);
+				case VVM_OP_b2i: SETI(UA & 1u);
+				case VVM_OP_sin_cos: if constexpr (FULL) { _Pragma("unroll") LANES { float sn, cs; f_sincos(A, sn, cs); r[k] = aux ? cs : sn; } } break;   // aux: 0 sine, 1 cosine
+				case VVM_OP_half_to_float: SETF(load_half(UA));             // RT.cpp:1113-1127
+				case VVM_OP_exec_index_addi: SETI(DESC_U32(c.dp, exec_index_base) + inst_i + slot_offset<V>(k) + UA);             // RT.cpp:925-951
+				// aux2 = ordinal of the random op within the script
+				case VVM_OP_random: SETF(rand01(rand_u32(DESC_U32(c.dp, rand_seed_lo), DESC_U32(c.dp, rand_seed_hi), DESC_U32(c.dp, rand_instance_base) + inst_i + slot_offset<V>(k), aux2)) * A);
+				case VVM_OP_randomi: SETI(cvtt(rand01(rand_u32(DESC_U32(c.dp, rand_seed_lo), DESC_U32(c.dp, rand_seed_hi), DESC_U32(c.dp, rand_instance_base) + inst_i + slot_offset<V>(k), aux2)) * i2f(IA)));
+				default: { _Pragma("unroll") LANES r[k] = 0.0f; } break;
+				}
+			}
+			else if (nin_is(nin, 4u)) {
 				float a[V], b[V], cc[V], dd[V];
 				fetch<V, SPILL>(RARGS, uni, c, o0, a);
 				fetch<V, SPILL>(RARGS, uni, c, o1, b);
@@ -1233,8 +1202,42 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 				case VVM_OP_select_add: SETF(f_sel(A, B, C) + D);
 				default: { _Pragma("unroll") LANES r[k] = 0.0f; } break;
 				}
-			} break;
-			default: {
+			}
+			else if (nin_is(nin, 0u)) {
+				switch (op) {
+				case VVM_OP_exec_index: SETI(DESC_U32(c.dp, exec_index_base) + inst_i + slot_offset<V>(k));                       // RT.cpp:880-900
+				case VVM_OP_exec_indexf: SETF(i2f((int32_t)(DESC_U32(c.dp, exec_index_base) + inst_i + slot_offset<V>(k))));      // RT.cpp:902-923
+				case VVM_OP_acquire_id: if constexpr (FULL) {
+					// VectorVMRuntime.cpp:1404-1440.  Instance g of the Exec takes FreeIDTable[NumFreeIDs - 1 - g]: each chunk pops its
+					// IDs from the end of the free list, reversed (:1417-1421), and the chunks pop in order.  The IDs are also logged as
+					// spawned: chunk c's, in instance order, at FreeIDTable[Max - (NumSpawnedIDs + instances up to the end of chunk c)]
+					// (:1429-1432).  aux 1 is the instruction's second destination, the tag (:1435).
+					const void* idp = (const void*)DESC_PTR(c.dp, ids);
+					if (aux == 1) {
+						const uint32_t tag_value = sload32(idp, offsetof(VvmIdDesc, acquire_tag) / 4);
+						_Pragma("unroll") LANES r[k] = bitsf(tag_value);
+					} else {
+						const uint32_t table_max = sload32(idp, offsetof(VvmIdDesc, free_table_max) / 4);
+						const rsrc_t rs_free = make_rsrc(sload64(idp, offsetof(VvmIdDesc, free_table) / 8), 4u * table_max);
+						const uint32_t num_free = sload32(idp, offsetof(VvmIdDesc, num_free_start) / 4), num_spawned = sload32(idp, offsetof(VvmIdDesc, num_spawned_start) / 4);
+						const uint32_t chunk = sload32(idp, offsetof(VvmIdDesc, chunk_instances) / 4);
+						_Pragma("unroll") LANES {
+							const uint32_t g = inst_i + slot_offset<V>(k);
+							const uint32_t ok = (uint32_t)(g < c.num_instances) & (uint32_t)(g < num_free);
+							const uint32_t id = __builtin_amdgcn_raw_buffer_load_b32(rs_free, (int)(ok ? (num_free - 1u - g) * 4u : VVM_RSRC_NOWHERE), 0, 0);
+							const uint32_t ci = g / chunk;
+							const uint32_t chunk_end = min(c.num_instances, (ci + 1u) * chunk);
+							uint32_t pos = table_max - (num_spawned + chunk_end) + (g - ci * chunk);
+							asm volatile("" : "+v"(pos));      // computed for every lane, then selected: otherwise the division ends up behind a per-lane branch
+							__builtin_amdgcn_raw_buffer_store_b32(id, rs_free, (int)(ok ? pos * 4u : VVM_RSRC_NOWHERE), 0, 0);
+							r[k] = bitsf(id);
+						}
+					}
+				} break;
+				default: { _Pragma("unroll") LANES r[k] = 0.0f; } break;
+				}
+			}
+			else if (nin_is(nin, 5u)) {
 				float a[V], b[V], cc[V], dd[V], ee[V];
 				fetch<V, SPILL>(RARGS, uni, c, o0, a);
 				fetch<V, SPILL>(RARGS, uni, c, o1, b);
@@ -1246,8 +1249,8 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 				case VVM_OP_mad_mad1: SETF(f_mad(f_mad(A, B, C), D, E));
 				default: { _Pragma("unroll") LANES r[k] = 0.0f; } break;
 				}
-			} break;
 			}
+			else goto leave_run;      // VVM_NIN_SPECIAL: done, or a device-only instruction (handled below)
 #undef LANES
 #undef A
 #undef B
@@ -1266,6 +1269,7 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 			// the one place where the interpreter writes registers
 			REG_WRITE(VVM_OPND_IDX(dst), r);
 		}
+leave_run:
 
 		if (op == VVM_DOP_ACQUIRE) {
 			// sign bit of the predicate = keep (VectorVMRuntime.cpp:838-841); instances past the end never survive (:846-857)

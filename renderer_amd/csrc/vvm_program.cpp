@@ -571,6 +571,10 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 	}
 	lp.code.push_back(VvmIns{VVM_INS_W0(VVM_OP_done, 0, 0, 0, 0), 0, 0, 0});
 	lp.code.push_back(VvmIns{VVM_INS_W0(VVM_OP_done, 0, 0, 0, 0), 0, 0, 0});   // the kernel fetches one instruction ahead
+	for (VvmIns& k : lp.code) {
+		const uint32_t op = k.w0 & 0xFFu;
+		if (op == VVM_OP_done || op >= VVM_DOP_LOADN16) k.w0 = (k.w0 & ~(7u << 8)) | (VVM_NIN_SPECIAL << 8);
+	}
 
 	for (const InputInfo& in : lp.inputs) if (!in.noadvance) lp.bytes_in_per_instance += (in.type == 2) ? 2 : 4;
 	for (uint32_t i = 0; i < s.num_outputs_remapped; ++i) if (s.out_dst[i] != 0xFFFF) lp.bytes_out_per_instance += (s.out_type[i] == 2) ? 2 : 4;

@@ -54,7 +54,42 @@ def main():
                           "kernel_ms": kernel_ms, "updates_per_s": n * args.steps / el, "algorithmic_GBps": alg / kernel_ms / 1e6,
                           "frac_of_8TBps": alg / kernel_ms / 1e6 / 8000.0, "instances_per_lane": width}), flush=True)
 
+    def arith_script(n_ops):
+        """4 streams in, 4 out, n_ops dependent mad / mul / add instructions spread over the streams: interpreter throughput."""
+        from renderer_amd.assembler import FLOAT, Script
+        s = Script()
+        ins_ = [s.input(0, FLOAT, i) for i in range(4)]
+        s.acquireindex(s.const(0), 0)
+        cur = list(ins_)
+        for k in range(n_ops):
+            t = s.temp()
+            a, b = cur[k % 4], cur[(k + 1) % 4]
+            if k % 3 == 0:
+                s.op("mad", a, s.const(1), b, t)
+            elif k % 3 == 1:
+                s.op("mul", a, b, t)
+            else:
+                s.op("add", a, s.const(2), t)
+            cur[k % 4] = t
+        s.output_data(FLOAT, 0, [(cur[i], s.output(0, FLOAT, i)) for i in range(4)])
+        return s.build(alias_outputs=True)
+
     which = args.which.split(",")
+    if "arith" in which:
+        import struct
+        from renderer_amd import scripts as _s
+        n = 64 * 1024 * 1024
+        ins = _s.fountain_streams_torch(0, n, dev, pad=PAD)
+        for n_ops in (16, 64):
+            class W:      # (run_single wants .script and .constants)
+                pass
+            w = W()
+            w.script = arith_script(n_ops)
+            w.constants = struct.pack("<I2f", 0xFFFFFFFF, 1.0009765625, 0.125) + bytes(4)
+            t_before = time.perf_counter()
+            run_single("arithmetic %d ops, 4 streams in / 4 out, 64Mi" % n_ops, w, ins[:4], 4, n)
+            print(json.dumps({"config": "arithmetic %d ops: interpreted instructions x instances per second = value of 'updates_per_s' x %d" % (n_ops, n_ops)}), flush=True)
+
     if "transcendental" in which:
         n = 16 * 1024 * 1024
         w = scripts.transcendental(True)
