@@ -1011,6 +1011,9 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 #define SETF(expr) { _Pragma("unroll") LANES r[k] = (expr); } break
 #define SETI(expr) { _Pragma("unroll") LANES r[k] = bitsf((uint32_t)(expr)); } break
 #define SETM(expr) { _Pragma("unroll") LANES r[k] = mask(expr); } break
+// the most common ops of an operand count are tested first, one after the other, ahead of the switch over the rest
+#define HOTF(opcode, expr) if (nin_is(op, opcode)) { _Pragma("unroll") LANES r[k] = (expr); } else
+#define HOTM(opcode, expr) if (nin_is(op, opcode)) { _Pragma("unroll") LANES r[k] = mask(expr); } else
 			// One group of cases per operand count: the operands an instruction has are fetched, no others exist (a common fetch
 			// sequence in front of one big switch leaves the compiler with placeholder values to materialize for the missing ones).
 			// (tested in order of how common the operand counts are: a chain of equality tests, not a balanced tree)
@@ -1018,6 +1021,7 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 				float a[V], b[V];
 				fetch<V, SPILL>(RARGS, uni, c, o0, a);
 				fetch<V, SPILL>(RARGS, uni, c, o1, b);
+				HOTF(VVM_OP_mul, A * B) HOTF(VVM_OP_add, A + B) HOTF(VVM_OP_sub, A - B) HOTM(VVM_OP_cmplt, A < B)
 				switch (op) {
 				case VVM_OP_add: SETF(A + B);
 				case VVM_OP_sub: SETF(A - B);
@@ -1071,6 +1075,7 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 				fetch<V, SPILL>(RARGS, uni, c, o0, a);
 				fetch<V, SPILL>(RARGS, uni, c, o1, b);
 				fetch<V, SPILL>(RARGS, uni, c, o2, cc);
+				HOTF(VVM_OP_mad, f_mad(A, B, C)) HOTF(VVM_OP_select, f_sel(A, B, C)) HOTF(VVM_OP_mul_add, (A * B) + C)
 				switch (op) {
 				case VVM_OP_mad: SETF(f_mad(A, B, C));
 				case VVM_OP_lerp: SETF(f_lerp(A, B, C));
@@ -1182,6 +1187,7 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 				fetch<V, SPILL>(RARGS, uni, c, o1, b);
 				fetch<V, SPILL>(RARGS, uni, c, o2, cc);
 				fetch<V, SPILL>(RARGS, uni, c, o3, dd);
+				HOTF(VVM_OP_mad_mul, f_mad(A, B, C) * D) HOTF(VVM_OP_mad_add, f_mad(A, B, C) + D)
 				switch (op) {
 				// merged ops, VectorVMRuntime.cpp:1999-2074
 				case VVM_OP_cmplt_select: SETF(f_sel(mask(A < B), C, D));
@@ -1266,6 +1272,8 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 #undef SETF
 #undef SETI
 #undef SETM
+#undef HOTF
+#undef HOTM
 			// the one place where the interpreter writes registers
 			REG_WRITE(VVM_OPND_IDX(dst), r);
 		}
