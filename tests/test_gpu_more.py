@@ -164,7 +164,8 @@ def test_batched_execs_with_distinct_bytecode():
     """One launch for many emitters, each with its own script variant, constants and size; same results as one Exec each."""
     be = abi.load_hip_backend()
     emitters = 48
-    sizes = [0, 1, 7, 1024, 1025, 3000] + [2000 + 97 * e for e in range(emitters - 6)]
+    # (two emitters are large enough for the eight-instances-per-lane kernel: the batch then runs as two groups, one per kernel)
+    sizes = [0, 1, 7, 1024, 1025, 3000, 300_001, 262_144] + [2000 + 97 * e for e in range(emitters - 8)]
     states, frames, streams, refs, opts = [], [], [], [], []
     try:
         for e in range(emitters):
