@@ -548,6 +548,12 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #define VVM_RSRC_FLAGS 0x00020000      // raw buffer, 32-bit data format (descriptor dword 3 for this target family)
 #define AUX_STREAM 2                   // nt: streamed once, keep it out of the way of the caches
+#ifndef AUX_STREAM_LOAD
+#define AUX_STREAM_LOAD AUX_STREAM
+#endif
+#ifndef AUX_STREAM_STORE
+#define AUX_STREAM_STORE AUX_STREAM
+#endif
 #define AUX_AGENT  16                  // sc1: device-scope visibility, what a relaxed agent-scope atomic access uses here
 DEV rsrc_t make_rsrc(uint64_t base, uint32_t num_bytes) { return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)num_bytes, VVM_RSRC_FLAGS); }
 
@@ -556,14 +562,14 @@ template <int V> DEV void load_stream32(const Ctx& c, uint64_t base, float (&out
 {
 	const rsrc_t rs = make_rsrc(base + 4ull * c.tile_first, 4u * c.valid);
 	if constexpr (V >= 4) {
-		const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(c.tid * 16u), 0, AUX_STREAM);
+		const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(c.tid * 16u), 0, AUX_STREAM_LOAD);
 		out[0] = bitsf(v.x); out[1] = bitsf(v.y); out[2] = bitsf(v.z); out[3] = bitsf(v.w);
 		if constexpr (V == 8) {
-			const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(VVM_HALF_TILE * 4u + c.tid * 16u), 0, AUX_STREAM);
+			const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(VVM_HALF_TILE * 4u + c.tid * 16u), 0, AUX_STREAM_LOAD);
 			out[4] = bitsf(u.x); out[5] = bitsf(u.y); out[6] = bitsf(u.z); out[7] = bitsf(u.w);
 		}
 	} else {
-		out[0] = bitsf(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(c.tid * 4u), 0, AUX_STREAM));
+		out[0] = bitsf(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(c.tid * 4u), 0, AUX_STREAM_LOAD));
 	}
 }
 template <int V> DEV void load_stream16(const Ctx& c, uint64_t base, float (&out)[V])    // raw half bits, zero-extended
@@ -571,7 +577,7 @@ template <int V> DEV void load_stream16(const Ctx& c, uint64_t base, float (&out
 	const rsrc_t rs = make_rsrc(base + 2ull * c.tile_first, 2u * c.valid);
 #pragma unroll
 	for (int k = 0; k < V; ++k)
-		out[k] = bitsf((uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)((c.tid * lane_stride<V>() + slot_offset<V>(k)) * 2u), 0, AUX_STREAM));
+		out[k] = bitsf((uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)((c.tid * lane_stride<V>() + slot_offset<V>(k)) * 2u), 0, AUX_STREAM_LOAD));
 }
 // 64-bit device-scope store by the first lane of the calling wave
 DEV void store_u64_first_lane(gu64* addr, u64 value, uint32_t lane)
@@ -817,21 +823,21 @@ template <int V, bool ANY16, bool LAST> DEV void store_slot(uint64_t e, const fl
 		const rsrc_t rs = make_rsrc(ptr + (off4 >> 1), ptr ? (rec4 >> 1) : 0u);
 #pragma unroll
 		for (int k = 0; k < V; ++k)
-			__builtin_amdgcn_raw_buffer_store_b16((uint16_t)fbits(q[slot_offset<V>(k)]), rs, (int)((i0 + slot_offset<V>(k)) * 2u), 0, AUX_STREAM);
+			__builtin_amdgcn_raw_buffer_store_b16((uint16_t)fbits(q[slot_offset<V>(k)]), rs, (int)((i0 + slot_offset<V>(k)) * 2u), 0, AUX_STREAM_STORE);
 		return;
 	}
 	const rsrc_t rs = make_rsrc(ptr + off4, ptr ? rec4 : 0u);
 	if constexpr (V >= 4) {
 		const f4a x = *(const f4a*)q;
 		u32x4 y; y.x = fbits(x.x); y.y = fbits(x.y); y.z = fbits(x.z); y.w = fbits(x.w);
-		__builtin_amdgcn_raw_buffer_store_b128(y, rs, (int)(i0 * 4u), 0, AUX_STREAM);
+		__builtin_amdgcn_raw_buffer_store_b128(y, rs, (int)(i0 * 4u), 0, AUX_STREAM_STORE);
 		if constexpr (V == 8) {
 			const f4a x2 = *(const f4a*)(q + VVM_HALF_TILE);
 			u32x4 y2; y2.x = fbits(x2.x); y2.y = fbits(x2.y); y2.z = fbits(x2.z); y2.w = fbits(x2.w);
-			__builtin_amdgcn_raw_buffer_store_b128(y2, rs, (int)((VVM_HALF_TILE + i0) * 4u), 0, AUX_STREAM);
+			__builtin_amdgcn_raw_buffer_store_b128(y2, rs, (int)((VVM_HALF_TILE + i0) * 4u), 0, AUX_STREAM_STORE);
 		}
 	} else {
-		__builtin_amdgcn_raw_buffer_store_b32(fbits(q[0]), rs, (int)(i0 * 4u), 0, AUX_STREAM);
+		__builtin_amdgcn_raw_buffer_store_b32(fbits(q[0]), rs, (int)(i0 * 4u), 0, AUX_STREAM_STORE);
 	}
 }
 template <int V, bool ANY16, bool FULL> DEV void store_slots(const uint64_t (&entry)[VVM_STAGE_SLOTS], uint32_t n, const float* src, const StoreArgs& a)
