@@ -123,6 +123,8 @@ def main():
     ap.add_argument("--workload", default="fountain", choices=["fountain", "fountain_kill_half"])
     ap.add_argument("--particles", type=int, default=64 * 1024 * 1024, help="instances per GPU")
     ap.add_argument("--width", default="auto", choices=["auto", "4", "8"], help="instances per lane of the kernel (auto: the library's choice)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse the multi-rank path on one GPU: all ranks then share device 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -138,8 +140,13 @@ def main():
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if distributed else 0)
@@ -157,18 +164,29 @@ def main():
     state = VectorVMState(w.script.blob)
     ds = abi.DataSet([t.data_ptr() for t in ins], [t.data_ptr() for t in outs], 0)
     frame = state.frame([ds], n, [w.constants])
-    stream = torch.cuda.current_stream().cuda_stream
+    # everything of a step is enqueued on ONE explicit stream: the Exec, the device-to-device copy of its survivor count, and
+    # (through torch's current stream) the all-gather that reads that count.  (Stream 0 would mean "the state's own stream" to
+    # the library, which the collective does not wait for.)
+    torch_stream = torch.cuda.Stream(device=dev)
+    stream = torch_stream.cuda_stream
     flags = {"auto": 0, "4": abi.VVM_EXEC_NO_EIGHT_WIDE, "8": abi.VVM_EXEC_FORCE_EIGHT_WIDE}[args.width]
     opt = abi.ExecOptions(0, first if first < 2 ** 31 else 0, first if first < 2 ** 31 else 0, stream, flags)
     counts_dev = torch.zeros(1, dtype=torch.int32, device=dev)
     gathered = torch.zeros(world, dtype=torch.int32, device=dev)
 
     def step():
-        state.exec_async(frame, opt)
-        if distributed:
-            # the path's one exchange: every rank's survivor count, for the global acquireindex offsets
-            state.copy_counts(counts_dev.data_ptr(), stream)
-            dist.all_gather_into_tensor(gathered, counts_dev)
+        with torch.cuda.stream(torch_stream):
+            state.exec_async(frame, opt)
+            if distributed:
+                # the path's one exchange: every rank's survivor count, for the global acquireindex offsets
+                state.copy_counts(counts_dev.data_ptr(), stream)
+                if args.backend == "nccl":
+                    dist.all_gather_into_tensor(gathered, counts_dev)
+                else:      # rehearsal: gloo gathers host tensors
+                    torch_stream.synchronize()
+                    parts = [torch.zeros(1, dtype=torch.int32) for _ in range(world)]
+                    dist.all_gather(parts, counts_dev.cpu())
+                    gathered.copy_(torch.cat(parts))
 
     for _ in range(args.warmup):
         step()
