@@ -292,7 +292,7 @@ int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, P
 		// eight instances per lane: the same program, twice the work per interpreted instruction; only worth it when there are
 		// enough tiles left to keep every CU busy for several rounds
 		const uint32_t flags = opt ? opt->Flags : 0;
-		const bool can = pe.lp->instances_per_lane == 4 && !pe.lp->full_kernel && pe.lp->lds_spill_slots == 0 && !(flags & VVM_EXEC_NO_EIGHT_WIDE);
+		const bool can = pe.lp->instances_per_lane == 4 && !pe.lp->full_kernel && !pe.lp->many_registers && !(flags & VVM_EXEC_NO_EIGHT_WIDE);
 		// (the size of the Exec itself decides, also inside a batch: many small Execs measured faster four wide, 0.88 ms against
 		// 0.92 ms for 4096 Execs of 16 Ki instances)
 		if (can && (ctx->NumInstances >= VVM_EIGHT_WIDE_MIN_INSTANCES || (flags & VVM_EXEC_FORCE_EIGHT_WIDE))) pe.instances_per_lane = 8;
@@ -438,9 +438,9 @@ hipError_t reset_launch_state(VvmLaunchState* d)
 }
 
 // Persistent workgroups: as many as can be resident (workgroups per CU by the kernel's register budget), never more than tiles.
-uint32_t grid_for(uint32_t tiles, uint32_t instances_per_lane, bool full)
+uint32_t grid_for(uint32_t tiles, uint32_t instances_per_lane, bool full, bool many_registers)
 {
-	const uint32_t per_cu = instances_per_lane == 8 ? 2u : full ? 3u : instances_per_lane == 4 ? 4u : 8u;
+	const uint32_t per_cu = (instances_per_lane == 8 || (instances_per_lane == 4 && many_registers)) ? 2u : full ? 3u : instances_per_lane == 4 ? 4u : 8u;
 	return std::max<uint32_t>(1, std::min<uint32_t>(tiles, (uint32_t)g_dev.num_cus * per_cu));
 }
 
@@ -580,7 +580,8 @@ VVM_API int vvm_exec_async(vvm_exec_context* ctx, const vvm_exec_options* opt)
 		HIP_TRY(hipMemcpyAsync(st->ring.dev[slot], st->ring.host[slot], pe.bytes, hipMemcpyHostToDevice, stream));
 		if (timed && pass == 0) HIP_TRY(hipEventRecord(st->ev_start[st->ev_used], stream));
 		const int lrc = vvm_launch_exec_kernel((int)pe.instances_per_lane, (const VvmExecDesc*)st->ring.dev[slot], 1, pe.tiles, st->d_launch,
-		                                       pe.lp->lds_spill_slots, pe.lp->full_kernel ? 1 : 0, grid_for(pe.tiles, pe.instances_per_lane, pe.lp->full_kernel), stream);
+		                                       pe.lp->many_registers ? 1 : 0, pe.lp->lds_spill_slots, pe.lp->full_kernel ? 1 : 0,
+		                                       grid_for(pe.tiles, pe.instances_per_lane, pe.lp->full_kernel, pe.lp->many_registers), stream);
 		if (lrc != 0) return hip_fail((hipError_t)lrc, "kernel launch");
 		if (timed && pass + 1 == num_passes) { HIP_TRY(hipEventRecord(st->ev_stop[st->ev_used], stream)); st->ev_used++; }
 		if (pe.lp->uses_ids && pe.lp->updates_ids) {
@@ -683,7 +684,7 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 		const vvm::LinkedProgram& lp = *pes[(size_t)i].lp;
 		if (lp.uses_ids) return fail(VVM_E_UNSUPPORTED_OP, "scripts with update_id / acquire_id cannot be part of a batched Exec");
 		if (lp.num_passes > 1) return fail(VVM_E_UNSUPPORTED_OP, "scripts with acquireindex on several datasets cannot be part of a batched Exec");
-		const int key = (int)pes[(size_t)i].instances_per_lane * 4 + (lp.lds_spill_slots ? 2 : 0) + (lp.full_kernel ? 1 : 0);
+		const int key = (int)pes[(size_t)i].instances_per_lane * 4 + (lp.many_registers ? 2 : 0) + (lp.full_kernel ? 1 : 0);
 		Group* g = nullptr;
 		for (Group& c : groups) if (c.key == key) g = &c;
 		if (!g) { groups.push_back(Group{key, {}, 0, 0}); g = &groups.back(); }
@@ -764,8 +765,9 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 		if (groups[g].tiles == 0) continue;
 		const vvm::LinkedProgram& lp = *pes[(size_t)groups[g].members[0]].lp;
 		const int lrc = vvm_launch_exec_kernel((int)pes[(size_t)groups[g].members[0]].instances_per_lane, (const VvmExecDesc*)(g_batch.dev + group_desc_off[g]),
-		                                       (uint32_t)groups[g].members.size(), groups[g].tiles, g_batch.d_launch[g], groups[g].spill,
-		                                       lp.full_kernel ? 1 : 0, grid_for(groups[g].tiles, pes[(size_t)groups[g].members[0]].instances_per_lane, lp.full_kernel), g_batch.stream);
+		                                       (uint32_t)groups[g].members.size(), groups[g].tiles, g_batch.d_launch[g], lp.many_registers ? 1 : 0, groups[g].spill,
+		                                       lp.full_kernel ? 1 : 0,
+		                                       grid_for(groups[g].tiles, pes[(size_t)groups[g].members[0]].instances_per_lane, lp.full_kernel, lp.many_registers), g_batch.stream);
 		if (lrc != 0) return hip_fail((hipError_t)lrc, "batched kernel launch");
 		HIP_TRY(hipMemcpyAsync(&g_batch.h_launch[g], g_batch.d_launch[g], 80, hipMemcpyDeviceToHost, g_batch.stream));
 	}

@@ -5,13 +5,14 @@
 #include "vvm_device.h"
 
 extern "C" {
-// Enqueue the interpreter over `total_tiles` tiles described by `descs` (device memory).  instances_per_lane is 4 or 1;
-// full != 0 selects the kernel that also implements the transcendental ops and the noise built-ins.
+// Enqueue the interpreter over `total_tiles` tiles described by `descs` (device memory).  instances_per_lane is 8, 4 or 1;
+// many_registers != 0 selects the kernels with 32 resident registers plus lds_spill_slots registers in LDS; full != 0 the
+// kernels that also implement the transcendental ops, the noise built-ins and the ID instructions.
 int vvm_launch_exec_kernel(int instances_per_lane, const VvmExecDesc* descs, uint32_t num_execs, uint32_t total_tiles,
-                           VvmLaunchState* ls, uint32_t lds_spill_slots, int full, uint32_t grid, hipStream_t stream);
+                           VvmLaunchState* ls, int many_registers, uint32_t lds_spill_slots, int full, uint32_t grid, hipStream_t stream);
 // update_id's MaxUsedID pass over an Exec that has run (same stream).
 int vvm_launch_max_id_kernel(const VvmIdDesc* ids, uint32_t num_chunks, hipStream_t stream);
 int vvm_kernel_max_dynamic_lds(void);
-uint32_t vvm_kernel_resident_registers(int instances_per_lane);
+uint32_t vvm_kernel_resident_registers(int instances_per_lane, int many_registers);
 uint32_t vvm_kernel_lds_fixed_bytes(int instances_per_lane);
 }

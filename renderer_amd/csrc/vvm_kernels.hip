@@ -78,9 +78,12 @@ __device__ __forceinline__ void sload64x8(const void* p, uint32_t first, uint64_
 // values each one is an SSA vector indexed through the scalar GPR-index mode (s_set_gpr_idx_on + v_mov_b32).
 typedef float vec16f __attribute__((ext_vector_type(16)));
 typedef float vec32f __attribute__((ext_vector_type(32)));
-template <int V> struct RegTraits;
-template <> struct RegTraits<4> { typedef vec16f vec; static constexpr uint32_t RV = 16; };
-template <> struct RegTraits<8> { typedef vec16f vec; static constexpr uint32_t RV = 16; };
+// Resident registers per kernel shape.  SPILL marks the kernels for scripts with many registers: at four instances per lane
+// they hold 32 registers in VGPRs (and further ones in LDS slots) at half the occupancy of the 16-register kernel.
+template <int V, bool SPILL> struct RegTraits;
+template <> struct RegTraits<4, false> { typedef vec16f vec; static constexpr uint32_t RV = 16; };
+template <> struct RegTraits<4, true> { typedef vec32f vec; static constexpr uint32_t RV = 32; };
+template <> struct RegTraits<8, false> { typedef vec16f vec; static constexpr uint32_t RV = 16; };
 
 // Instance slots of a lane.  V = 1: the lane's one instance.  V = 4: four consecutive instances, [4 tid, 4 tid + 4) of the
 // tile.  V = 8: two such groups, the second one VVM_HALF_TILE instances after the first: the tile is two halves of 1024
@@ -89,7 +92,8 @@ template <> struct RegTraits<8> { typedef vec16f vec; static constexpr uint32_t 
 #define VVM_HALF_TILE (VVM_BLOCK_THREADS * 4u)
 template <int V> __device__ __forceinline__ constexpr uint32_t lane_stride() { return V == 8 ? 4u : (uint32_t)V; }     // instances between neighbouring lanes
 template <int V> __device__ __forceinline__ constexpr uint32_t slot_offset(int k) { return (V == 8 && k >= 4) ? VVM_HALF_TILE - 4u + (uint32_t)k : (uint32_t)k; }
-template <> struct RegTraits<1> { typedef vec32f vec; static constexpr uint32_t RV = 32; };
+template <> struct RegTraits<1, false> { typedef vec32f vec; static constexpr uint32_t RV = 32; };
+template <> struct RegTraits<1, true> { typedef vec32f vec; static constexpr uint32_t RV = 32; };
 template <typename VEC> __device__ __forceinline__ float vget(VEC v, uint32_t i) { return v[i]; }
 template <typename VEC> __device__ __forceinline__ VEC vset(VEC v, uint32_t i, float x) { v[i] = x; return v; }
 
@@ -464,7 +468,7 @@ DEV uint32_t wave_sum(uint32_t v)
 DEV bool nin_is(uint32_t nin, uint32_t n) { asm volatile("" : "+s"(nin)); return nin == n; }
 
 // ---- per-tile interpreter state ----------------------------------------------------------------------
-#define RVEC typename RegTraits<V>::vec
+#define RVEC typename RegTraits<V, SPILL>::vec
 // (eight vectors are handed around whatever V is; the ones past V are never touched and cost nothing)
 #define CREGS RVEC R0, RVEC R1, RVEC R2, RVEC R3, RVEC R4, RVEC R5, RVEC R6, RVEC R7
 #define RARGS R0, R1, R2, R3, R4, R5, R6, R7
@@ -493,7 +497,7 @@ struct Ctx {
 // the old value back into the element it aliases.
 template <int V, bool SPILL> DEV void reg_read(CREGS, const Ctx& c, uint32_t idx, float (&out)[V])
 {
-	constexpr uint32_t RV = RegTraits<V>::RV;
+	constexpr uint32_t RV = RegTraits<V, SPILL>::RV;
 	const uint32_t i = idx & (RV - 1);
 	out[0] = vget(R0, i);
 	if constexpr (V >= 4) { out[1] = vget(R1, i); out[2] = vget(R2, i); out[3] = vget(R3, i); }
@@ -509,14 +513,14 @@ template <int V, bool SPILL> DEV void reg_read(CREGS, const Ctx& c, uint32_t idx
 }
 template <int V, bool SPILL> DEV RVEC reg_put(RVEC Rk, bool enable, uint32_t idx, float x)
 {
-	constexpr uint32_t RV = RegTraits<V>::RV;
+	constexpr uint32_t RV = RegTraits<V, SPILL>::RV;
 	const uint32_t i = idx & (RV - 1);
 	if constexpr (SPILL) enable = enable && (idx < RV);
 	return vset(Rk, i, enable ? x : vget(Rk, i));
 }
 template <int V, bool SPILL> DEV void reg_spill(const Ctx& c, bool enable, uint32_t idx, const float (&in)[V])
 {
-	constexpr uint32_t RV = RegTraits<V>::RV;
+	constexpr uint32_t RV = RegTraits<V, SPILL>::RV;
 	if constexpr (SPILL) {
 		if (enable && idx >= RV) {
 			float* p = c.spill + ((idx - RV) * VVM_BLOCK_THREADS + c.tid) * V;
@@ -1394,7 +1398,7 @@ leave_run:
 
 // DBG: the bring-up switches of KernelEnv::debug_skip are compiled in (one instantiation only); otherwise they cost nothing.
 template <int V, bool SPILL, bool FULL, bool DBG = false>
-__global__ void __launch_bounds__(VVM_BLOCK_THREADS, (V == 8 ? 2 : FULL ? 3 : (V == 4 ? 4 : 8))) vvm_exec_kernel(KernelEnv env)
+__global__ void __launch_bounds__(VVM_BLOCK_THREADS, (V == 8 || (V == 4 && SPILL) ? 2 : FULL ? 3 : (V == 4 ? 4 : 8))) vvm_exec_kernel(KernelEnv env)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	const uint32_t dbgw = DBG ? env.debug_skip : 0u;
@@ -1530,14 +1534,14 @@ extern "C" int vvm_launch_max_id_kernel(const VvmIdDesc* idp, uint32_t num_chunk
 
 // ---- host-callable launcher --------------------------------------------------------------------------
 extern "C" int vvm_launch_exec_kernel(int instances_per_lane, const VvmExecDesc* descs, uint32_t num_execs, uint32_t total_tiles,
-                                      VvmLaunchState* ls, uint32_t lds_spill_slots, int full, uint32_t grid, hipStream_t stream)
+                                      VvmLaunchState* ls, int many_registers, uint32_t lds_spill_slots, int full, uint32_t grid, hipStream_t stream)
 {
 	KernelEnv env;
 	env.descs = descs; env.num_execs = num_execs; env.total_tiles = total_tiles; env.ls = ls; env.lds_spill_slots = lds_spill_slots;
 	{ const char* dbg = getenv("VVM_DEBUG_SKIP"); env.debug_skip = dbg ? (uint32_t)strtoul(dbg, nullptr, 0) : 0u; }
 	const size_t lds_bytes = (instances_per_lane == 8 ? LDS_SPILL_OFF(8) : instances_per_lane == 4 ? LDS_SPILL_OFF(4) : LDS_SPILL_OFF(1)) +
 	                         (size_t)lds_spill_slots * VVM_BLOCK_THREADS * 4u * (size_t)instances_per_lane;
-	const bool spill = lds_spill_slots > 0;
+	const bool spill = many_registers != 0;      // the kernels with 32 resident registers and LDS register slots
 #ifdef VVM_EXPERIMENT_ONE_KERNEL
 	(void)spill; (void)full; hipLaunchKernelGGL((vvm_exec_kernel<VVM_EXPERIMENT_ONE_KERNEL>), dim3(grid), dim3(VVM_BLOCK_THREADS), lds_bytes, stream, env);
 	return (int)hipGetLastError();
@@ -1579,5 +1583,9 @@ extern "C" int vvm_kernel_max_dynamic_lds(void)
 	return 160 * 1024 - 64;
 }
 
-extern "C" uint32_t vvm_kernel_resident_registers(int instances_per_lane) { return instances_per_lane == 4 ? RegTraits<4>::RV : RegTraits<1>::RV; }
+extern "C" uint32_t vvm_kernel_resident_registers(int instances_per_lane, int many_registers)
+{
+	if (instances_per_lane == 1) return RegTraits<1, true>::RV;
+	return many_registers ? RegTraits<4, true>::RV : RegTraits<4, false>::RV;
+}
 extern "C" uint32_t vvm_kernel_lds_fixed_bytes(int instances_per_lane) { return instances_per_lane == 4 ? LDS_SPILL_OFF(4) : LDS_SPILL_OFF(1); }

@@ -206,7 +206,8 @@ static int decode(const ThawedScript& s, std::vector<Decoded>& out, std::string&
 }
 
 // ---- linker ------------------------------------------------------------------------------------------
-static const uint32_t kMaxSpillWide = 12;      // LDS register slots of the 4-instances-per-lane kernel (4 KB each per workgroup)
+static const uint32_t kMaxSpillWide = 11;      // LDS register slots of the 4-instances-per-lane kernel (4 KB each per workgroup; two
+                                               // workgroups per CU must fit: 2 x (36 KB + 11 x 4 KB) = 160 KB)
 static const uint32_t kMaxSpillNarrow = 128;   // 1 KB each
 
 int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, std::string& err, uint32_t pass)
@@ -349,7 +350,10 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 	const uint32_t num_loaded = (uint32_t)(prefetch32.size() + prefetch16.size());
 
 	// choose the kernel shape
+	// up to 16 registers: everything in VGPRs at full occupancy; up to 32 + LDS slots: the four-wide kernel with 32 resident
+	// registers; beyond: one instance per lane
 	uint32_t V = 4, RV = 16;
+	if (nv + num_loaded > 16) RV = 32;
 	if (force_narrow || nv + num_loaded > RV + kMaxSpillWide) { V = 1; RV = 32; }
 	if (nv + num_loaded > RV + (V == 4 ? kMaxSpillWide : kMaxSpillNarrow)) {
 		snprintf(msg, sizeof(msg), "script needs %u per-lane registers; the executor holds at most %u", nv + num_loaded, RV + kMaxSpillNarrow);
@@ -376,6 +380,7 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 	lp.num_vregs = next_vreg;
 	lp.instances_per_lane = V;
 	lp.resident_regs = RV;
+	lp.many_registers = (RV == 32 && V == 4) || next_vreg > RV;
 	lp.lds_spill_slots = next_vreg > RV ? next_vreg - RV : 0;
 	lp.full_kernel = heavy || lp.uses_ids;      // (the ID instructions are compiled into the full kernels only)
 	lp.uses_perlin = uses_perlin;

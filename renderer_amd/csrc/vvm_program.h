@@ -40,6 +40,7 @@ struct LinkedProgram {
 	uint32_t instances_per_lane = 4;   // 4 or 1
 	uint32_t resident_regs = 16;
 	uint32_t lds_spill_slots = 0;
+	bool     many_registers = false;   // runs on the kernels with 32 resident registers (and LDS register slots)
 	bool     full_kernel = false;      // needs the transcendental / noise kernel
 	bool     uses_perlin = false;
 	bool     uses_ids = false;         // update_id or acquire_id ...

@@ -173,12 +173,14 @@ def test_noadvance_inputs_and_many_constants():
         np.testing.assert_array_equal(got[0][off:off + n].view(np.uint32), ref[0][off:off + n].view(np.uint32))
 
 
-def test_registers_spilled_to_lds():
-    """More live temps than resident registers: the 4-instances-per-lane kernel keeps the rest in LDS."""
+@pytest.mark.parametrize("n_temps,lds_registers", [(22, 0), (30, 0), (38, 7), (42, 11)])
+def test_many_live_registers(n_temps, lds_registers):
+    """More live temps than the 16 registers of the plain kernel: the 4-instances-per-lane kernel with 32 resident registers,
+    and LDS slots for the ones beyond."""
     s = Script()
     s.acquireindex(s.const(0), 0)
     x = s.input(0, FLOAT, 0)
-    ts = s.temps(22)
+    ts = s.temps(n_temps)
     for i, t in enumerate(ts):
         s.op("mad", x if i == 0 else ts[i - 1], s.const(1), s.const(2), t)
     acc = s.temp()
@@ -194,6 +196,6 @@ def test_registers_spilled_to_lds():
     xs = np.linspace(-2, 2, n).astype(f32)
     ref, _, _ = run_oracle(built, [consts], [xs], [f32, f32], n)
     got, got_n, info = run_hip(built, [consts], [xs], [f32, f32], n)
-    assert info.InstancesPerLane == 4 and info.LdsSpillRegisters > 0 and got_n == n
+    assert info.InstancesPerLane == 4 and info.LdsSpillRegisters == lds_registers and got_n == n
     for k in range(2):
         np.testing.assert_array_equal(got[k][:n].view(np.uint32), ref[k][:n].view(np.uint32))
