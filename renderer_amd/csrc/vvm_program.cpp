@@ -210,6 +210,73 @@ static const uint32_t kMaxSpillWide = 11;      // LDS register slots of the 4-in
                                                // workgroups per CU must fit: 2 x (36 KB + 11 x 4 KB) = 160 KB)
 static const uint32_t kMaxSpillNarrow = 128;   // 1 KB each
 
+// Packs the per-lane registers of a linked program by live range.  The program is straight-line code that every tile runs from
+// the top, so a register's value lives from the instruction that writes it to the last one that reads it, and two values whose
+// ranges do not overlap can share a register.  An instruction reads all its sources before it writes its destination, so the
+// destination may take over a register whose value dies at that very instruction.  The loaded inputs keep registers
+// 0..num_loaded-1 (the load instructions address consecutive numbers) and give them up after their last use; a register that
+// is read before anything wrote it keeps a register of its own from the top of the program (its content is whatever the last
+// tile left, as the reference's is whatever its batch memory held).  Returns the number of registers in use after packing.
+static uint32_t reallocate_registers(std::vector<VvmIns>& code, uint32_t num_loaded, uint32_t provisional)
+{
+	struct Value { int32_t def, last; uint32_t reg; };
+	struct Ref { uint32_t ins, field, value; };
+	std::vector<Value> values;
+	std::vector<Ref> refs;
+	std::vector<int32_t> holds(provisional, -1);      // value each provisional register holds at the current instruction
+	auto field_of = [](VvmIns& k, uint32_t f) -> uint32_t { const uint32_t w = (&k.w1)[f >> 1]; return (f & 1) ? w >> 16 : w & 0xFFFFu; };
+	auto set_field = [](VvmIns& k, uint32_t f, uint32_t v) {
+		uint32_t& w = (&k.w1)[f >> 1];
+		w = (f & 1) ? (w & 0xFFFFu) | (v << 16) : (w & 0xFFFF0000u) | v;
+	};
+	for (uint32_t i = 0; i < num_loaded; ++i) { values.push_back(Value{-1, -1, i}); holds[i] = (int32_t)i; }
+	for (uint32_t p = 0; p < code.size(); ++p) {
+		VvmIns& k = code[p];
+		const uint32_t op = k.w0 & 0xFFu;
+		uint32_t reads = 0;
+		bool writes = false;
+		if (op == VVM_DOP_ACQUIRE || op == VVM_DOP_UPDATE_ID) reads = 1;
+		else if (op == VVM_DOP_OUTPUT32 || op == VVM_DOP_OUTPUT16 || op == VVM_DOP_OUTPUT16_FROM16 || op == VVM_DOP_OUTPUT32_FROM16) reads = (k.w0 >> 16) & 0xFFu;
+		else if (op == VVM_OP_done || op >= VVM_DOP_LOADN16) reads = 0;
+		else { reads = (k.w0 >> 8) & 7u; writes = true; }
+		for (uint32_t f = 0; f < reads; ++f) {
+			const uint32_t o = field_of(k, f);
+			if (VVM_OPND_CLS(o) != VVM_OPC_VREG) continue;
+			const uint32_t r = VVM_OPND_IDX(o);
+			if (holds[r] < 0) { holds[r] = (int32_t)values.size(); values.push_back(Value{-1, -1, 0}); }
+			values[(size_t)holds[r]].last = (int32_t)p;
+			refs.push_back(Ref{p, f, (uint32_t)holds[r]});
+		}
+		if (writes) {
+			const uint32_t o = field_of(k, 5);
+			if (VVM_OPND_CLS(o) == VVM_OPC_VREG) {
+				const uint32_t r = VVM_OPND_IDX(o);
+				holds[r] = (int32_t)values.size();
+				values.push_back(Value{(int32_t)p, (int32_t)p, 0});
+				refs.push_back(Ref{p, 5, (uint32_t)holds[r]});
+			}
+		}
+	}
+	// linear scan in order of definition; the lowest free register first
+	std::vector<uint32_t> order;
+	for (uint32_t v = num_loaded; v < values.size(); ++v) order.push_back(v);
+	std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return values[a].def < values[b].def; });
+	std::vector<int32_t> busy_until(num_loaded, 0);      // per register: last instruction that reads the value it holds
+	for (uint32_t i = 0; i < num_loaded; ++i) busy_until[i] = values[i].last;
+	for (uint32_t v : order) {
+		Value& val = values[v];
+		uint32_t reg = 0;
+		// a value defined at instruction p may take a register whose value is last read at p or earlier; a value live from the top
+		// (def -1) only a register of its own
+		while (reg < busy_until.size() && !(val.def >= 0 && busy_until[reg] <= val.def)) ++reg;
+		if (reg == busy_until.size()) busy_until.push_back(0);
+		busy_until[reg] = val.last;
+		val.reg = reg;
+	}
+	for (const Ref& r : refs) set_field(code[r.ins], r.field, VVM_OPND(VVM_OPC_VREG, values[r.value].reg));
+	return (uint32_t)busy_until.size();
+}
+
 int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, std::string& err, uint32_t pass)
 {
 	std::vector<Decoded> ins;
@@ -245,17 +312,14 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 
 	// which output registers are used as op operands (temps aliased onto output buffers, VectorVMOptimizer.cpp:2855-2978)
 	std::vector<int32_t> out_vreg(O, -1);
-	std::vector<uint32_t> vreg_uses;      // access count per virtual register
 	uint32_t nv = T;
-	vreg_uses.assign(T, 0);
 	auto reg_class_ok = [&](uint16_t r) { return r == VVM_INVALID_REG || r < out0 + O; };
 	auto touch = [&](uint16_t r) {
 		if (r == VVM_INVALID_REG) return;
-		if (r < T) { vreg_uses[r]++; return; }
+		if (r < T) return;
 		if (r >= out0) {
 			const uint32_t o = r - out0;
-			if (out_vreg[o] < 0) { out_vreg[o] = (int32_t)nv++; vreg_uses.push_back(0); }
-			vreg_uses[(size_t)out_vreg[o]]++;
+			if (out_vreg[o] < 0) out_vreg[o] = (int32_t)nv++;
 		}
 	};
 	lp.acquires_dataset.assign(std::max<uint32_t>(s.max_output_dataset, 1), 0);
@@ -314,7 +378,7 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 		if (aliasing > 1) max_scratch = std::max(max_scratch, aliasing - 1);
 	}
 	const uint32_t scratch0 = nv;
-	for (uint32_t i = 0; i < max_scratch; ++i) { ++nv; vreg_uses.push_back(1); }
+	nv += max_scratch;
 	if (lp.uses_ids && lp.updates_ids && !(lp.id_dataset < lp.acquires_dataset.size() && lp.acquires_dataset[lp.id_dataset])) {
 		err = "update_id on a dataset the script has no acquireindex for";       // it walks that dataset's keep mask (VectorVMRuntime.cpp:1178)
 		return VVM_E_UNSUPPORTED_OP;
@@ -349,39 +413,23 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 	}
 	const uint32_t num_loaded = (uint32_t)(prefetch32.size() + prefetch16.size());
 
-	// choose the kernel shape
-	// up to 16 registers: everything in VGPRs at full occupancy; up to 32 + LDS slots: the four-wide kernel with 32 resident
-	// registers; beyond: one instance per lane
-	uint32_t V = 4, RV = 16;
-	if (nv + num_loaded > 16) RV = 32;
-	if (force_narrow || nv + num_loaded > RV + kMaxSpillWide) { V = 1; RV = 32; }
-	if (nv + num_loaded > RV + (V == 4 ? kMaxSpillWide : kMaxSpillNarrow)) {
-		snprintf(msg, sizeof(msg), "script needs %u per-lane registers; the executor holds at most %u", nv + num_loaded, RV + kMaxSpillNarrow);
+	// Provisional register numbers for the emission below: the loaded inputs take 0..num_loaded-1 (consecutive numbers, in load
+	// order, which is what the load instructions address), the temps, aliased output registers and scratch registers follow.
+	// reallocate_registers() then packs the latter by live range, and the kernel shape is chosen from the packed count.
+	if (num_loaded > 160 || num_loaded + nv > VVM_MAX_OPND_INDEX) {
+		snprintf(msg, sizeof(msg), "script needs %u per-lane registers; the executor holds at most %u", num_loaded + nv, 32 + kMaxSpillNarrow);
 		err = msg;
 		return VVM_E_TOO_LARGE;
 	}
-
-	// place virtual registers: the most used ones take the VGPR-resident slots, the rest go to LDS slots
 	std::vector<uint32_t> place(nv);
-	{
-		std::vector<uint32_t> order(nv);
-		for (uint32_t i = 0; i < nv; ++i) order[i] = i;
-		if (nv > RV) std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return vreg_uses[a] > vreg_uses[b]; });
-		for (uint32_t i = 0; i < nv; ++i) place[order[i]] = i;
-	}
-	uint32_t next_vreg = nv;
-
-	// the loaded inputs follow the temps (consecutive numbers, which is what the load instructions address); when the resident
-	// registers run out they are the first to live in LDS
+	for (uint32_t i = 0; i < nv; ++i) place[i] = num_loaded + i;
 	std::vector<int32_t> input_vreg(I, -1);
-	for (uint32_t i : prefetch32) input_vreg[i] = (int32_t)next_vreg++;
-	for (uint32_t i : prefetch16) input_vreg[i] = (int32_t)next_vreg++;
+	{
+		uint32_t next_vreg = 0;
+		for (uint32_t i : prefetch32) input_vreg[i] = (int32_t)next_vreg++;
+		for (uint32_t i : prefetch16) input_vreg[i] = (int32_t)next_vreg++;
+	}
 	lp.num_prefetched_inputs = num_loaded;
-	lp.num_vregs = next_vreg;
-	lp.instances_per_lane = V;
-	lp.resident_regs = RV;
-	lp.many_registers = (RV == 32 && V == 4) || next_vreg > RV;
-	lp.lds_spill_slots = next_vreg > RV ? next_vreg - RV : 0;
 	lp.full_kernel = heavy || lp.uses_ids;      // (the ID instructions are compiled into the full kernels only)
 	lp.uses_perlin = uses_perlin;
 
@@ -576,6 +624,23 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 	}
 	lp.code.push_back(VvmIns{VVM_INS_W0(VVM_OP_done, 0, 0, 0, 0), 0, 0, 0});
 	lp.code.push_back(VvmIns{VVM_INS_W0(VVM_OP_done, 0, 0, 0, 0), 0, 0, 0});   // the kernel fetches one instruction ahead
+	// pack the per-lane registers, then choose the kernel shape: up to 16 registers: everything in VGPRs at full occupancy
+	// (four or eight instances per lane); up to 32 + LDS slots: the four-wide kernel with 32 resident registers; beyond: one
+	// instance per lane.  Registers past the resident ones live in LDS slots.
+	const uint32_t packed = reallocate_registers(lp.code, num_loaded, num_loaded + nv);
+	uint32_t V = 4, RV = 16;
+	if (packed > 16) RV = 32;
+	if (force_narrow || packed > RV + kMaxSpillWide) { V = 1; RV = 32; }
+	if (packed > RV + (V == 4 ? kMaxSpillWide : kMaxSpillNarrow)) {
+		snprintf(msg, sizeof(msg), "script needs %u per-lane registers; the executor holds at most %u", packed, RV + kMaxSpillNarrow);
+		err = msg;
+		return VVM_E_TOO_LARGE;
+	}
+	lp.num_vregs = packed;
+	lp.instances_per_lane = V;
+	lp.resident_regs = RV;
+	lp.many_registers = (RV == 32 && V == 4) || packed > RV;
+	lp.lds_spill_slots = packed > RV ? packed - RV : 0;
 	for (VvmIns& k : lp.code) {
 		const uint32_t op = k.w0 & 0xFFu;
 		if (op == VVM_OP_done || op >= VVM_DOP_LOADN16) k.w0 = (k.w0 & ~(7u << 8)) | (VVM_NIN_SPECIAL << 8);

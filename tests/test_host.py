@@ -154,7 +154,8 @@ def test_fountain_links_to_the_expected_program():
     body = [c for c in code if 0 < c["op"] < 190]
     assert [opcodes.NAME[c["op"]] for c in body] == ["add", "cmplt"] + ["mad_mul", "mad"] * 3
     info = be().inspect_blob(w.script.blob)
-    assert info.InstancesPerLane == 4 and info.LdsSpillRegisters == 0 and info.NumVirtualRegisters == 16
+    assert info.InstancesPerLane == 4 and info.LdsSpillRegisters == 0
+    assert info.NumVirtualRegisters == 9           # eight streams; most results take over the register of a stream read for the last time
     # constants are uniform-register operands, streams and temps per-lane registers
     for c in body:
         for o in c["o"][:c["nin"]]:
@@ -231,14 +232,45 @@ def test_many_registers_spill_to_lds_then_narrow_kernel():
     small = be().inspect_blob(chain(10).blob)
     assert small.InstancesPerLane == 4 and small.LdsSpillRegisters == 0
     mid = be().inspect_blob(chain(22).blob)                 # more than 16: the four-wide kernel with 32 resident registers
-    assert mid.InstancesPerLane == 4 and mid.LdsSpillRegisters == 0 and mid.NumVirtualRegisters == 23
+    assert mid.InstancesPerLane == 4 and mid.LdsSpillRegisters == 0 and mid.NumVirtualRegisters == 22
     more = be().inspect_blob(chain(36).blob)                # more than 32: the rest in LDS slots
-    assert more.InstancesPerLane == 4 and more.LdsSpillRegisters == 5
+    assert more.InstancesPerLane == 4 and more.LdsSpillRegisters == 4
     big = be().inspect_blob(chain(60).blob)
     assert big.InstancesPerLane == 1
     with pytest.raises(abi.VVMError) as e:
         be().inspect_blob(chain(400).blob)
     assert e.value.code == abi.VVM_E_TOO_LARGE
+
+
+def test_registers_are_packed_by_live_range():
+    """12 streams summed through 11 fresh temps: every sum takes over the register of a stream or sum read for the last time."""
+    s = Script()
+    s.acquireindex(s.const(0), 0)
+    xs = [s.input(0, FLOAT, i) for i in range(12)]
+    acc = xs[0]
+    for x in xs[1:]:
+        t = s.temp()
+        s.op("add", acc, x, t)
+        acc = t
+    s.output_data(FLOAT, 0, [(acc, s.output(0, FLOAT, 0))])
+    built = s.build()
+    info = be().inspect_blob(built.blob)
+    assert info.NumVirtualRegisters == 12 and info.InstancesPerLane == 4 and info.LdsSpillRegisters == 0
+    code = [decode(i) for i in be().inspect_code(built.blob)]
+    adds = [c for c in code if c["op"] == opcodes.CODE["add"]]
+    assert all(c["o"][5] in c["o"][:2] for c in adds)                            # in place
+    # a value that is still needed keeps its register: b = a + 1; c = b + 1; out = b + c  (a's register is free for b, b's not for c)
+    s = Script()
+    s.acquireindex(s.const(0), 0)
+    a = s.input(0, FLOAT, 0)
+    b, c, d = s.temps(3)
+    s.op("add", a, s.const(1), b)
+    s.op("add", b, s.const(1), c)
+    s.op("add", b, c, d)
+    s.output_data(FLOAT, 0, [(d, s.output(0, FLOAT, 0))])
+    code = [decode(i) for i in be().inspect_code(s.build().blob)]
+    adds = [c for c in code if c["op"] == opcodes.CODE["add"]]
+    assert adds[0]["o"][5] == adds[0]["o"][0] and adds[1]["o"][5] != adds[1]["o"][0] and adds[2]["o"][5] in adds[2]["o"][:2]
 
 
 def test_half_and_noadvance_inputs():
