@@ -258,16 +258,45 @@ VVM_API int vvm_state_info(const vvm_state* state, vvm_program_info* out);
  * Lets host-side tooling validate a script on a machine with no GPU. */
 VVM_API int vvm_inspect_blob(const uint8_t* blob, size_t num_bytes, vvm_program_info* out);
 
-/* Thaw and link a blob without touching a device and copy out the linked device program: 4 dwords per instruction
- * (renderer_amd/csrc/vvm_device.h gives the encoding), at most `capacity_instructions` of them.  Returns the number of
- * instructions of the program (negative status code on failure).  narrow != 0 links for the 1-instance-per-lane kernel. */
 /* Instances per lane (8, 4 or 1) of the kernel the state's last vvm_exec* ran on; 0 before the first.  No counterpart in the
  * reference (its loop is always four wide, VectorVMRuntime.cpp:2135-2175). */
 VVM_API int32_t vvm_state_last_exec_width(const vvm_state* state);
 /* vm.PageSizeInKB (VectorVMRuntime.cpp:44-50, default 64): the page the reference sizes its chunks by (:2210-2261).  The
  * executor does not chunk, but Internal.* and the chunk-dependent results of update_id / acquire_id follow it.  Process-wide. */
 VVM_API void vvm_set_page_size_kb(int kb);
+/* Thaw and link a blob without touching a device and copy out the linked device program: 4 dwords per instruction
+ * (renderer_amd/csrc/vvm_device.h gives the encoding), at most `capacity_instructions` of them.  Returns the number of
+ * instructions of the program (negative status code on failure).  narrow != 0 links for the 1-instance-per-lane kernel. */
 VVM_API int vvm_inspect_code(const uint8_t* blob, size_t num_bytes, int narrow, uint32_t* out_words, int32_t capacity_instructions);
+
+/* ---- script compile side (host only, no device) ----
+ * OptimizeVectorVMScript (VectorVMOptimizer.h:17, VectorVMOptimizer.cpp:700-3177) followed by FreezeOptimizerContext
+ * (VectorVMBridge.h:25, VectorVMBridge.cpp:151-178): takes bytecode in the format the Niagara compiler emits (decoder
+ * VectorVMOptimizer.cpp:744-1025) plus the input / output counts of its external functions, and returns the frozen blob that
+ * vvm_alloc_state consumes, in malloc'd memory released with vvm_free_blob.  A NULL or one-byte script yields no blob
+ * (*blob = NULL) and VVM_OK, as the reference returns 0 and leaves the context empty (:703-712).  On failure returns
+ * VVM_E_BAD_BLOB with the reference's EVectorVMOptimizeError bits (VectorVMEditor.h:104-120) in *error_flags. */
+typedef struct vvm_ext_fn_io {      /* the counts of FVectorVMExtFunctionData, VectorVM.h:360-365 */
+	int32_t NumInputs;
+	int32_t NumOutputs;
+} vvm_ext_fn_io;
+enum {
+	VVM_OPT_ERR_OUT_OF_MEMORY         = 1 << 0,
+	VVM_OPT_ERR_OVERFLOW              = 1 << 1,
+	VVM_OPT_ERR_BYTECODE              = 1 << 2,
+	VVM_OPT_ERR_REGISTER_USAGE        = 1 << 3,
+	VVM_OPT_ERR_CONST_REMAP           = 1 << 4,
+	VVM_OPT_ERR_INSTRUCTIONS          = 1 << 5,
+	VVM_OPT_ERR_INPUT_MERGE_BUFFER    = 1 << 6,
+	VVM_OPT_ERR_INSTRUCTION_REORDER   = 1 << 7,
+	VVM_OPT_ERR_SSA_REMAP             = 1 << 8,
+	VVM_OPT_ERR_OPTIMIZED_BYTECODE    = 1 << 9,
+	VVM_OPT_ERR_EXTERNAL_FUNCTION     = 1 << 10,
+	VVM_OPT_ERR_REDUNDANT_INSTRUCTION = 1 << 11
+};
+VVM_API int vvm_optimize_script(const uint8_t* bytecode, int32_t num_bytes, const vvm_ext_fn_io* ext_fns, int32_t num_ext_fns,
+                                uint64_t hash_id, uint32_t flags, uint8_t** blob, size_t* blob_bytes, uint32_t* error_flags);
+VVM_API void vvm_free_blob(uint8_t* blob);
 
 /* Thread-local text of the last failure in this library. */
 VVM_API const char* vvm_last_error(void);

@@ -294,6 +294,11 @@ class HipBackend(Backend):
         L.vvm_state_collect_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
         L.vvm_state_copy_counts.restype = C.c_int
         L.vvm_state_copy_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.vvm_optimize_script.restype = C.c_int
+        L.vvm_optimize_script.argtypes = [C.c_char_p, C.c_int32, C.c_void_p, C.c_int32, C.c_uint64, C.c_uint32,
+                                          C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32)]
+        L.vvm_free_blob.restype = None
+        L.vvm_free_blob.argtypes = [C.c_void_p]
 
     def _check(self, rc: int, where: str) -> None:
         if rc != VVM_OK:
@@ -349,6 +354,21 @@ class HipBackend(Backend):
         pi = ProgramInfo()
         self._check(self.lib.vvm_state_info(state, C.byref(pi)), "vvm_state_info")
         return pi
+
+    def optimize_script(self, bytecode: bytes, ext_fns: Sequence = (), hash_id: int = 0, flags: int = 0) -> bytes:
+        """OptimizeVectorVMScript + FreezeOptimizerContext (VectorVMOptimizer.cpp:700, VectorVMBridge.cpp:151): bytecode in the
+        compiler's format -> frozen blob.  ``ext_fns`` = (NumInputs, NumOutputs) per external function.  An empty script gives b"".
+        Raises VVMError carrying the optimizer's error bits."""
+        io = (C.c_int32 * (2 * len(ext_fns)))(*[v for pair in ext_fns for v in pair]) if ext_fns else None
+        blob, size, err = C.c_void_p(), C.c_size_t(), C.c_uint32()
+        rc = self.lib.vvm_optimize_script(bytecode, len(bytecode), C.cast(io, C.c_void_p) if io else None, len(ext_fns), hash_id, flags,
+                                          C.byref(blob), C.byref(size), C.byref(err))
+        if rc != VVM_OK:
+            raise VVMError(rc, "vvm_optimize_script", "optimizer error flags 0x%x" % err.value)
+        try:
+            return C.string_at(blob, size.value) if blob.value else b""
+        finally:
+            self.lib.vvm_free_blob(blob)
 
 
 def hip_library_path() -> str:

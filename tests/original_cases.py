@@ -1,0 +1,163 @@
+"""Scripts in the compiler's bytecode format for the optimizer tests, and a restatement of such a script by other means:
+``translate`` turns the instruction list of an OriginalScript into an assembler Script one instruction at a time (no reordering,
+no merged ops, every output its own instruction), so that the optimizer's output can be checked against it on the same inputs."""
+from __future__ import annotations
+
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+from renderer_amd.assembler import FLOAT, HALF, INT32, INVALID, Script
+from renderer_amd.original import K, UNUSED, OriginalScript
+
+f32 = np.float32
+
+
+def translate(orig: OriginalScript) -> Script:
+    s = Script()
+    for ni, no in orig.ext:
+        s.ext_fn(ni, no)
+    cur: Dict[int, object] = {}            # temp register -> the operand that holds its value now
+    half_of: Dict[int, object] = {}        # temp register -> converted copy of a half input
+
+    def read(o, for_output_type=None):
+        if isinstance(o, K):
+            return s.const(o.dword), False
+        v = cur[o]
+        if getattr(v, "kind", "") == "i" and v.b == HALF:
+            if for_output_type is not None:
+                return v, True                 # outputs copy half inputs directly (the *_from_half instructions)
+            if o not in half_of:
+                t = s.temp()
+                s.op("half_to_float", v, t)
+                half_of[o] = t
+            return half_of[o], False
+        return v, False
+
+    for ins in orig.ir:
+        kind = ins[0]
+        if kind == "input":
+            _, ds, typ, index, noadvance, dst = ins
+            cur[dst] = s.input(ds, typ, index, noadvance)
+            half_of.pop(dst, None)
+        elif kind == "op":
+            _, name, srcs, dst = ins
+            if name in ("fasi", "iasf"):       # bit casts: the same bits under another name
+                cur[dst] = read(srcs[0])[0]
+                half_of.pop(dst, None)
+                continue
+            operands = [read(o)[0] for o in srcs]
+            t = s.temp()
+            s.op(name, *operands, t)
+            cur[dst] = t
+            half_of.pop(dst, None)
+        elif kind == "acquireindex":
+            _, pred, index_temp, ds = ins
+            s.acquireindex(read(pred)[0], ds)
+        elif kind == "output":
+            _, typ, ds, index_temp, src, dst_reg = ins
+            v, from_half = read(src, typ)
+            s.output_data(typ, ds, [(v, s.output(ds, typ, dst_reg))], from_half=from_half)
+        elif kind == "call":
+            _, fn, ins_, outs = ins
+            a = [INVALID if o == UNUSED else read(o)[0] for o in ins_]
+            b = []
+            for o in outs:
+                if o == UNUSED:
+                    b.append(INVALID)
+                else:
+                    t = s.temp()
+                    cur[o] = t
+                    half_of.pop(o, None)
+                    b.append(t)
+            s.call(fn, a, b)
+        elif kind == "exec_index":
+            t = s.temp()
+            s.op("exec_index", t)
+            cur[ins[1]] = t
+        elif kind == "update_id":
+            _, ds, a, b = ins
+            s.update_id(read(a)[0], read(b)[0], ds)
+        elif kind == "acquire_id":
+            _, ds, a, b = ins
+            ta, tb = s.temp(), s.temp()
+            cur[a], cur[b] = ta, tb
+            s.acquire_id(ta, tb, ds)
+    return s
+
+
+# ---- scripts ----------------------------------------------------------------------------------------------------------------
+def fountain() -> Tuple[OriginalScript, dict]:
+    """The particle update of renderer_amd.scripts.fountain as a compiler would write it: all inputs first, one temp per value,
+    the kill test and acquireindex in the middle, all outputs last.  Constants: dt, gx, gy, gz, drag (dwords 0..4)."""
+    o = OriginalScript()
+    px, py, pz, vx, vy, vz, age, life = [o.input(0, FLOAT, i, o.temp()) for i in range(8)]
+    dt, g, drag = K(0), [K(1), K(2), K(3)], K(4)
+    age2 = o.temp(); o.op("add", age, dt, age2)
+    alive = o.temp(); o.op("cmplt", age2, life, alive)
+    vel, pos = [], []
+    for v, p, gi in zip((vx, vy, vz), (px, py, pz), g):
+        t = o.temp(); o.op("mad", gi, dt, v, t)
+        v2 = o.temp(); o.op("mul", t, drag, v2)
+        p2 = o.temp(); o.op("mad", v2, dt, p, p2)
+        vel.append(v2); pos.append(p2)
+    idx = o.temp(); o.acquireindex(alive, idx, 0)
+    for i, r in enumerate(pos + vel + [age2]):
+        o.output(FLOAT, 0, idx, r, i)
+    o.output(FLOAT, 0, idx, life, 7)
+    return o, {"n_in": 8, "n_out": 8, "consts": np.array([1 / 60, 0, 0, -980, 0.98], f32).tobytes()}
+
+
+# (first op, second op, which operand of the second reads the first's result, merged opcode expected)
+MERGE_PAIRS: List[Tuple[str, str, int, str]] = [
+    ("mad", "add", 0, "mad_add"), ("mad", "add", 1, "mad_add"), ("mad", "mul", 0, "mad_mul"), ("mad", "sub", 0, "mad_sub0"),
+    ("mad", "sub", 1, "mad_sub1"), ("mad", "sqrt", 0, "mad_sqrt"), ("mad", "mad", 2, "mad_mad0"), ("mad", "mad", 0, "mad_mad1"),
+    ("mad", "mad", 1, "mad_mad1"),
+    ("mul", "mad", 0, "mul_mad0"), ("mul", "mad", 1, "mul_mad0"), ("mul", "mad", 2, "mul_mad1"), ("mul", "add", 0, "mul_add"),
+    ("mul", "add", 1, "mul_add"), ("mul", "sub", 0, "mul_sub0"), ("mul", "sub", 1, "mul_sub1"), ("mul", "mul", 1, "mul_mul"),
+    ("mul", "max", 0, "mul_max"),
+    ("add", "mad", 2, "add_mad1"), ("add", "add", 1, "add_add"),
+    ("sub", "cmplt", 1, "sub_cmplt1"), ("sub", "neg", 0, "sub_neg"), ("sub", "mul", 0, "sub_mul"),
+    ("div", "mad", 0, "div_mad0"), ("div", "mad", 1, "div_mad0"), ("div", "f2i", 0, "div_f2i"), ("div", "mul", 1, "div_mul"),
+    ("muli", "addi", 0, "muli_addi"), ("addi", "bit_rshift", 0, "addi_bit_rshift"), ("addi", "muli", 1, "addi_muli"),
+    ("i2f", "div", 0, "i2f_div0"), ("i2f", "div", 1, "i2f_div1"), ("i2f", "mul", 0, "i2f_mul"), ("i2f", "mad", 0, "i2f_mad0"),
+    ("i2f", "mad", 1, "i2f_mad0"), ("i2f", "mad", 2, "i2f_mad1"),
+    ("f2i", "select", 1, "f2i_select1"), ("f2i", "maxi", 0, "f2i_maxi"), ("f2i", "addi", 1, "f2i_addi"),
+    ("bit_and", "i2f", 0, "bit_and_i2f"), ("select", "mul", 0, "select_mul"), ("select", "add", 1, "select_add"),
+    ("neg", "cmplt", 0, "neg_cmplt"), ("neg", "cmplt", 1, "neg_cmplt"), ("max", "f2i", 0, "max_f2i"),
+    ("bit_rshift", "bit_and", 0, "bit_rshift_bit_and"), ("fmod", "add", 0, "fmod_add"), ("bit_or", "muli", 1, "bit_or_muli"),
+    ("bit_lshift", "bit_or", 0, "bit_lshift_bit_or"),
+    ("cmplt", "select", 0, "cmplt_select"), ("cmple", "select", 0, "cmple_select"), ("cmpgt", "select", 0, "cmple_select"),
+    ("cmpge", "select", 0, "cmplt_select"), ("cmpeq", "select", 0, "cmpeq_select"), ("cmpneq", "select", 0, "cmpeq_select"),
+    ("cmplti", "select", 0, "cmplti_select"), ("cmplei", "select", 0, "cmplei_select"), ("cmpgti", "select", 0, "cmplei_select"),
+    ("cmpgei", "select", 0, "cmplti_select"), ("cmpeqi", "select", 0, "cmpeqi_select"), ("cmpneqi", "select", 0, "cmpeqi_select"),
+] + [("cmp%s%s" % (c, s), "logic_%s" % l, pos, "cmp%s%s_logic_%s" % ("ne" if c == "neq" else c, s, l))
+     for c in ("lt", "le", "gt", "ge", "eq", "neq") for s in ("", "i") for l, pos in (("and", 0), ("or", 1))]
+
+INT_IN = {"addi", "subi", "muli", "divi", "mini", "maxi", "cmplti", "cmplei", "cmpgti", "cmpgei", "cmpeqi", "cmpneqi", "bit_and", "bit_or",
+          "bit_xor", "bit_lshift", "bit_rshift", "logic_and", "logic_or", "i2f"}
+
+
+def merge_pair(first: str, second: str, position: int) -> Tuple[OriginalScript, dict]:
+    """in0..in5 -> r = first(...); out0 = second(.., r at `position`, ..).  Three float and three int32 input streams; the ops
+    take whichever fit.  Two inputs come first so that instruction 1 of the script is not an op."""
+    from renderer_amd.original import op_inputs
+    o = OriginalScript()
+    fl = [o.input(0, FLOAT, i, o.temp()) for i in range(3)]
+    it = [o.input(0, INT32, i, o.temp()) for i in range(3)]
+    ones = K(0)
+    idx = o.temp(); o.acquireindex(ones, idx, 0)
+
+    def sources(name, count, skip=0):
+        pool = it if name in INT_IN else fl
+        if name == "select":           # an int stream as the mask (a fresh compare would itself merge with the select)
+            return [it[0], fl[1], fl[2]]
+        return [pool[(skip + i) % 3] for i in range(count)]
+
+    a_src = sources(first, op_inputs(first))
+    r = o.temp(); o.op(first, *a_src, r)
+    b_src = sources(second, op_inputs(second), skip=1)
+    b_src[position] = r
+    out = o.temp(); o.op(second, *b_src, out)
+    o.output(FLOAT, 0, idx, out, 0)          # a 32-bit output copies bits, whatever they mean
+    return o, {"n_float_in": 3, "n_int_in": 3}
