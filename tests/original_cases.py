@@ -126,7 +126,7 @@ MERGE_PAIRS: List[Tuple[str, str, int, str]] = [
     ("bit_and", "i2f", 0, "bit_and_i2f"), ("select", "mul", 0, "select_mul"), ("select", "add", 1, "select_add"),
     ("neg", "cmplt", 0, "neg_cmplt"), ("neg", "cmplt", 1, "neg_cmplt"), ("max", "f2i", 0, "max_f2i"),
     ("bit_rshift", "bit_and", 0, "bit_rshift_bit_and"), ("fmod", "add", 0, "fmod_add"), ("bit_or", "muli", 1, "bit_or_muli"),
-    ("bit_lshift", "bit_or", 0, "bit_lshift_bit_or"),
+    ("bit_lshift", "bit_or", 0, "bit_lshift_bit_or"), ("random", "add", 0, "random_add"), ("random", "add", 1, "random_add"),
     ("cmplt", "select", 0, "cmplt_select"), ("cmple", "select", 0, "cmple_select"), ("cmpgt", "select", 0, "cmple_select"),
     ("cmpge", "select", 0, "cmplt_select"), ("cmpeq", "select", 0, "cmpeq_select"), ("cmpneq", "select", 0, "cmpeq_select"),
     ("cmplti", "select", 0, "cmplti_select"), ("cmplei", "select", 0, "cmplei_select"), ("cmpgti", "select", 0, "cmplei_select"),
