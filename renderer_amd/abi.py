@@ -382,5 +382,12 @@ def load_hip_backend() -> HipBackend:
         if not os.path.exists(_HIP_LIB_PATH):
             raise RuntimeError("%s is missing: build it with `python __graft_entry__.py build` "
                                "(there is no CPU fallback for the VectorVM executor)" % _HIP_LIB_PATH)
+        # PyTorch brings its own copy of the HIP runtime.  A process that has initialised one copy cannot open the GPU through
+        # the other ("No HIP GPUs are available"), so when torch is installed its copy is loaded first and this library binds to
+        # it (same soname); callers that never use torch lose nothing.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _hip_backend = HipBackend(C.CDLL(_HIP_LIB_PATH))
     return _hip_backend

@@ -669,31 +669,47 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 	auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
 	const auto t_begin = now();
 	std::vector<PreparedExec> pes((size_t)n);
-	// group by kernel shape: (instances per lane, spill, full)
-	struct Group { int key; std::vector<int> members; uint32_t tiles = 0; uint32_t spill = 0; };
-	std::vector<Group> groups;
-	size_t total_bytes = 0; uint32_t total_tiles = 0;
-	for (int i = 0; i < n; ++i) {
-		if (!ctxs[i].VVMState) return fail(VVM_E_INVALID_ARG, "null state in batch");
-		if (ctxs[i].VVMState->batch_stamp == stamp) return fail(VVM_E_INVALID_ARG, "a state appears twice in one batch (one Exec at a time per state)");
-		ctxs[i].VVMState->batch_stamp = stamp;
-		rc = prepare(ctxs[i].VVMState, &ctxs[i], opts ? &opts[i] : nullptr, pes[(size_t)i]);
-		if (rc != VVM_OK) return rc;
-		vvm_state* st = ctxs[i].VVMState;
-		if (st->in_flight && st->last_stream) { HIP_TRY(hipStreamSynchronize(st->last_stream)); st->in_flight = false; }
-		const vvm::LinkedProgram& lp = *pes[(size_t)i].lp;
-		if (lp.uses_ids) return fail(VVM_E_UNSUPPORTED_OP, "scripts with update_id / acquire_id cannot be part of a batched Exec");
-		if (lp.num_passes > 1) return fail(VVM_E_UNSUPPORTED_OP, "scripts with acquireindex on several datasets cannot be part of a batched Exec");
-		const int key = (int)pes[(size_t)i].instances_per_lane * 4 + (lp.many_registers ? 2 : 0) + (lp.full_kernel ? 1 : 0);
-		Group* g = nullptr;
-		for (Group& c : groups) if (c.key == key) g = &c;
-		if (!g) { groups.push_back(Group{key, {}, 0, 0}); g = &groups.back(); }
-		g->members.push_back(i);
-		g->spill = std::max(g->spill, lp.lds_spill_slots);
-		total_bytes += pes[(size_t)i].bytes;
-		total_tiles += pes[(size_t)i].tiles;
+	// The batch is cut into slices of consecutive Execs; a slice is filled, uploaded and launched while the kernels of the
+	// slices before it run, so that most of the host's work on the parameter blocks is hidden behind the GPU.  Within a slice
+	// the Execs are grouped by kernel shape (instances per lane, register tier, full), one launch per group.
+	const int num_slices = n >= 4096 ? 4 : n >= 1024 ? 2 : 1;
+	struct Group { int key; std::vector<int> members; uint32_t tiles = 0; uint32_t spill = 0; size_t desc_off = 0; };
+	struct Slice { int first = 0, count = 0; std::vector<Group> groups; size_t region_off = 0, region_bytes = 0; };
+	std::vector<Slice> slices((size_t)num_slices);
+	uint32_t total_tiles = 0;
+	size_t total_needed = 0;
+	for (int sl = 0; sl < num_slices; ++sl) {
+		Slice& slice = slices[(size_t)sl];
+		slice.first = (int)((int64_t)n * sl / num_slices);
+		slice.count = (int)((int64_t)n * (sl + 1) / num_slices) - slice.first;
+		size_t table_bytes = 0;
+		for (int i = slice.first; i < slice.first + slice.count; ++i) {
+			if (!ctxs[i].VVMState) return fail(VVM_E_INVALID_ARG, "null state in batch");
+			if (ctxs[i].VVMState->batch_stamp == stamp) return fail(VVM_E_INVALID_ARG, "a state appears twice in one batch (one Exec at a time per state)");
+			ctxs[i].VVMState->batch_stamp = stamp;
+			rc = prepare(ctxs[i].VVMState, &ctxs[i], opts ? &opts[i] : nullptr, pes[(size_t)i]);
+			if (rc != VVM_OK) return rc;
+			vvm_state* st = ctxs[i].VVMState;
+			if (st->in_flight && st->last_stream) { HIP_TRY(hipStreamSynchronize(st->last_stream)); st->in_flight = false; }
+			const vvm::LinkedProgram& lp = *pes[(size_t)i].lp;
+			if (lp.uses_ids) return fail(VVM_E_UNSUPPORTED_OP, "scripts with update_id / acquire_id cannot be part of a batched Exec");
+			if (lp.num_passes > 1) return fail(VVM_E_UNSUPPORTED_OP, "scripts with acquireindex on several datasets cannot be part of a batched Exec");
+			const int key = (int)pes[(size_t)i].instances_per_lane * 4 + (lp.many_registers ? 2 : 0) + (lp.full_kernel ? 1 : 0);
+			Group* g = nullptr;
+			for (Group& c : slice.groups) if (c.key == key) g = &c;
+			if (!g) { slice.groups.push_back(Group{key, {}, 0, 0, 0}); g = &slice.groups.back(); }
+			g->members.push_back(i);
+			g->spill = std::max(g->spill, lp.lds_spill_slots);
+			table_bytes += pes[(size_t)i].bytes;
+			total_tiles += pes[(size_t)i].tiles;
+		}
+		if (slice.groups.size() > 8) return fail(VVM_E_TOO_LARGE, "too many kernel shapes in one batch");
+		// a slice's region of the parameter buffer: the descriptors of its groups, contiguous per group (the kernel indexes them),
+		// then the tables of its Execs
+		slice.region_off = total_needed;
+		slice.region_bytes = align_up((size_t)slice.count * sizeof(VvmExecDesc), 256) + table_bytes;
+		total_needed += align_up(slice.region_bytes, 256);
 	}
-	if (groups.size() > 8) return fail(VVM_E_TOO_LARGE, "too many kernel shapes in one batch");
 	const auto t_prepared = now();
 	if (!g_batch.stream) HIP_TRY(hipStreamCreateWithFlags(&g_batch.stream, hipStreamNonBlocking));
 	if (total_tiles > g_batch.status_capacity) {
@@ -702,12 +718,14 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 		HIP_TRY(hipMalloc((void**)&g_batch.d_status, (size_t)g_batch.status_capacity * 8));
 		HIP_TRY(hipMemset(g_batch.d_status, 0, (size_t)g_batch.status_capacity * 8));
 	}
-	if (!g_batch.h_launch) HIP_TRY(hipHostMalloc((void**)&g_batch.h_launch, 8 * sizeof(VvmLaunchState), hipHostMallocDefault));
-	for (size_t g = 0; g < groups.size(); ++g)
-		if (!g_batch.d_launch[g]) {
-			HIP_TRY(hipMalloc((void**)&g_batch.d_launch[g], sizeof(VvmLaunchState)));
-			HIP_TRY(reset_launch_state(g_batch.d_launch[g]));
-		}
+	const size_t launch_slots = 4 * 8;      // (slices x groups)
+	if (!g_batch.h_launch) HIP_TRY(hipHostMalloc((void**)&g_batch.h_launch, launch_slots * sizeof(VvmLaunchState), hipHostMallocDefault));
+	for (const Slice& slice : slices)
+		for (size_t g = 0; g < slice.groups.size(); ++g)
+			if (!g_batch.d_launch[g]) {
+				HIP_TRY(hipMalloc((void**)&g_batch.d_launch[g], sizeof(VvmLaunchState)));
+				HIP_TRY(reset_launch_state(g_batch.d_launch[g]));
+			}
 
 	// one counts array for the whole batch (a device-to-host copy per state would cost more than the kernel)
 	std::vector<size_t> counts_off((size_t)n);
@@ -721,16 +739,6 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 		HIP_TRY(hipHostMalloc((void**)&g_batch.h_counts, g_batch.counts_capacity * 4, hipHostMallocDefault));
 	}
 	HIP_TRY(hipMemsetAsync(g_batch.d_counts, 0, total_counts * 4, g_batch.stream));
-
-	// Descriptors of one group are contiguous (the kernel indexes them); their tables follow all descriptors.
-	size_t desc_off = 0;
-	size_t table_off = align_up((size_t)n * sizeof(VvmExecDesc), 256);
-	uint32_t status_off = 0;
-	std::vector<size_t> group_desc_off(groups.size());
-	// per-exec parameter blocks are laid out as [desc | tables] by fill_params; here desc and tables are split, so fill into a
-	// scratch block and scatter (filling the pinned buffer in place measured slower: 0.58 ms against 0.42 ms for 4096 Execs)
-	std::vector<uint8_t> scratch;
-	const size_t total_needed = table_off + total_bytes;
 	if (total_needed > g_batch.bytes) {
 		if (g_batch.host) (void)hipHostFree(g_batch.host);
 		if (g_batch.dev) (void)hipFree(g_batch.dev);
@@ -738,56 +746,74 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 		HIP_TRY(hipHostMalloc((void**)&g_batch.host, g_batch.bytes, hipHostMallocDefault));
 		HIP_TRY(hipMalloc((void**)&g_batch.dev, g_batch.bytes));
 	}
-	for (size_t g = 0; g < groups.size(); ++g) {
-		group_desc_off[g] = desc_off;
-		uint32_t first_tile = 0;
-		for (int i : groups[g].members) {
-			PreparedExec& pe = pes[(size_t)i];
-			vvm_state* st = ctxs[i].VVMState;
-			// tables live at table_off in the device buffer; fill_params computes table addresses as dev + pe.off_*
-			uint8_t* dev_block = g_batch.dev + table_off;
-			scratch.resize(pe.bytes);
-			rc = fill_params(st, &ctxs[i], opts ? &opts[i] : nullptr, pe, scratch.data(), dev_block, g_batch.d_status + status_off, first_tile,
-			                 g_batch.d_counts + counts_off[(size_t)i]);
-			if (rc != VVM_OK) return rc;
-			memcpy(g_batch.host + desc_off, scratch.data(), sizeof(VvmExecDesc));
-			memcpy(g_batch.host + table_off, scratch.data(), pe.bytes);
-			desc_off += sizeof(VvmExecDesc);
-			table_off += pe.bytes;
-			status_off += pe.tiles;
-			first_tile += pe.tiles;
+
+	// per-exec parameter blocks are laid out as [desc | tables] by fill_params; here desc and tables are split, so fill into a
+	// scratch block and scatter (filling the pinned buffer in place measured slower: 0.58 ms against 0.42 ms for 4096 Execs)
+	std::vector<uint8_t> scratch;
+	uint32_t status_off = 0;
+	double fill_us = 0.0;
+	size_t parameter_bytes = 0;
+	for (int sl = 0; sl < num_slices; ++sl) {
+		Slice& slice = slices[(size_t)sl];
+		const auto t_slice = now();
+		size_t desc_off = slice.region_off;
+		size_t table_off = slice.region_off + align_up((size_t)slice.count * sizeof(VvmExecDesc), 256);
+		for (Group& grp : slice.groups) {
+			grp.desc_off = desc_off;
+			uint32_t first_tile = 0;
+			for (int i : grp.members) {
+				PreparedExec& pe = pes[(size_t)i];
+				vvm_state* st = ctxs[i].VVMState;
+				// tables live at table_off in the device buffer; fill_params computes table addresses as dev + pe.off_*
+				uint8_t* dev_block = g_batch.dev + table_off;
+				scratch.resize(pe.bytes);
+				rc = fill_params(st, &ctxs[i], opts ? &opts[i] : nullptr, pe, scratch.data(), dev_block, g_batch.d_status + status_off, first_tile,
+				                 g_batch.d_counts + counts_off[(size_t)i]);
+				if (rc != VVM_OK) { (void)hipStreamSynchronize(g_batch.stream); return rc; }
+				st->last_width = pe.instances_per_lane;
+				memcpy(g_batch.host + desc_off, scratch.data(), sizeof(VvmExecDesc));
+				memcpy(g_batch.host + table_off, scratch.data(), pe.bytes);
+				desc_off += sizeof(VvmExecDesc);
+				table_off += pe.bytes;
+				status_off += pe.tiles;
+				first_tile += pe.tiles;
+			}
+			grp.tiles = first_tile;
 		}
-		groups[g].tiles = first_tile;
-	}
-	const auto t_filled = now();
-	HIP_TRY(hipMemcpyAsync(g_batch.dev, g_batch.host, table_off, hipMemcpyHostToDevice, g_batch.stream));
-	for (size_t g = 0; g < groups.size(); ++g) {
-		if (groups[g].tiles == 0) continue;
-		const vvm::LinkedProgram& lp = *pes[(size_t)groups[g].members[0]].lp;
-		const int lrc = vvm_launch_exec_kernel((int)pes[(size_t)groups[g].members[0]].instances_per_lane, (const VvmExecDesc*)(g_batch.dev + group_desc_off[g]),
-		                                       (uint32_t)groups[g].members.size(), groups[g].tiles, g_batch.d_launch[g], lp.many_registers ? 1 : 0, groups[g].spill,
-		                                       lp.full_kernel ? 1 : 0,
-		                                       grid_for(groups[g].tiles, pes[(size_t)groups[g].members[0]].instances_per_lane, lp.full_kernel, lp.many_registers), g_batch.stream);
-		if (lrc != 0) return hip_fail((hipError_t)lrc, "batched kernel launch");
-		HIP_TRY(hipMemcpyAsync(&g_batch.h_launch[g], g_batch.d_launch[g], 80, hipMemcpyDeviceToHost, g_batch.stream));
+		fill_us += us(t_slice, now());
+		parameter_bytes += table_off - slice.region_off;
+		if (slice.count == 0) continue;
+		HIP_TRY(hipMemcpyAsync(g_batch.dev + slice.region_off, g_batch.host + slice.region_off, table_off - slice.region_off, hipMemcpyHostToDevice, g_batch.stream));
+		for (size_t g = 0; g < slice.groups.size(); ++g) {
+			const Group& grp = slice.groups[g];
+			if (grp.tiles == 0) continue;
+			const PreparedExec& pe0 = pes[(size_t)grp.members[0]];
+			const vvm::LinkedProgram& lp = *pe0.lp;
+			const int lrc = vvm_launch_exec_kernel((int)pe0.instances_per_lane, (const VvmExecDesc*)(g_batch.dev + grp.desc_off), (uint32_t)grp.members.size(), grp.tiles,
+			                                       g_batch.d_launch[g], lp.many_registers ? 1 : 0, grp.spill, lp.full_kernel ? 1 : 0,
+			                                       grid_for(grp.tiles, pe0.instances_per_lane, lp.full_kernel, lp.many_registers), g_batch.stream);
+			if (lrc != 0) { (void)hipStreamSynchronize(g_batch.stream); return hip_fail((hipError_t)lrc, "batched kernel launch"); }
+			HIP_TRY(hipMemcpyAsync(&g_batch.h_launch[(size_t)sl * 8 + g], g_batch.d_launch[g], 80, hipMemcpyDeviceToHost, g_batch.stream));
+		}
 	}
 	HIP_TRY(hipMemcpyAsync(g_batch.h_counts, g_batch.d_counts, total_counts * 4, hipMemcpyDeviceToHost, g_batch.stream));
 	const auto t_enqueued = now();
 	HIP_TRY(hipStreamSynchronize(g_batch.stream));
 	if (report)
-		fprintf(stderr, "vvm batch host phases (us): prepare %.0f  fill %.0f  enqueue %.0f  wait %.0f  (%d Execs, %zu parameter bytes)\n",
-		        us(t_begin, t_prepared), us(t_prepared, t_filled), us(t_filled, t_enqueued), us(t_enqueued, now()), n, table_off);
+		fprintf(stderr, "vvm batch host phases (us): prepare %.0f  fill %.0f (of %.0f in %d slices, launches in between)  wait %.0f  (%d Execs, %zu parameter bytes)\n",
+		        us(t_begin, t_prepared), fill_us, us(t_prepared, t_enqueued), num_slices, us(t_enqueued, now()), n, parameter_bytes);
 	for (int i = 0; i < n; ++i) {
 		vvm_state* st = ctxs[i].VVMState;
 		const size_t ncounts = std::max<uint32_t>(st->script.max_output_dataset, 1);
 		memcpy(st->h_counts, g_batch.h_counts + counts_off[(size_t)i], ncounts * 4);
 	}
-	for (size_t g = 0; g < groups.size(); ++g)
-		if (groups[g].tiles && g_batch.h_launch[g].pad != 0) {
-			(void)reset_launch_state(g_batch.d_launch[g]);
-			(void)hipMemset(g_batch.d_status, 0, (size_t)g_batch.status_capacity * 8);
-			return fail(VVM_E_HIP, "look-back timed out inside the batched kernel");
-		}
+	for (int sl = 0; sl < num_slices; ++sl)
+		for (size_t g = 0; g < slices[(size_t)sl].groups.size(); ++g)
+			if (slices[(size_t)sl].groups[g].tiles && g_batch.h_launch[(size_t)sl * 8 + g].pad != 0) {
+				for (size_t k = 0; k < 8; ++k) if (g_batch.d_launch[k]) (void)reset_launch_state(g_batch.d_launch[k]);
+				(void)hipMemset(g_batch.d_status, 0, (size_t)g_batch.status_capacity * 8);
+				return fail(VVM_E_HIP, "look-back timed out inside the batched kernel");
+			}
 	for (int i = 0; i < n; ++i) write_back_counts(ctxs[i].VVMState, &ctxs[i], ctxs[i].NumInstances > 0);
 	return VVM_OK;
 }

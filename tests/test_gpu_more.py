@@ -199,6 +199,47 @@ def test_batched_execs_with_distinct_bytecode():
             ds.free()
 
 
+def test_large_batch_is_launched_in_slices():
+    """1100 emitters: the batch is cut into two slices that are filled and launched one after the other; every emitter's result
+    equals its own Exec on the oracle.  The streams of all emitters are ranges of one device allocation per attribute."""
+    import torch
+    be = abi.load_hip_backend()
+    dev = torch.device("cuda", 0)
+    emitters = 1100
+    sizes = [(e * 37) % 500 for e in range(emitters)]
+    sizes[700] = 270_000                       # one emitter on the eight-wide kernel, in the second slice
+    starts, total = [], 0
+    for n in sizes:
+        starts.append(total)
+        total += (n + PAD + 63) // 64 * 64
+    host_in = scripts.fountain_streams_np(7, total, kill_half=True)
+    d_in = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in host_in]
+    d_out = [torch.full((total,), -3.0, dtype=torch.float32, device=dev) for _ in range(8)]
+    torch.cuda.synchronize()
+    states, frames = [], []
+    try:
+        for e in range(emitters):
+            w = scripts.fountain(variant=e % 64)
+            st = VectorVMState(w.script.blob, be)
+            states.append(st)
+            off = starts[e] * 4
+            frames.append(st.frame([abi.DataSet([t.data_ptr() + off for t in d_in], [t.data_ptr() + off for t in d_out], 0)], sizes[e], [w.constants]))
+        be.exec_batch(frames, [abi.ExecOptions(0, 0, 0, None, 0) for _ in range(emitters)])
+        got = [t.cpu().numpy() for t in d_out]
+        for e in range(0, emitters, 7):
+            w = scripts.fountain(variant=e % 64)
+            n = sizes[e]
+            ins = [a[starts[e]:starts[e] + max(n, 1)] for a in host_in]
+            ref, ref_n, _ = run_oracle(w.script, [w.constants], ins, [f32] * 8, n)
+            assert frames[e].survivors(0) == ref_n, "emitter %d" % e
+            for k in range(8):
+                assert np.array_equal(_bits(got[k][starts[e]:starts[e] + ref_n]), _bits(ref[k][:ref_n])), "emitter %d stream %d" % (e, k)
+        assert states[700].last_exec_width() == 8 and states[699].last_exec_width() == 4
+    finally:
+        for st in states:
+            st.close()
+
+
 def test_async_execs_in_a_row():
     be = abi.load_hip_backend()
     w = scripts.fountain()
