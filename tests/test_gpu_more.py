@@ -302,6 +302,42 @@ def test_full_size_against_torch(kill_half):
         st.close()
 
 
+def test_streams_larger_than_4_gib():
+    """1.2 G particles, half of them dying: every stream is 4.8 GB, so instance and output positions pass 2^30 and byte offsets
+    pass 2^32.  Checked like the full-size test, one attribute at a time to bound the memory of the check."""
+    import torch
+    n = 1_200_000_123
+    dev = torch.device("cuda", 0)
+    be = abi.load_hip_backend()
+    w = scripts.fountain()
+    ins = scripts.fountain_streams_torch(0, n, dev, kill_half=True, pad=64)
+    outs = [torch.full((n + 64,), -7.0, dtype=torch.float32, device=dev) for _ in range(8)]
+    torch.cuda.synchronize()
+    st = VectorVMState(w.script.blob, be)
+    try:
+        frame = st.frame([abi.DataSet([t.data_ptr() for t in ins], [t.data_ptr() for t in outs], 0)], n, [w.constants])
+        surv = st.exec(frame)
+        dt, drag = torch.tensor(1.0 / 60.0, dtype=torch.float32, device=dev), torch.tensor(0.98, dtype=torch.float32, device=dev)
+        age1 = ins[6][:n] + dt
+        keep = age1 < ins[7][:n]
+        assert surv == int(keep.sum().item()) and n // 3 < surv < 2 * (n // 3)
+        assert torch.equal(outs[6][:surv].view(torch.int32), age1[keep].view(torch.int32))
+        del age1
+        assert torch.equal(outs[7][:surv].view(torch.int32), ins[7][:n][keep].view(torch.int32))
+        for c in range(3):
+            g = torch.tensor(-980.0 if c == 2 else 0.0, dtype=torch.float32, device=dev)
+            v1 = (g * dt + ins[3 + c][:n]) * drag
+            assert torch.equal(outs[3 + c][:surv].view(torch.int32), v1[keep].view(torch.int32)), "velocity %d" % c
+            p1 = v1 * dt + ins[c][:n]
+            del v1
+            assert torch.equal(outs[c][:surv].view(torch.int32), p1[keep].view(torch.int32)), "position %d" % c
+            del p1
+        for k in range(8):
+            assert bool((outs[k][surv:] == -7.0).all()), "stream %d written past its survivors" % k
+    finally:
+        st.close()
+
+
 # ---- two datasets ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n,secondary_first,many", [(1, False, False), (1000, False, False), (5003, True, False), (300007, False, True), (300007, True, False)])
 def test_two_datasets_match_the_oracle(n, secondary_first, many):
