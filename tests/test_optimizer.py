@@ -331,3 +331,31 @@ def test_optimized_blob_links_for_the_gpu():
     info = be().inspect_blob(optimize(o))
     assert (info.NumInputBuffers, info.NumOutputBuffers, info.BytesInPerInstance, info.BytesOutPerInstance) == (8, 8, 32, 32)
     assert info.InstancesPerLane == 4 and info.NumVirtualRegisters <= 16
+
+
+def test_malformed_bytecode_is_rejected_or_optimized_never_fatal():
+    """Random bytes and mutated / truncated copies of a real script: a status comes back every time (tools/fuzz_optimizer.cpp runs
+    the same under the host sanitizers)."""
+    import random
+    r = random.Random(1)
+    base = oc.fountain()[0].done()
+    outcomes = {"ok": 0, "rejected": 0}
+    for _ in range(3000):
+        if r.random() < 0.3:
+            b = bytes(r.randrange(256) for _ in range(r.randrange(2, 80)))
+        else:
+            m = bytearray(base)
+            for _ in range(r.randrange(1, 6)):
+                m[r.randrange(len(m))] = r.randrange(256)
+            b = bytes(m[:r.randrange(2, len(m))] if r.random() < 0.2 else m)
+        try:
+            blob = be().optimize_script(b, [(3, 3), (3, 1)])
+            outcomes["ok"] += 1
+            if blob:
+                try:
+                    be().inspect_blob(blob)
+                except abi.VVMError:
+                    pass
+        except abi.VVMError:
+            outcomes["rejected"] += 1
+    assert outcomes["ok"] > 100 and outcomes["rejected"] > 100
