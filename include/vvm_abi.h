@@ -232,8 +232,11 @@ VVM_API int vvm_exec_ex(vvm_exec_context* ctx, const vvm_exec_options* opt);
 VVM_API int vvm_exec_async(vvm_exec_context* ctx, const vvm_exec_options* opt);
 VVM_API int vvm_exec_finish(vvm_exec_context* ctx);
 
-/* Many independent Execs (one state each, e.g. one per emitter) in ONE kernel launch.
- * Same result as calling vvm_exec_ex on each context in order. opts may be NULL or an array of n. */
+/* Many independent Execs (one state each, e.g. one per emitter) in one call: one kernel launch per kernel shape (a batch of 1024
+ * Execs or more is cut into up to four slices that are filled and launched one after the other, so that filling the parameter
+ * blocks overlaps the kernels).  Scripts with update_id / acquire_id, or with acquireindex on several datasets, take launches
+ * of their own behind the batched ones.  Same result as calling vvm_exec_ex on each context in order.  opts may be NULL or an
+ * array of n.  No counterpart in the reference, which runs one Exec per call (VectorVMRuntime.cpp:2182). */
 VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_options* opts);
 
 /* Device pointer (int32[MaxOutputDataSet]) to the survivor counts of the last Exec of this state;

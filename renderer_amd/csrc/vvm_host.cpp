@@ -676,6 +676,7 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 	struct Group { int key; std::vector<int> members; uint32_t tiles = 0; uint32_t spill = 0; size_t desc_off = 0; };
 	struct Slice { int first = 0, count = 0; std::vector<Group> groups; size_t region_off = 0, region_bytes = 0; };
 	std::vector<Slice> slices((size_t)num_slices);
+	std::vector<uint8_t> single((size_t)n, 0);
 	uint32_t total_tiles = 0;
 	size_t total_needed = 0;
 	for (int sl = 0; sl < num_slices; ++sl) {
@@ -692,8 +693,9 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 			vvm_state* st = ctxs[i].VVMState;
 			if (st->in_flight && st->last_stream) { HIP_TRY(hipStreamSynchronize(st->last_stream)); st->in_flight = false; }
 			const vvm::LinkedProgram& lp = *pes[(size_t)i].lp;
-			if (lp.uses_ids) return fail(VVM_E_UNSUPPORTED_OP, "scripts with update_id / acquire_id cannot be part of a batched Exec");
-			if (lp.num_passes > 1) return fail(VVM_E_UNSUPPORTED_OP, "scripts with acquireindex on several datasets cannot be part of a batched Exec");
+			// Scripts with ID instructions (they need the MaxUsedID pass and the dataset's counters) and scripts that take one kernel
+			// pass per acquired dataset do not share a launch: they are enqueued one by one behind the batched kernels, on the same stream.
+			if (lp.uses_ids || lp.num_passes > 1) { single[(size_t)i] = 1; continue; }
 			const int key = (int)pes[(size_t)i].instances_per_lane * 4 + (lp.many_registers ? 2 : 0) + (lp.full_kernel ? 1 : 0);
 			Group* g = nullptr;
 			for (Group& c : slice.groups) if (c.key == key) g = &c;
@@ -730,7 +732,10 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 	// one counts array for the whole batch (a device-to-host copy per state would cost more than the kernel)
 	std::vector<size_t> counts_off((size_t)n);
 	size_t total_counts = 0;
-	for (int i = 0; i < n; ++i) { counts_off[(size_t)i] = total_counts; total_counts += std::max<uint32_t>(ctxs[i].VVMState->script.max_output_dataset, 1); }
+	for (int i = 0; i < n; ++i) {
+		counts_off[(size_t)i] = total_counts;
+		if (!single[(size_t)i]) total_counts += std::max<uint32_t>(ctxs[i].VVMState->script.max_output_dataset, 1);
+	}
 	if (total_counts > g_batch.counts_capacity) {
 		if (g_batch.d_counts) (void)hipFree(g_batch.d_counts);
 		if (g_batch.h_counts) (void)hipHostFree(g_batch.h_counts);
@@ -738,7 +743,7 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 		HIP_TRY(hipMalloc((void**)&g_batch.d_counts, g_batch.counts_capacity * 4));
 		HIP_TRY(hipHostMalloc((void**)&g_batch.h_counts, g_batch.counts_capacity * 4, hipHostMallocDefault));
 	}
-	HIP_TRY(hipMemsetAsync(g_batch.d_counts, 0, total_counts * 4, g_batch.stream));
+	if (total_counts) HIP_TRY(hipMemsetAsync(g_batch.d_counts, 0, total_counts * 4, g_batch.stream));
 	if (total_needed > g_batch.bytes) {
 		if (g_batch.host) (void)hipHostFree(g_batch.host);
 		if (g_batch.dev) (void)hipFree(g_batch.dev);
@@ -796,13 +801,21 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 			HIP_TRY(hipMemcpyAsync(&g_batch.h_launch[(size_t)sl * 8 + g], g_batch.d_launch[g], 80, hipMemcpyDeviceToHost, g_batch.stream));
 		}
 	}
-	HIP_TRY(hipMemcpyAsync(g_batch.h_counts, g_batch.d_counts, total_counts * 4, hipMemcpyDeviceToHost, g_batch.stream));
+	if (total_counts) HIP_TRY(hipMemcpyAsync(g_batch.h_counts, g_batch.d_counts, total_counts * 4, hipMemcpyDeviceToHost, g_batch.stream));
+	for (int i = 0; i < n; ++i) {
+		if (!single[(size_t)i]) continue;
+		vvm_exec_options o = opts ? opts[i] : vvm_exec_options{};
+		o.Stream = g_batch.stream;
+		rc = vvm_exec_async(&ctxs[i], &o);
+		if (rc != VVM_OK) { (void)hipStreamSynchronize(g_batch.stream); return rc; }
+	}
 	const auto t_enqueued = now();
 	HIP_TRY(hipStreamSynchronize(g_batch.stream));
 	if (report)
 		fprintf(stderr, "vvm batch host phases (us): prepare %.0f  fill %.0f (of %.0f in %d slices, launches in between)  wait %.0f  (%d Execs, %zu parameter bytes)\n",
 		        us(t_begin, t_prepared), fill_us, us(t_prepared, t_enqueued), num_slices, us(t_enqueued, now()), n, parameter_bytes);
 	for (int i = 0; i < n; ++i) {
+		if (single[(size_t)i]) continue;
 		vvm_state* st = ctxs[i].VVMState;
 		const size_t ncounts = std::max<uint32_t>(st->script.max_output_dataset, 1);
 		memcpy(st->h_counts, g_batch.h_counts + counts_off[(size_t)i], ncounts * 4);
@@ -814,7 +827,14 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 				(void)hipMemset(g_batch.d_status, 0, (size_t)g_batch.status_capacity * 8);
 				return fail(VVM_E_HIP, "look-back timed out inside the batched kernel");
 			}
-	for (int i = 0; i < n; ++i) write_back_counts(ctxs[i].VVMState, &ctxs[i], ctxs[i].NumInstances > 0);
+	for (int i = 0; i < n; ++i) {
+		if (single[(size_t)i]) {
+			rc = vvm_exec_finish(&ctxs[i]);
+			if (rc != VVM_OK) return rc;
+		} else {
+			write_back_counts(ctxs[i].VVMState, &ctxs[i], ctxs[i].NumInstances > 0);
+		}
+	}
 	return VVM_OK;
 }
 

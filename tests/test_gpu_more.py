@@ -240,6 +240,83 @@ def test_large_batch_is_launched_in_slices():
             st.close()
 
 
+def test_id_and_multi_dataset_scripts_inside_a_batch():
+    """A batch may hold scripts with update_id / acquire_id and scripts that acquire several datasets: they run behind the batched
+    kernels on the same stream, with the results of an Exec of their own; the plain emitters around them are unaffected."""
+    import dataset_cases
+    import id_cases
+    from vm_harness import IdState
+    be = abi.load_hip_backend()
+    plain, states, streams, refs = [], [], [], []
+    try:
+        for e in range(4):
+            w = scripts.fountain(variant=e)
+            n = 3000 + 511 * e
+            ins = scripts.fountain_streams_np(e * 7777, n, kill_half=True)
+            refs.append(run_oracle(w.script, [w.constants], ins, [f32] * 8, n))
+            ds = _DeviceStreams(be, ins, 8, n)
+            streams.append(ds)
+            st = VectorVMState(w.script.blob, be)
+            states.append(st)
+            plain.append(st.frame([abi.DataSet(ds.ins, ds.outs, 0)], n, [w.constants]))
+
+        def check_plain():
+            for e in range(4):
+                ref, ref_n, _ = refs[e]
+                assert plain[e].survivors(0) == ref_n
+                for k in range(8):
+                    assert np.array_equal(_bits(streams[e].download(k)[:ref_n]), _bits(ref[k][:ref_n]))
+
+        # update_id
+        n = 70001
+        rng = np.random.default_rng(11)
+        x = rng.random(n).astype(f32)
+        ids = rng.permutation(n + 7)[:n].astype(np.int32)
+        st0 = IdState(np.full(n + 7, -1, np.int32), np.full(2 * n + 16, -7, np.int32), num_free=5, max_used=3)
+        st0.free_table[:5] = [100001, 100002, 100003, 100004, 100005]
+        script, consts = id_cases.update_script(), [id_cases.update_constants(f32(0.5))]
+        want, got = st0.copy(), st0.copy()
+        ref, ref_n, _ = run_oracle(script, consts, [x, ids], [f32, np.int32], n, ids=want, page_kb=2)
+        out, out_n, _ = run_hip(script, consts, [x, ids], [f32, np.int32], n, ids=got, page_kb=2, batch_with=plain)
+        assert out_n == ref_n
+        for a, b in zip(out, ref):
+            assert np.array_equal(_bits(a[:out_n]), _bits(b[:ref_n]))
+        assert np.array_equal(got.id_table, want.id_table) and np.array_equal(got.free_table, want.free_table)
+        assert (got.num_free, got.max_used) == (want.num_free, want.max_used)
+        check_plain()
+
+        # acquire_id
+        m = 4099
+        sp = IdState(np.zeros(0, np.int32), np.full(3 * m + 40, -3, np.int32), num_free=m + 11, max_used=0, num_spawned=6, tag=77)
+        sp.free_table[:m + 11] = rng.permutation(10 * m + 100)[:m + 11]
+        want, got = sp.copy(), sp.copy()
+        sconsts = [bytes([255] * 4) + bytes(12)]
+        ref, ref_n, _ = run_oracle(id_cases.spawn_script(), sconsts, [], [np.int32, np.int32], m, ids=want)
+        out, out_n, _ = run_hip(id_cases.spawn_script(), sconsts, [], [np.int32, np.int32], m, ids=got, batch_with=plain)
+        assert out_n == ref_n == m and np.array_equal(out[0][:m], ref[0][:m]) and np.array_equal(out[1][:m], ref[1][:m])
+        assert np.array_equal(got.free_table, want.free_table) and (got.num_free, got.num_spawned) == (want.num_free, want.num_spawned)
+
+        # two acquired datasets
+        k = 5003
+        xx, yy = rng.random(k).astype(f32), rng.random(k).astype(f32)
+        two = dataset_cases.two_dataset_script(True, False)
+        tconsts = [dataset_cases.constants(0.5, 0.7)]
+        ref_more, got_more = [], []
+        ref, ref_n, _ = run_oracle(two, tconsts, [xx, yy], [f32] * 2, k, more_datasets=[[f32, np.int32]], more_results=ref_more)
+        out, out_n, _ = run_hip(two, tconsts, [xx, yy], [f32] * 2, k, more_datasets=[[f32, np.int32]], more_results=got_more, batch_with=plain)
+        assert out_n == ref_n and got_more[0][1] == ref_more[0][1]
+        for a, b in zip(out, ref):
+            assert np.array_equal(_bits(a[:out_n]), _bits(b[:ref_n]))
+        for a, b in zip(got_more[0][0], ref_more[0][0]):
+            assert np.array_equal(a[:got_more[0][1]].view(np.uint32), b[:ref_more[0][1]].view(np.uint32))
+        check_plain()
+    finally:
+        for st in states:
+            st.close()
+        for ds in streams:
+            ds.free()
+
+
 def test_async_execs_in_a_row():
     be = abi.load_hip_backend()
     w = scripts.fountain()

@@ -87,8 +87,10 @@ def run_hip(script: BuiltScript, const_tables: Sequence[bytes], inputs: Sequence
             out_dtypes: Sequence, n: int, instance_offset: int = 0, ext_fns: Sequence = (),
             seed: int = 0, exec_index_base: int = 0, rand_instance_base: int = 0, flags: int = 0,
             out_fill: int = 0xCD, repeat: int = 1, ids: Optional[IdState] = None, page_kb: int = 64,
-            more_datasets: Sequence[Sequence] = (), more_results: Optional[list] = None) -> Tuple[List[np.ndarray], int, abi.ProgramInfo]:
-    """Same contract as run_oracle, through the C ABI of libvvm_hip.so with streams in device memory."""
+            more_datasets: Sequence[Sequence] = (), more_results: Optional[list] = None,
+            batch_with: Optional[Sequence] = None) -> Tuple[List[np.ndarray], int, abi.ProgramInfo]:
+    """Same contract as run_oracle, through the C ABI of libvvm_hip.so with streams in device memory.
+    batch_with: call frames of other emitters; the Exec then runs as the middle member of one vvm_exec_batch call with them."""
     be = abi.load_hip_backend()
     L = be.lib
     total = instance_offset + n + PAD
@@ -136,7 +138,13 @@ def run_hip(script: BuiltScript, const_tables: Sequence[bytes], inputs: Sequence
             frame = abi.CallFrame(state, [ds] + more_ds, n, const_tables, ext_fns)
             opt = abi.ExecOptions(seed, exec_index_base, rand_instance_base, None, flags)
             for _ in range(repeat):
-                be.exec_ex(frame, opt)
+                if batch_with is None:
+                    be.exec_ex(frame, opt)
+                else:
+                    others = list(batch_with)
+                    half = len(others) // 2
+                    plain = abi.ExecOptions(0, 0, 0, None, 0)
+                    be.exec_batch(others[:half] + [frame] + others[half:], [plain] * half + [opt] + [plain] * (len(others) - half))
             surv = frame.survivors(0)
             info = be.info(state)
             if more_results is not None:
