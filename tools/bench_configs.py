@@ -3,6 +3,8 @@
 
   transcendental   16 Mi particles, sin_cos + exp + curl-noise script            (BASELINE.json configs[2])
   kill_half        64 Mi particles, fountain with 50 % death                      (configs[3], one GPU's share scaled down)
+  kill_half_250m   250 M particles, fountain with 50 % death                      (configs[3], one GPU's share of 2 G particles)
+  one_million      1 Mi particles, fountain                                       (configs[0], the reference's CPU-runnable case)
   batch            4096 emitters x 16 Ki particles, 64 distinct bytecode bodies, one launch per kernel shape  (configs[4])
 
 Prints one JSON object per configuration.  Times are wall-clock around synchronous calls (vvm_exec / vvm_exec_batch), so
@@ -98,6 +100,14 @@ def main():
         n = 64 * 1024 * 1024
         w = scripts.fountain()
         run_single("fountain 64Mi, 50% death", w, scripts.fountain_streams_torch(0, n, dev, kill_half=True, pad=PAD), 8, n)
+    if "kill_half_250m" in which:
+        n = 250_000_000
+        w = scripts.fountain()
+        run_single("fountain 250M, 50% death (one GPU's share of 2G particles)", w, scripts.fountain_streams_torch(0, n, dev, kill_half=True, pad=PAD), 8, n)
+    if "one_million" in which:
+        n = 1024 * 1024
+        w = scripts.fountain()
+        run_single("fountain 1Mi", w, scripts.fountain_streams_torch(0, n, dev, pad=PAD), 8, n)
     if "batch" in which:
         emitters, per = 4096, 16384
         total = emitters * per
