@@ -359,3 +359,16 @@ def test_malformed_bytecode_is_rejected_or_optimized_never_fatal():
         except abi.VVMError:
             outcomes["rejected"] += 1
     assert outcomes["ok"] > 100 and outcomes["rejected"] > 100
+
+
+def test_golden_blobs():
+    """Today's output for a set of scripts (tests/golden/make_optimizer_golden.py wrote them): a change of the optimizer's output
+    must be deliberate."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "optimizer_fixtures.json")) as f:
+        cases = json.load(f)
+    assert len(cases) >= 10
+    for name, c in cases.items():
+        got = be().optimize_script(bytes.fromhex(c["bytecode"]), [tuple(e) for e in c["ext_fns"]])
+        assert got.hex() == c["blob"], name
