@@ -101,3 +101,37 @@ def disassemble(t: Thawed) -> List[Tuple]:
             _, ni, no = OPS[name]
             out.append((name,) + tuple(t.reg(u16(p + 2 * i)) for i in range(ni + no))); p += 2 * (ni + no)
     return out
+
+
+def listing(blob: bytes) -> str:
+    """The script as text, one instruction per line, with the side tables first: what the reference's GenerateHumanReadableScript
+    (VectorVMOptimizer.cpp:220-253) is for."""
+    t = thaw(blob)
+    kinds = ("float", "int32", "half")
+    lines = ["temps %d  constants %d  inputs %d  outputs %d  external functions %d  flags 0x%x  hash 0x%016x"
+             % (t.num_temps, len(t.const_remap), len(t.input_remap), len(t.out_dst), len(t.ext_fns), t.flags, t.hash_id)]
+    lines += ["c%-3d = constant dword %d" % (i, d) for i, d in enumerate(t.const_remap)]
+    for ds in range(len(t.input_dataset_offsets) // 8):
+        off = t.input_dataset_offsets[8 * ds:8 * ds + 8]
+        for k in range(6):
+            for i in range(off[k], off[k + 1]):
+                lines.append("i%-3d = dataset %d %s%s input %d" % (i, ds, "no-advance " if k >= 3 else "", kinds[k % 3], t.input_remap[i]))
+    for i, d in enumerate(t.out_dst):
+        lines.append("o%-3d = dataset %d %s output %s" % (i, t.out_dataset[i], kinds[t.out_type[i]], "-" if d == 0xFFFF else d))
+    for i, (a, b) in enumerate(t.ext_fns):
+        lines.append("fn%-2d = external function, %d inputs, %d outputs" % (i, a, b))
+    for n, c in enumerate(t.code):
+        name = c[0]
+        if name.startswith("outputdata"):
+            body = "dataset %d: %s" % (c[1], ", ".join("%s -> %s" % p for p in c[2]))
+        elif name == "acquireindex":
+            body = "%s, dataset %d" % (c[1], c[2])
+        elif name == "external_func_call":
+            body = "fn%d(%s)" % (c[1], ", ".join(c[2]))
+        elif name in ("update_id", "acquire_id"):
+            body = "%s, %s, dataset %d" % (c[1], c[2], c[3])
+        else:
+            _, ni, no = OPS.get(name, (0, 0, len(c) - 1))
+            body = "%s = (%s)" % (", ".join(c[1 + ni:]), ", ".join(c[1:1 + ni])) if ni else ", ".join(c[1:])
+        lines.append("%3d | %-22s %s" % (n, name, body))
+    return "\n".join(lines)

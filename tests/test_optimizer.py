@@ -372,3 +372,10 @@ def test_golden_blobs():
     for name, c in cases.items():
         got = be().optimize_script(bytes.fromhex(c["bytecode"]), [tuple(e) for e in c["ext_fns"]])
         assert got.hex() == c["blob"], name
+
+
+def test_listing_reads_like_the_script():
+    from renderer_amd.disasm import listing
+    text = listing(optimize(oc.fountain()[0]))
+    assert "  1 | cmplt                  o0 = (o6, i7)" in text and "acquireindex           o0, dataset 0" in text
+    assert "c2   = constant dword 4" in text and "i7   = dataset 0 float input 7" in text and text.count("outputdata_float") == 3
