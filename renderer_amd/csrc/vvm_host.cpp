@@ -133,6 +133,7 @@ struct vvm_state {
 	hipStream_t last_stream = nullptr;
 	bool in_flight = false;                // an asynchronous Exec has been enqueued and not finished yet
 	uint64_t batch_stamp = 0;              // the last vvm_exec_batch call this state took part in
+	bool results_pending = false;          // a kernel has run whose counts have not been copied back yet
 
 	// map caches, VectorVMRuntime.cpp:485-553 (constants only: inputs are classified at link time)
 	bool maps_ready = false;
@@ -527,6 +528,7 @@ VVM_API int vvm_exec_async(vvm_exec_context* ctx, const vvm_exec_options* opt)
 	st->in_flight = true;
 	st->last_width = pe.instances_per_lane;
 	if (pe.tiles == 0) {     // nothing to run: zero chunks in the reference too (RT.cpp:2277)
+		if (st->results_pending) { HIP_TRY(hipStreamSynchronize(stream)); st->results_pending = false; }
 		st->h_counts[0] = 0;
 		for (uint32_t i = 0; i < st->script.max_output_dataset; ++i) st->h_counts[i] = 0;
 		return VVM_OK;
@@ -591,8 +593,9 @@ VVM_API int vvm_exec_async(vvm_exec_context* ctx, const vvm_exec_options* opt)
 		HIP_TRY(hipEventRecord(st->ring.done[slot], stream));
 		st->ring.pending[slot] = true;
 	}
-	HIP_TRY(hipMemcpyAsync(st->h_counts, st->d_counts, (ncounts + 1) * 4, hipMemcpyDeviceToHost, stream));     // (and the MaxUsedID word)
-	HIP_TRY(hipMemcpyAsync(st->h_counts + ncounts + 4, st->d_launch, 80, hipMemcpyDeviceToHost, stream));     // the words up to and including stats[]
+	// (the survivor counts and the launch words come back in vvm_exec_finish: of several Execs queued on a state only the last
+	// one's are reported, and two copies per Exec were a fifth of the host's time per call)
+	st->results_pending = true;
 	return VVM_OK;
 }
 
@@ -601,7 +604,15 @@ VVM_API int vvm_exec_finish(vvm_exec_context* ctx)
 	if (!ctx || !ctx->VVMState) return fail(VVM_E_INVALID_ARG, "null context or state");
 	vvm_state* st = ctx->VVMState;
 	const bool ran = ctx->NumInstances > 0;
-	if (st->last_stream) HIP_TRY(hipStreamSynchronize(st->last_stream));
+	if (st->last_stream) {
+		if (st->results_pending) {
+			const size_t nc = std::max<uint32_t>(st->script.max_output_dataset, 1);
+			HIP_TRY(hipMemcpyAsync(st->h_counts, st->d_counts, (nc + 1) * 4, hipMemcpyDeviceToHost, st->last_stream));     // (and the MaxUsedID word)
+			HIP_TRY(hipMemcpyAsync(st->h_counts + nc + 4, st->d_launch, 80, hipMemcpyDeviceToHost, st->last_stream));     // the words up to and including stats[]
+		}
+		HIP_TRY(hipStreamSynchronize(st->last_stream));
+	}
+	st->results_pending = false;
 	st->in_flight = false;
 	if (ran) {
 		const size_t ncounts = std::max<uint32_t>(st->script.max_output_dataset, 1);
