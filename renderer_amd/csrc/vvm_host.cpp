@@ -90,7 +90,7 @@ struct ParamRing {
 
 struct DeviceInfo {
 	int num_cus = 256;
-	bool ready = false;
+	bool ready[64] = {};      // per device ordinal: the kernels' LDS limit has been raised there
 };
 DeviceInfo g_dev;
 std::mutex g_dev_mutex;
@@ -98,14 +98,15 @@ std::mutex g_dev_mutex;
 int ensure_device_info()
 {
 	std::lock_guard<std::mutex> lock(g_dev_mutex);
-	if (g_dev.ready) return VVM_OK;
 	int dev = 0;
 	HIP_TRY(hipGetDevice(&dev));
+	if (dev < 0 || dev >= 64) return fail(VVM_E_INVALID_ARG, "device ordinal out of range");
+	if (g_dev.ready[dev]) return VVM_OK;
 	hipDeviceProp_t prop;
 	HIP_TRY(hipGetDeviceProperties(&prop, dev));
 	g_dev.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-	(void)vvm_kernel_max_dynamic_lds();
-	g_dev.ready = true;
+	(void)vvm_kernel_max_dynamic_lds();      // (a function attribute belongs to the device that is current)
+	g_dev.ready[dev] = true;
 	return VVM_OK;
 }
 

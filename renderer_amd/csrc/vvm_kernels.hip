@@ -1567,19 +1567,15 @@ extern "C" int vvm_launch_exec_kernel(int instances_per_lane, const VvmExecDesc*
 
 extern "C" int vvm_kernel_max_dynamic_lds(void)
 {
-	static int done = 0;
+	// raises the dynamic-LDS limit of the kernels that use more than the default 64 KB, on the current device
 #ifndef VVM_EXPERIMENT_ONE_KERNEL
-	if (!done) {
-		(void)hipFuncSetAttribute((const void*)vvm_exec_kernel<4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-		(void)hipFuncSetAttribute((const void*)vvm_exec_kernel<1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-		(void)hipFuncSetAttribute((const void*)vvm_exec_kernel<4, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-		(void)hipFuncSetAttribute((const void*)vvm_exec_kernel<1, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-		(void)hipFuncSetAttribute((const void*)vvm_exec_kernel<8, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-		(void)hipFuncSetAttribute((const void*)vvm_exec_kernel<8, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-		done = 1;
-	}
+	(void)hipFuncSetAttribute((const void*)vvm_exec_kernel<4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+	(void)hipFuncSetAttribute((const void*)vvm_exec_kernel<1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+	(void)hipFuncSetAttribute((const void*)vvm_exec_kernel<4, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+	(void)hipFuncSetAttribute((const void*)vvm_exec_kernel<1, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+	(void)hipFuncSetAttribute((const void*)vvm_exec_kernel<8, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+	(void)hipFuncSetAttribute((const void*)vvm_exec_kernel<8, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
 #endif
-	(void)done;
 	return 160 * 1024 - 64;
 }
 

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 
 namespace vvm {
 
@@ -80,11 +81,10 @@ enum OpKind : uint8_t { K_INVALID = 0, K_ORD, K_DST_ONLY, K_ACQUIRE, K_OUTPUT, K
 struct OpInfo { uint8_t kind, nin, nout; bool heavy; };
 
 static OpInfo g_ops[256];
-static bool g_ops_ready = false;
+static std::once_flag g_ops_once;
 
-static void build_op_table()
+static void fill_op_table()
 {
-	if (g_ops_ready) return;
 	memset(g_ops, 0, sizeof(g_ops));
 	auto set = [](std::initializer_list<int> ops, uint8_t nin, uint8_t nout) {
 		for (int o : ops) g_ops[o] = OpInfo{K_ORD, nin, nout, false};
@@ -123,8 +123,8 @@ static void build_op_table()
 	g_ops[VVM_OP_external_func_call] = OpInfo{K_EXTFN, 0, 0, true};
 	g_ops[VVM_OP_update_id] = OpInfo{K_IDS, 2, 0, false};
 	g_ops[VVM_OP_acquire_id] = OpInfo{K_IDS, 0, 2, false};
-	g_ops_ready = true;
 }
+static void build_op_table() { std::call_once(g_ops_once, fill_op_table); }
 
 // ---- decoded instruction -----------------------------------------------------------------------------
 struct Decoded {
