@@ -393,13 +393,62 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 	lp.pass_dataset = pass_dataset;
 	if (multi_pass && lp.updates_ids && lp.id_dataset != pass_dataset) { lp.uses_ids = false; lp.updates_ids = false; }     // update_id runs in its dataset's pass
 
+	// Instructions whose results reach neither an output, an acquireindex nor an ID table of this pass are left out (one
+	// backward sweep over the straight-line script).  A pass of a script with several acquired datasets then only computes what
+	// its own dataset needs, and only loads the streams that feeds on.  Nothing observable changes: such results live in
+	// per-lane registers only, also where the script keeps them in an output register.
+	std::vector<uint8_t> needed(ins.size(), 1);
+	{
+		std::vector<uint8_t> live((size_t)out0 + O, 0);
+		auto holds_value = [&](uint16_t r) { return r != VVM_INVALID_REG && (r < T || r >= out0); };
+		heavy = false; uses_perlin = false;
+		for (size_t k = ins.size(); k-- > 0;) {
+			const Decoded& d = ins[k];
+			const bool other_pass = multi_pass && d.dataset != pass_dataset;
+			bool keep = true;
+			switch (d.kind) {
+			case K_OUTPUT:
+				keep = !other_pass;
+				if (keep) for (auto& p : d.pairs) if (holds_value(p.first)) live[p.first] = 1;
+				break;
+			case K_ACQUIRE:
+				keep = !other_pass;
+				if (keep && holds_value(d.in[0])) live[d.in[0]] = 1;
+				break;
+			case K_IDS:
+				if (d.op == VVM_OP_update_id) {
+					keep = !other_pass;
+					if (keep && holds_value(d.in[0])) live[d.in[0]] = 1;
+				} else {
+					for (uint16_t r : d.out) if (holds_value(r)) live[r] = 0;      // (kept whatever reads it: it takes IDs off the free list)
+				}
+				break;
+			case K_ORD: case K_DST_ONLY: case K_EXTFN: {
+				keep = false;
+				for (uint16_t r : d.out) keep |= holds_value(r) && live[r];
+				if (keep) {
+					for (uint16_t r : d.out) if (holds_value(r)) live[r] = 0;
+					for (uint16_t r : d.in) if (holds_value(r)) live[r] = 1;
+					if (g_ops[d.op].heavy) heavy = true;
+					if (d.kind == K_EXTFN) uses_perlin = true;
+				}
+				break;
+			}
+			default: break;
+			}
+			needed[k] = keep ? 1 : 0;
+		}
+	}
+
 	// Every advancing input stream the script reads is loaded once, at the start of a tile, into a per-lane register of its own
 	// (VVM_DOP_LOADN / VVM_DOP_LOADN16, eight streams per instruction, in order of first use; 32-bit streams first).  The
 	// interpreter loop itself then never touches stream memory.
 	std::vector<uint32_t> prefetch32, prefetch16;
 	{
 		std::vector<uint8_t> seen(I, 0);
-		for (const Decoded& d : ins) {
+		for (size_t k = 0; k < ins.size(); ++k) {
+			if (!needed[k]) continue;
+			const Decoded& d = ins[k];
 			auto consider = [&](uint16_t r) {
 				if (r == VVM_INVALID_REG || r < T + C || r >= T + C + I) return;
 				const uint32_t i = r - (T + C);
@@ -514,7 +563,9 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 		}
 		return out_cursor;
 	};
-	for (const Decoded& d : ins) {
+	for (size_t at_ins = 0; at_ins < ins.size(); ++at_ins) {
+		if (!needed[at_ins]) continue;
+		const Decoded& d = ins[at_ins];
 		VvmIns k{0, 0, 0, 0};
 		switch (d.kind) {
 		case K_ORD: case K_DST_ONLY: {
@@ -646,7 +697,7 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 		if (op == VVM_OP_done || op >= VVM_DOP_LOADN16) k.w0 = (k.w0 & ~(7u << 8)) | (VVM_NIN_SPECIAL << 8);
 	}
 
-	for (const InputInfo& in : lp.inputs) if (!in.noadvance) lp.bytes_in_per_instance += (in.type == 2) ? 2 : 4;
+	lp.bytes_in_per_instance += 4u * (uint32_t)prefetch32.size() + 2u * (uint32_t)prefetch16.size();      // the streams this pass loads
 	for (uint32_t i = 0; i < s.num_outputs_remapped; ++i) if (s.out_dst[i] != 0xFFFF) lp.bytes_out_per_instance += (s.out_type[i] == 2) ? 2 : 4;
 	return VVM_OK;
 }

@@ -273,6 +273,25 @@ def test_registers_are_packed_by_live_range():
     assert adds[0]["o"][5] == adds[0]["o"][0] and adds[1]["o"][5] != adds[1]["o"][0] and adds[2]["o"][5] in adds[2]["o"][:2]
 
 
+def test_instructions_nothing_reads_are_left_out():
+    """A chain whose result reaches no output, acquireindex or ID table is not linked, and the stream only it reads is not loaded."""
+    s = Script()
+    s.acquireindex(s.const(0), 0)
+    a, b, unused = s.input(0, FLOAT, 0), s.input(0, FLOAT, 1), s.input(0, FLOAT, 2)
+    d1, d2, r = s.temps(3)
+    s.op("sin", unused, d1)
+    s.op("mul", d1, a, d2)              # dead: nothing reads d2
+    s.op("add", a, b, r)
+    s.output_data(FLOAT, 0, [(r, s.output(0, FLOAT, 0))])
+    built = s.build()
+    code = [decode(i) for i in be().inspect_code(built.blob)]
+    names = [opcodes.NAME[c["op"]] for c in code if 0 < c["op"] < 190]
+    assert names == ["add"]
+    assert code[0]["op"] == DOP_LOADN and code[0]["aux"] == 2          # two streams loaded, not three
+    info = be().inspect_blob(built.blob)
+    assert info.NumVirtualRegisters == 2 and info.InstancesPerLane == 4
+
+
 def test_half_and_noadvance_inputs():
     s = Script()
     s.acquireindex(s.const(0), 0)
