@@ -72,3 +72,25 @@ def test_half_inputs_and_constant_outputs_on_the_gpu():
     assert got[1] == ref[1] and 0 < got[1] < n
     assert_same(got, ref, 3)
     np.testing.assert_array_equal(got[0][3][:got[1]].view(np.uint16), ref[0][3][:ref[1]].view(np.uint16))
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_random_scripts_on_the_gpu(block):
+    """The generator of tests/test_optimizer_fuzz.py (register reuse, dead values, constants, compares, integer ops, a kill predicate):
+    the optimized blob on libvvm_hip.so against the same blob on the oracle, bit for bit, at a size with several tiles and a ragged end."""
+    from test_optimizer_fuzz import gen
+    for seed in range(1000 + block * 25, 1000 + block * 25 + 25):
+        o, nf, ni, fo, io = gen(seed)
+        n = 2048 * 3 + 77
+        rng = np.random.default_rng(seed)
+        ins = [rng.uniform(-3, 3, n).astype(f32) for _ in range(nf)] + [rng.integers(-20, 20, n).astype(np.int32) for _ in range(ni)]
+        consts = ALL_ONES + np.array([0.5, -1.25, 2.0, 0.0], f32).tobytes() + np.array([3], np.int32).tobytes()
+        dts = [f32] * fo + [np.int32] * io
+        blob = Blob(optimize(o))
+        ref = run_oracle(blob, [consts], ins, dts, n)
+        got = run_hip(blob, [consts], ins, dts, n)
+        assert got[1] == ref[1], seed
+        for k in range(len(dts)):
+            x, y = got[0][k][:got[1]].view(np.uint32), ref[0][k][:ref[1]].view(np.uint32)
+            both_nan = np.isnan(x.view(f32)) & np.isnan(y.view(f32)) if k < fo else np.zeros(got[1], bool)
+            assert np.array_equal(x[~both_nan], y[~both_nan]), (seed, k)
