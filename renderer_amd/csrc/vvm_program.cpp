@@ -564,8 +564,13 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 		return out_cursor;
 	};
 	for (size_t at_ins = 0; at_ins < ins.size(); ++at_ins) {
-		if (!needed[at_ins]) continue;
 		const Decoded& d = ins[at_ins];
+		if (!needed[at_ins]) {
+			// a draw that is left out keeps its place in the numbering: the draws that stay must not change
+			if (d.op == VVM_OP_random || d.op == VVM_OP_randomi || d.op == VVM_OP_random_add) rand_ordinal += 1;
+			else if (d.op == VVM_OP_random_2x) rand_ordinal += 2;
+			continue;
+		}
 		VvmIns k{0, 0, 0, 0};
 		switch (d.kind) {
 		case K_ORD: case K_DST_ONLY: {

@@ -2,6 +2,7 @@
 built-ins, batched Execs with distinct bytecode, asynchronous Execs, and full-size (64 Mi) properties.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -467,3 +468,27 @@ def test_internal_fields_follow_the_reference_chunking():
                 be.lib.vvm_device_free(p)
         finally:
             be.set_page_size_kb(64)
+
+
+@pytest.mark.parametrize("block", range(3))
+def test_random_scripts_in_the_optimized_format(block):
+    """Scripts from the generator of tools/gpu_fuzz_linker.py (merged opcodes, two-output ops, transcendentals, random draws, half and
+    no-advance inputs, up to 24 outputs of three kinds, dead values, up to 48 live streams: every kernel shape): GPU against oracle."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import gpu_fuzz_linker as fz
+    for seed in range(5000 + 40 * block, 5000 + 40 * block + 40):
+        built, nf, ni, nh, dts = fz.gen(seed)
+        n = 2048 + 1 + (seed * 37) % 3000
+        rng = np.random.default_rng(seed)
+        ins = [rng.uniform(-3, 3, n).astype(f32) for _ in range(nf)] + [rng.integers(-20, 20, n).astype(np.int32) for _ in range(ni)] + \
+              [rng.uniform(-2, 2, n).astype(np.float16) for _ in range(nh)]
+        consts = bytes([255] * 4) + np.array([0.5, -1.25, 2.0, 0.0], f32).tobytes() + np.array([3], np.int32).tobytes()
+        ref = run_oracle(built, [consts], ins, dts, n, seed=seed)
+        got = run_hip(built, [consts], ins, dts, n, seed=seed, flags=abi.VVM_EXEC_FORCE_EIGHT_WIDE if seed % 2 else 0)
+        assert got[1] == ref[1], seed
+        for k, dt in enumerate(dts):
+            a, b = got[0][k][:got[1]], ref[0][k][:ref[1]]
+            view = np.uint16 if dt == np.float16 else np.uint32
+            nan = (np.isnan(a) & np.isnan(b)) if dt != np.int32 else np.zeros(len(a), bool)
+            assert np.array_equal(a.view(view)[~nan], b.view(view)[~nan]), (seed, k)

@@ -292,6 +292,19 @@ def test_instructions_nothing_reads_are_left_out():
     assert info.NumVirtualRegisters == 2 and info.InstancesPerLane == 4
 
 
+def test_a_random_draw_keeps_its_number_when_earlier_draws_are_left_out():
+    s = Script()
+    s.acquireindex(s.const(0), 0)
+    x = s.input(0, FLOAT, 0)
+    dead, kept = s.temps(2)
+    s.op("random", x, dead)             # nothing reads it
+    s.op("random", x, kept)
+    s.output_data(FLOAT, 0, [(kept, s.output(0, FLOAT, 0))])
+    code = [decode(i) for i in be().inspect_code(s.build().blob)]
+    draws = [c for c in code if c["op"] == opcodes.CODE["random"]]
+    assert len(draws) == 1 and draws[0]["aux2"] == 1
+
+
 def test_half_and_noadvance_inputs():
     s = Script()
     s.acquireindex(s.const(0), 0)

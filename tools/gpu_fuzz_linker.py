@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""usage: gpu_fuzz_linker.py <first seed> <last seed>   (on a GPU box)  random scripts written straight in the optimized format
+(renderer_amd.assembler), wider than the optimizer fuzz: up to 60 instructions over float / int32 / half / no-advance inputs, merged
+opcodes, two-output ops, the bit-exact transcendentals, exec_index, random, up to 24 outputs of three kinds (several staging groups),
+many values alive at once (the 32-register kernels, LDS register slots, the one-instance-per-lane kernel).  Each script runs on
+libvvm_hip.so and on the CPU oracle; results must agree bit for bit (NaN payloads aside)."""
+import os
+import random
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np                                                      # noqa: E402
+from renderer_amd import abi                                            # noqa: E402
+from renderer_amd.assembler import FLOAT, HALF, INT32, Script          # noqa: E402
+from renderer_amd.opcodes import OPS                                    # noqa: E402
+from vm_harness import run_hip, run_oracle                              # noqa: E402
+
+f32 = np.float32
+FLOAT_OPS = ("add sub mul div mad lerp min max neg abs floor ceil frac trunc round sign step clamp sqrt rsq sin cos exp log pow atan2 "
+             "asin acos fmod mad_add mad_sub0 mad_sub1 mad_mul mad_sqrt mad_mad0 mad_mad1 mul_mad0 mul_mad1 mul_add mul_sub0 mul_sub1 "
+             "mul_mul mul_max add_mad1 add_add sub_neg sub_mul div_mad0 div_mul fmod_add").split()
+MASK_FIRST = "select select_mul select_add".split()                     # (mask, float...) -> float
+CMP = "cmplt cmple cmpgt cmpge cmpeq cmpneq sub_cmplt1 neg_cmplt".split()            # floats -> mask
+CMP_SELECT = "cmplt_select cmple_select cmpeq_select".split()           # (a, b, x, y) -> float
+CMP_LOGIC = ["cmp%s_logic_%s" % (c, l) for c in "lt le gt ge eq ne".split() for l in ("and", "or")]      # (a, b, mask) -> mask
+INT_OPS = "addi subi muli divi mini maxi bit_and bit_or bit_xor negi absi muli_addi addi_muli bit_or_muli".split()
+CMPI = "cmplti cmplei cmpgti cmpgei cmpeqi cmpneqi".split()
+
+
+def gen(seed):
+    r = random.Random(seed)
+    s = Script()
+    nf, ni, nh, nna = r.randint(1, 10), r.randint(0, 3), r.randint(0, 2), r.randint(0, 1)
+    if seed % 5 == 0:
+        nf = r.randint(17, 48)                  # every stream is in a register from the top of the tile: the big-register kernels
+    fvals = [s.input(0, FLOAT, i) for i in range(nf)]
+    ivals = [s.input(0, INT32, i) for i in range(ni)]
+    if nna:
+        fvals.append(s.input(0, FLOAT, nf, noadvance=True))
+    for i in range(nh):
+        t = s.temp()
+        s.op("half_to_float", s.input(0, HALF, i), t)
+        fvals.append(t)
+    masks = []
+    pred_at = r.randint(0, 8)
+    acquired = False
+    keep_alive = r.random() < 0.4               # retire few values: many registers
+    def fsrc():
+        return s.const(r.randint(1, 4)) if r.random() < 0.2 else r.choice(fvals)
+    n_ops = r.randint(3, 60)
+    for k in range(n_ops):
+        if k == pred_at:
+            s.acquireindex(r.choice(masks) if masks and r.random() < 0.7 else s.const(0), 0)
+            acquired = True
+        kind = r.random()
+        if kind < 0.55:
+            name = r.choice(FLOAT_OPS)
+            _, a, b = OPS[name]
+            t = s.temp()
+            s.op(name, *[fsrc() for _ in range(a)], t)
+            fvals.append(t)
+        elif kind < 0.62 and masks:
+            name = r.choice(MASK_FIRST)
+            _, a, b = OPS[name]
+            t = s.temp()
+            s.op(name, r.choice(masks), *[fsrc() for _ in range(a - 1)], t)
+            fvals.append(t)
+        elif kind < 0.72:
+            name = r.choice(CMP)
+            _, a, b = OPS[name]
+            t = s.temp()
+            s.op(name, *[fsrc() for _ in range(a)], t)
+            masks.append(t)
+        elif kind < 0.76:
+            t = s.temp()
+            s.op(r.choice(CMP_SELECT), fsrc(), fsrc(), fsrc(), fsrc(), t)
+            fvals.append(t)
+        elif kind < 0.80 and masks:
+            t = s.temp()
+            s.op(r.choice(CMP_LOGIC), fsrc(), fsrc(), r.choice(masks), t)
+            masks.append(t)
+        elif kind < 0.84:
+            a_, b_ = s.temp(), s.temp()
+            if r.random() < 0.5:
+                s.op("sin_cos", fsrc(), a_, b_)
+            else:
+                s.op("mul_2x", fsrc(), fsrc(), a_, b_)
+            fvals += [a_, b_]
+        elif kind < 0.87:
+            t = s.temp()
+            if r.random() < 0.5:
+                s.op("exec_indexf", t); fvals.append(t)
+            else:
+                s.op("exec_index", t); ivals.append(t)
+        elif kind < 0.90:
+            t = s.temp()
+            s.op("random", fsrc(), t)
+            fvals.append(t)
+        elif kind < 0.93:
+            t = s.temp()
+            if ivals and r.random() < 0.5:
+                s.op("i2f", r.choice(ivals), t); fvals.append(t)
+            else:
+                s.op("f2i", r.choice(fvals), t); ivals.append(t)
+        elif ivals:
+            if r.random() < 0.25:
+                t = s.temp()
+                s.op(r.choice(CMPI), r.choice(ivals), r.choice(ivals), t)
+                masks.append(t)
+            else:
+                name = r.choice(INT_OPS)
+                _, a, b = OPS[name]
+                t = s.temp()
+                s.op(name, *[r.choice(ivals) if r.random() < 0.8 else s.const(5) for _ in range(a)], t)
+                ivals.append(t)
+        if not keep_alive and len(fvals) > nf + 3 and r.random() < 0.5:
+            fvals.pop(r.randrange(nf, len(fvals)))
+    if seed % 5 == 0:
+        acc = fvals[0]                              # a sum over every stream at the very end keeps all of them alive
+        for i in range(1, nf):
+            t = s.temp()
+            s.op("add", acc, s.input(0, FLOAT, i), t)
+            acc = t
+        fvals = [acc] + fvals[-6:]
+    if not acquired:
+        s.acquireindex(r.choice(masks) if masks and r.random() < 0.7 else s.const(0), 0)
+    n_out = r.randint(1, 24) if keep_alive else r.randint(1, 9)
+    dts, fo, io, ho = [], 0, 0, 0
+    outs = []
+    for _ in range(n_out):
+        c = r.random()
+        if c < 0.2 and ivals:
+            outs.append((INT32, r.choice(ivals)))
+        elif c < 0.35:
+            outs.append((HALF, r.choice(fvals)))
+        else:
+            outs.append((FLOAT, r.choice(fvals) if r.random() < 0.95 else s.const(2)))
+    # streams are ordered float, int32, half
+    for typ in (FLOAT, INT32, HALF):
+        idx = 0
+        group = []
+        for t_, v in outs:
+            if t_ != typ:
+                continue
+            group.append((v, s.output(0, typ, idx)))
+            idx += 1
+            dts.append({FLOAT: f32, INT32: np.int32, HALF: np.float16}[typ])
+        for i in range(0, len(group), 5):
+            s.output_data(typ, 0, group[i:i + 5])
+    return s.build(alias_outputs=r.random() < 0.5), nf + nna, ni, nh, dts
+
+
+def main():
+    bad = skipped = 0
+    shapes = {}
+    for seed in range(int(sys.argv[1]), int(sys.argv[2])):
+        try:
+            built, nf, ni, nh, dts = gen(seed)
+        except AssertionError:
+            skipped += 1
+            continue
+        n = 2048 + 1 + (seed * 37) % 3000
+        rng = np.random.default_rng(seed)
+        ins = [rng.uniform(-3, 3, n).astype(f32) for _ in range(nf)] + [rng.integers(-20, 20, n).astype(np.int32) for _ in range(ni)] + \
+              [rng.uniform(-2, 2, n).astype(np.float16) for _ in range(nh)]
+        consts = bytes([255] * 4) + np.array([0.5, -1.25, 2.0, 0.0], f32).tobytes() + np.array([3], np.int32).tobytes()
+        try:
+            ref = run_oracle(built, [consts], ins, dts, n, seed=seed)
+            got = run_hip(built, [consts], ins, dts, n, seed=seed, flags=abi.VVM_EXEC_FORCE_EIGHT_WIDE if seed % 2 else 0)
+        except abi.VVMError as e:
+            if e.code == abi.VVM_E_TOO_LARGE:
+                skipped += 1
+                continue
+            raise
+        info = got[2]
+        key = (info.InstancesPerLane, info.NumVirtualRegisters > 16, info.LdsSpillRegisters > 0)
+        shapes[key] = shapes.get(key, 0) + 1
+        ok = got[1] == ref[1]
+        for k in range(len(dts)):
+            if not ok:
+                break
+            if dts[k] == np.float16:
+                x, y = got[0][k][:got[1]].view(np.uint16), ref[0][k][:ref[1]].view(np.uint16)
+                nan = np.isnan(got[0][k][:got[1]]) & np.isnan(ref[0][k][:ref[1]])
+            else:
+                x, y = got[0][k][:got[1]].view(np.uint32), ref[0][k][:ref[1]].view(np.uint32)
+                nan = np.isnan(x.view(f32)) & np.isnan(y.view(f32)) if dts[k] == f32 else np.zeros(got[1], bool)
+            if not np.array_equal(x[~nan], y[~nan]):
+                ok = False
+                bad_k = k
+        if not ok:
+            bad += 1
+            print("seed", seed, "MISMATCH (survivors %d / %d)" % (got[1], ref[1]), "vregs", info.NumVirtualRegisters, "width", info.InstancesPerLane, flush=True)
+        if seed % 100 == 0:
+            print("seed", seed, "failures so far", bad, "skipped", skipped, "kernel shapes", shapes, flush=True)
+    print("done: failures", bad, "skipped", skipped, "kernel shapes (instances per lane, more than 16 registers, LDS registers):", shapes)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
