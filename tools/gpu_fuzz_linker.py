@@ -162,14 +162,15 @@ def main():
         except AssertionError:
             skipped += 1
             continue
-        n = 2048 + 1 + (seed * 37) % 3000
+        n = (seed // 7) % 10 if seed % 7 == 0 else 2048 + 1 + (seed * 37) % 3000          # (some tiny Execs, empty ones included)
+        offset = 1 + seed % 9 if seed % 3 == 0 else 0                                        # InstanceOffset
         rng = np.random.default_rng(seed)
-        ins = [rng.uniform(-3, 3, n).astype(f32) for _ in range(nf)] + [rng.integers(-20, 20, n).astype(np.int32) for _ in range(ni)] + \
-              [rng.uniform(-2, 2, n).astype(np.float16) for _ in range(nh)]
+        ins = [rng.uniform(-3, 3, max(n, 1)).astype(f32) for _ in range(nf)] + [rng.integers(-20, 20, max(n, 1)).astype(np.int32) for _ in range(ni)] + \
+              [rng.uniform(-2, 2, max(n, 1)).astype(np.float16) for _ in range(nh)]
         consts = bytes([255] * 4) + np.array([0.5, -1.25, 2.0, 0.0], f32).tobytes() + np.array([3], np.int32).tobytes()
         try:
-            ref = run_oracle(built, [consts], ins, dts, n, seed=seed)
-            got = run_hip(built, [consts], ins, dts, n, seed=seed, flags=abi.VVM_EXEC_FORCE_EIGHT_WIDE if seed % 2 else 0)
+            ref = run_oracle(built, [consts], ins, dts, n, seed=seed, instance_offset=offset)
+            got = run_hip(built, [consts], ins, dts, n, seed=seed, instance_offset=offset, flags=abi.VVM_EXEC_FORCE_EIGHT_WIDE if seed % 2 else 0)
         except abi.VVMError as e:
             if e.code == abi.VVM_E_TOO_LARGE:
                 skipped += 1
@@ -183,10 +184,10 @@ def main():
             if not ok:
                 break
             if dts[k] == np.float16:
-                x, y = got[0][k][:got[1]].view(np.uint16), ref[0][k][:ref[1]].view(np.uint16)
-                nan = np.isnan(got[0][k][:got[1]]) & np.isnan(ref[0][k][:ref[1]])
+                x, y = got[0][k][offset:offset + got[1]].view(np.uint16), ref[0][k][offset:offset + ref[1]].view(np.uint16)
+                nan = np.isnan(got[0][k][offset:offset + got[1]]) & np.isnan(ref[0][k][offset:offset + ref[1]])
             else:
-                x, y = got[0][k][:got[1]].view(np.uint32), ref[0][k][:ref[1]].view(np.uint32)
+                x, y = got[0][k][offset:offset + got[1]].view(np.uint32), ref[0][k][offset:offset + ref[1]].view(np.uint32)
                 nan = np.isnan(x.view(f32)) & np.isnan(y.view(f32)) if dts[k] == f32 else np.zeros(got[1], bool)
             if not np.array_equal(x[~nan], y[~nan]):
                 ok = False
