@@ -492,3 +492,60 @@ def test_random_scripts_in_the_optimized_format(block):
             view = np.uint16 if dt == np.float16 else np.uint32
             nan = (np.isnan(a) & np.isnan(b)) if dt != np.int32 else np.zeros(len(a), bool)
             assert np.array_equal(a.view(view)[~nan], b.view(view)[~nan]), (seed, k)
+
+
+def test_random_scripts_in_one_batch():
+    """Thirty scripts of the random generator, every kernel shape among them, in ONE vvm_exec_batch call: each emitter's result equals
+    its own Exec on the oracle."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import gpu_fuzz_linker as fz
+    from vm_harness import _type_offsets
+    be = abi.load_hip_backend()
+    L = be.lib
+    frames, opts, states, allocs, expect = [], [], [], [], []
+    try:
+        for seed in range(8000, 8030):
+            built, nf, ni, nh, dts = fz.gen(seed)
+            n = 1500 + (seed * 131) % 4000
+            rng = np.random.default_rng(seed)
+            ins = [rng.uniform(-3, 3, n).astype(f32) for _ in range(nf)] + [rng.integers(-20, 20, n).astype(np.int32) for _ in range(ni)] + \
+                  [rng.uniform(-2, 2, n).astype(np.float16) for _ in range(nh)]
+            consts = bytes([255] * 4) + np.array([0.5, -1.25, 2.0, 0.0], f32).tobytes() + np.array([3], np.int32).tobytes()
+            expect.append(run_oracle(built, [consts], ins, dts, n, seed=seed) + (dts, n))
+            d_in, d_out = [], []
+            for a in ins:
+                buf = np.zeros(n + PAD, a.dtype); buf[:n] = a
+                p = L.vvm_device_alloc(buf.nbytes); assert p
+                be._check(L.vvm_device_upload(p, buf.ctypes.data, buf.nbytes), "upload")
+                d_in.append(p)
+            for dt in dts:
+                p = L.vvm_device_alloc((n + PAD) * np.dtype(dt).itemsize); assert p
+                be._check(L.vvm_device_memset(p, 0xCD, (n + PAD) * np.dtype(dt).itemsize), "memset")
+                d_out.append(p)
+            allocs.append((d_in, d_out))
+            st = VectorVMState(built.blob, be)
+            states.append(st)
+            ds = abi.DataSet(d_in, d_out, 0, _type_offsets(ins), _type_offsets([np.empty(0, dt) for dt in dts]))
+            frames.append(st.frame([ds], n, [consts]))
+            opts.append(abi.ExecOptions(seed, 0, 0, None, 0))
+        be.exec_batch(frames, opts)
+        shapes = set()
+        for e, (ref, ref_n, _, dts, n) in enumerate(expect):
+            assert frames[e].survivors(0) == ref_n, "emitter %d" % e
+            info = states[e].info()
+            shapes.add((info.InstancesPerLane, info.NumVirtualRegisters > 16, info.LdsSpillRegisters > 0))
+            for k, dt in enumerate(dts):
+                h = np.empty(n + PAD, dtype=dt)
+                be._check(L.vvm_device_download(h.ctypes.data, allocs[e][1][k], h.nbytes), "download")
+                a, b = h[:ref_n], ref[k][:ref_n]
+                view = np.uint16 if dt == np.float16 else np.uint32
+                nan = (np.isnan(a) & np.isnan(b)) if dt != np.int32 else np.zeros(len(a), bool)
+                assert np.array_equal(a.view(view)[~nan], b.view(view)[~nan]), (e, k)
+        assert len(shapes) >= 3, shapes
+    finally:
+        for st in states:
+            st.close()
+        for d_in, d_out in allocs:
+            for p in d_in + d_out:
+                L.vvm_device_free(p)
