@@ -150,6 +150,16 @@ def gen(seed):
             dts.append({FLOAT: f32, INT32: np.int32, HALF: np.float16}[typ])
         for i in range(0, len(group), 5):
             s.output_data(typ, 0, group[i:i + 5])
+    dts1 = []
+    if seed % 4 == 1:                               # a second acquired dataset with outputs of its own
+        s.acquireindex(r.choice(masks) if masks and r.random() < 0.8 else s.const(0), 1)
+        pairs_f = [(r.choice(fvals), s.output(1, FLOAT, i)) for i in range(r.randint(1, 3))]
+        s.output_data(FLOAT, 1, pairs_f)
+        dts1 += [f32] * len(pairs_f)
+        if ivals:
+            s.output_data(INT32, 1, [(r.choice(ivals), s.output(1, INT32, 0))])
+            dts1.append(np.int32)
+    gen.second_dataset = dts1
     return s.build(alias_outputs=r.random() < 0.5), nf + nna, ni, nh, dts
 
 
@@ -169,8 +179,12 @@ def main():
               [rng.uniform(-2, 2, max(n, 1)).astype(np.float16) for _ in range(nh)]
         consts = bytes([255] * 4) + np.array([0.5, -1.25, 2.0, 0.0], f32).tobytes() + np.array([3], np.int32).tobytes()
         try:
-            ref = run_oracle(built, [consts], ins, dts, n, seed=seed, instance_offset=offset)
-            got = run_hip(built, [consts], ins, dts, n, seed=seed, instance_offset=offset, flags=abi.VVM_EXEC_FORCE_EIGHT_WIDE if seed % 2 else 0)
+            dts1 = gen.second_dataset
+            more = [dts1] if dts1 else []
+            ref_more, got_more = [], []
+            ref = run_oracle(built, [consts], ins, dts, n, seed=seed, instance_offset=offset, more_datasets=more, more_results=ref_more)
+            got = run_hip(built, [consts], ins, dts, n, seed=seed, instance_offset=offset, flags=abi.VVM_EXEC_FORCE_EIGHT_WIDE if seed % 2 else 0,
+                          more_datasets=more, more_results=got_more)
         except abi.VVMError as e:
             if e.code == abi.VVM_E_TOO_LARGE:
                 skipped += 1
@@ -192,6 +206,15 @@ def main():
             if not np.array_equal(x[~nan], y[~nan]):
                 ok = False
                 bad_k = k
+        if ok and dts1:
+            ok = got_more[0][1] == ref_more[0][1]
+            for k, dt in enumerate(dts1):
+                if not ok:
+                    break
+                m = got_more[0][1]
+                x, y = got_more[0][0][k][offset:offset + m].view(np.uint32), ref_more[0][0][k][offset:offset + m].view(np.uint32)
+                nan = np.isnan(x.view(f32)) & np.isnan(y.view(f32)) if dt == f32 else np.zeros(m, bool)
+                ok = np.array_equal(x[~nan], y[~nan])
         if not ok:
             bad += 1
             print("seed", seed, "MISMATCH (survivors %d / %d)" % (got[1], ref[1]), "vregs", info.NumVirtualRegisters, "width", info.InstancesPerLane, flush=True)
