@@ -348,6 +348,7 @@ int fill_params(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* op
 	d->out_list = (const uint64_t*)(dev + pe.off_out);
 	d->status = d_status;
 	d->counts = d_counts ? d_counts : st->d_counts;
+	if (lp.uses_perlin && !st->d_perlin) return fail(VVM_E_INVALID_ARG, "internal: the noise table of this state was not uploaded");
 	d->perlin = st->d_perlin;
 	d->num_instances = (uint32_t)ctx->NumInstances;
 	d->num_tiles = pe.tiles;
@@ -478,7 +479,9 @@ VVM_API vvm_state* vvm_alloc_state(const uint8_t* blob, size_t num_bytes)
 	if (upload_code(st->wide, &st->d_code_wide) != VVM_OK) { vvm_free_state(st); return nullptr; }
 	if (link_more_passes(st->script, false, st->wide, st->wide_more, st->d_code_wide_more) != VVM_OK) { vvm_free_state(st); return nullptr; }
 	hipError_t e;
-	if (st->wide.uses_perlin) {
+	bool any_perlin = st->wide.uses_perlin;      // (a pass links only what its dataset needs: any of them may be the one with the noise call)
+	for (const vvm::LinkedProgram& more : st->wide_more) any_perlin = any_perlin || more.uses_perlin;
+	if (any_perlin) {
 		if ((e = hipMalloc((void**)&st->d_perlin, 512)) != hipSuccess) return bail(e, "hipMalloc(perlin)");
 		if ((e = hipMemcpy(st->d_perlin, k_perlin_perm_host, 512, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(perlin)");
 	}

@@ -558,3 +558,28 @@ def test_random_scripts_in_one_batch():
         for d_in, d_out in allocs:
             for p in d_in + d_out:
                 L.vvm_device_free(p)
+
+
+def test_noise_call_that_only_a_second_dataset_needs():
+    """The first pass has no use for the noise call (it is not linked there); the second dataset's pass needs the noise table."""
+    from renderer_amd.assembler import FLOAT, Script
+    s = Script()
+    x, y, z = [s.input(0, FLOAT, i) for i in range(3)]
+    fn = s.ext_fn(3, 1)
+    keep = s.temp(); s.op("cmplt", x, s.const(1), keep)
+    s.acquireindex(s.const(0), 0)
+    s.acquireindex(keep, 1)
+    nz = s.temp(); s.call(fn, [x, y, z], [nz])
+    s.output_data(FLOAT, 0, [(y, s.output(0, FLOAT, 0))])
+    s.output_data(FLOAT, 1, [(nz, s.output(1, FLOAT, 0))])
+    built = s.build()
+    n = 5000
+    rng = np.random.default_rng(2)
+    ins = [rng.uniform(-3, 3, n).astype(f32) for _ in range(3)]
+    consts = [bytes([255] * 4) + np.array([0.5], f32).tobytes()]
+    ref_more, got_more = [], []
+    ref = run_oracle(built, consts, ins, [f32], n, ext_fns=[abi.VVM_EXTFN_PERLIN3], more_datasets=[[f32]], more_results=ref_more)
+    got = run_hip(built, consts, ins, [f32], n, ext_fns=[abi.VVM_EXTFN_PERLIN3], more_datasets=[[f32]], more_results=got_more)
+    assert got[1] == ref[1] == n and got_more[0][1] == ref_more[0][1] and 0 < got_more[0][1] < n
+    m = got_more[0][1]
+    assert np.array_equal(_bits(got_more[0][0][0][:m]), _bits(ref_more[0][0][0][:m]))

@@ -45,6 +45,12 @@ def gen(seed):
         s.op("half_to_float", s.input(0, HALF, i), t)
         fvals.append(t)
     masks = []
+    ext = []                                        # built-in ids in table order
+    if seed % 3 == 0:
+        perlin = s.ext_fn(3, 1); ext.append(abi.VVM_EXTFN_PERLIN3)
+        if seed % 6 == 0:
+            curl = s.ext_fn(3, 3); ext.append(abi.VVM_EXTFN_CURL_NOISE3)
+    gen.ext = ext
     pred_at = r.randint(0, 8)
     acquired = False
     keep_alive = r.random() < 0.4               # retire few values: many registers
@@ -89,6 +95,18 @@ def gen(seed):
             else:
                 s.op("mul_2x", fsrc(), fsrc(), a_, b_)
             fvals += [a_, b_]
+        elif kind < 0.855 and ext:
+            from renderer_amd.assembler import INVALID
+            if len(ext) == 2 and r.random() < 0.5:
+                outs3 = [s.temp() if r.random() < 0.7 else INVALID for _ in range(3)]
+                if all(o is INVALID for o in outs3):
+                    outs3[1] = s.temp()
+                s.call(curl, [r.choice(fvals) for _ in range(3)], outs3)
+                fvals += [o for o in outs3 if o is not INVALID]
+            else:
+                t = s.temp()
+                s.call(perlin, [r.choice(fvals) for _ in range(3)], [t])
+                fvals.append(t)
         elif kind < 0.87:
             t = s.temp()
             if r.random() < 0.5:
@@ -182,9 +200,9 @@ def main():
             dts1 = gen.second_dataset
             more = [dts1] if dts1 else []
             ref_more, got_more = [], []
-            ref = run_oracle(built, [consts], ins, dts, n, seed=seed, instance_offset=offset, more_datasets=more, more_results=ref_more)
+            ref = run_oracle(built, [consts], ins, dts, n, seed=seed, instance_offset=offset, more_datasets=more, more_results=ref_more, ext_fns=list(gen.ext))
             got = run_hip(built, [consts], ins, dts, n, seed=seed, instance_offset=offset, flags=abi.VVM_EXEC_FORCE_EIGHT_WIDE if seed % 2 else 0,
-                          more_datasets=more, more_results=got_more)
+                          more_datasets=more, more_results=got_more, ext_fns=list(gen.ext))
         except abi.VVMError as e:
             if e.code == abi.VVM_E_TOO_LARGE:
                 skipped += 1
