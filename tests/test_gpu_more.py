@@ -479,6 +479,8 @@ def test_random_scripts_in_the_optimized_format(block):
     import gpu_fuzz_linker as fz
     for seed in range(5000 + 40 * block, 5000 + 40 * block + 40):
         built, nf, ni, nh, dts = fz.gen(seed)
+        if fz.gen.with_ids:                 # (scripts with update_id need ID tables: tools/gpu_fuzz_linker.py runs those)
+            continue
         n = 2048 + 1 + (seed * 37) % 3000
         rng = np.random.default_rng(seed)
         ins = [rng.uniform(-3, 3, n).astype(f32) for _ in range(nf)] + [rng.integers(-20, 20, n).astype(np.int32) for _ in range(ni)] + \
@@ -486,9 +488,9 @@ def test_random_scripts_in_the_optimized_format(block):
         consts = bytes([255] * 4) + np.array([0.5, -1.25, 2.0, 0.0], f32).tobytes() + np.array([3], np.int32).tobytes()
         more = [fz.gen.second_dataset] if fz.gen.second_dataset else []          # (every fourth script acquires a second dataset)
         ref_more, got_more = [], []
-        ref = run_oracle(built, [consts], ins, dts, n, seed=seed, more_datasets=more, more_results=ref_more)
+        ref = run_oracle(built, [consts], ins, dts, n, seed=seed, more_datasets=more, more_results=ref_more, ext_fns=list(fz.gen.ext))
         got = run_hip(built, [consts], ins, dts, n, seed=seed, flags=abi.VVM_EXEC_FORCE_EIGHT_WIDE if seed % 2 else 0,
-                      more_datasets=more, more_results=got_more)
+                      more_datasets=more, more_results=got_more, ext_fns=list(fz.gen.ext))
         assert got[1] == ref[1], seed
         if more:
             assert got_more[0][1] == ref_more[0][1], seed
@@ -516,12 +518,14 @@ def test_random_scripts_in_one_batch():
     try:
         for seed in [v for v in range(8000, 8040) if v % 4 != 1]:          # (single-dataset scripts)
             built, nf, ni, nh, dts = fz.gen(seed)
+            if fz.gen.with_ids:
+                continue
             n = 1500 + (seed * 131) % 4000
             rng = np.random.default_rng(seed)
             ins = [rng.uniform(-3, 3, n).astype(f32) for _ in range(nf)] + [rng.integers(-20, 20, n).astype(np.int32) for _ in range(ni)] + \
                   [rng.uniform(-2, 2, n).astype(np.float16) for _ in range(nh)]
             consts = bytes([255] * 4) + np.array([0.5, -1.25, 2.0, 0.0], f32).tobytes() + np.array([3], np.int32).tobytes()
-            expect.append(run_oracle(built, [consts], ins, dts, n, seed=seed) + (dts, n))
+            expect.append(run_oracle(built, [consts], ins, dts, n, seed=seed, ext_fns=list(fz.gen.ext)) + (dts, n))
             d_in, d_out = [], []
             for a in ins:
                 buf = np.zeros(n + PAD, a.dtype); buf[:n] = a
@@ -536,7 +540,7 @@ def test_random_scripts_in_one_batch():
             st = VectorVMState(built.blob, be)
             states.append(st)
             ds = abi.DataSet(d_in, d_out, 0, _type_offsets(ins), _type_offsets([np.empty(0, dt) for dt in dts]))
-            frames.append(st.frame([ds], n, [consts]))
+            frames.append(st.frame([ds], n, [consts], list(fz.gen.ext)))
             opts.append(abi.ExecOptions(seed, 0, 0, None, 0))
         be.exec_batch(frames, opts)
         shapes = set()

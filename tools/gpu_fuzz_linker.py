@@ -16,7 +16,7 @@ import numpy as np                                                      # noqa: 
 from renderer_amd import abi                                            # noqa: E402
 from renderer_amd.assembler import FLOAT, HALF, INT32, Script          # noqa: E402
 from renderer_amd.opcodes import OPS                                    # noqa: E402
-from vm_harness import run_hip, run_oracle                              # noqa: E402
+from vm_harness import IdState, run_hip, run_oracle                     # noqa: E402
 
 f32 = np.float32
 FLOAT_OPS = ("add sub mul div mad lerp min max neg abs floor ceil frac trunc round sign step clamp sqrt rsq sin cos exp log pow atan2 "
@@ -145,6 +145,10 @@ def gen(seed):
         fvals = [acc] + fvals[-6:]
     if not acquired:
         s.acquireindex(r.choice(masks) if masks and r.random() < 0.7 else s.const(0), 0)
+    gen.with_ids = seed % 8 in (3, 5)
+    if gen.with_ids:                                # update_id over an ID stream of its own (the last int32 input)
+        s.update_id(s.input(0, INT32, ni), r.choice(ivals) if ivals else s.input(0, INT32, ni), 0)
+        ni += 1
     n_out = r.randint(1, 24) if keep_alive else r.randint(1, 9)
     dts, fo, io, ho = [], 0, 0, 0
     outs = []
@@ -198,11 +202,18 @@ def main():
         consts = bytes([255] * 4) + np.array([0.5, -1.25, 2.0, 0.0], f32).tobytes() + np.array([3], np.int32).tobytes()
         try:
             dts1 = gen.second_dataset
+            want_ids = got_ids = None
+            if gen.with_ids:
+                m = max(n, 1)
+                ins[nf + ni - 1] = rng.permutation(m + 7)[:m].astype(np.int32)          # distinct IDs
+                want_ids = IdState(np.full(m + 7, -1, np.int32), np.full(2 * m + 16, -7, np.int32), num_free=5, max_used=3)
+                want_ids.free_table[:5] = [100001, 100002, 100003, 100004, 100005]
+                got_ids = want_ids.copy()
             more = [dts1] if dts1 else []
             ref_more, got_more = [], []
-            ref = run_oracle(built, [consts], ins, dts, n, seed=seed, instance_offset=offset, more_datasets=more, more_results=ref_more, ext_fns=list(gen.ext))
+            ref = run_oracle(built, [consts], ins, dts, n, seed=seed, instance_offset=offset, more_datasets=more, more_results=ref_more, ext_fns=list(gen.ext), ids=want_ids)
             got = run_hip(built, [consts], ins, dts, n, seed=seed, instance_offset=offset, flags=abi.VVM_EXEC_FORCE_EIGHT_WIDE if seed % 2 else 0,
-                          more_datasets=more, more_results=got_more, ext_fns=list(gen.ext))
+                          more_datasets=more, more_results=got_more, ext_fns=list(gen.ext), ids=got_ids)
         except abi.VVMError as e:
             if e.code == abi.VVM_E_TOO_LARGE:
                 skipped += 1
@@ -224,6 +235,9 @@ def main():
             if not np.array_equal(x[~nan], y[~nan]):
                 ok = False
                 bad_k = k
+        if ok and want_ids is not None:
+            ok = np.array_equal(got_ids.id_table, want_ids.id_table) and np.array_equal(got_ids.free_table, want_ids.free_table) and \
+                (got_ids.num_free, got_ids.max_used) == (want_ids.num_free, want_ids.max_used)
         if ok and dts1:
             ok = got_more[0][1] == ref_more[0][1]
             for k, dt in enumerate(dts1):
