@@ -104,14 +104,14 @@ def recorded_traffic(workload, particles):
     """HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE).  Counters cannot be read from inside this process;
     tools/pmc_traffic.sh collects them with rocprofv3 in separate passes of this same command and profiles/ holds the result.
     Returned only when it was taken on this workload and size."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    try:
-        with open(path) as f:
-            t = json.load(f)
-    except (OSError, ValueError):
-        return None
-    if t.get("workload") == workload and t.get("particles_per_gpu") == particles:
-        return t.get("hbm_bytes_per_launch")
+    for name in ("r01_traffic.json", "r01_traffic_kill_half.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                t = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if t.get("workload") == workload and t.get("particles_per_gpu") == particles:
+            return t.get("hbm_bytes_per_launch")
     return None
 
 
