@@ -263,6 +263,7 @@ int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, P
 		return fail(VVM_E_EXTFN_MISMATCH, "ExtFunctionTable.num differs from the script's external function count");
 	if (s.bytecode.empty()) return fail(VVM_E_NO_BYTECODE, "state has no bytecode");                    // RT.cpp:2264-2267
 	if (ctx->NumInstances < 0) return fail(VVM_E_INVALID_ARG, "negative NumInstances");
+	if (ctx->DataSets.num < 0 || (ctx->DataSets.num > 0 && !ctx->DataSets.data)) return fail(VVM_E_INVALID_ARG, "DataSets view is null");
 	const bool narrow = opt && (opt->Flags & VVM_EXEC_NO_VGPR_WIDE);
 	if (narrow && st->wide.instances_per_lane != 1) {
 		if (!st->narrow_ready) {
@@ -363,6 +364,9 @@ int fill_params(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* op
 	uint32_t* consts = (uint32_t*)(host + pe.off_consts);                                               // RT.cpp:2204-2207
 	memset(consts, 0, pe.off_in - pe.off_consts);
 	for (uint32_t i = 0; i < s.num_consts; ++i) {
+		if ((int)st->const_table[i] >= ctx->ConstantTableCount || !ctx->ConstantTableData || !ctx->ConstantTableData[st->const_table[i]] ||
+		    4u * ((size_t)st->const_dword[i] + 1) > (size_t)ctx->ConstantTableNumBytes[st->const_table[i]])
+			return fail(VVM_E_INVALID_ARG, "a constant the script reads lies outside the constant tables of this call");
 		const uint8_t* table = ctx->ConstantTableData[st->const_table[i]];
 		memcpy(&consts[i], table + 4u * (size_t)st->const_dword[i], 4);
 	}
@@ -372,7 +376,9 @@ int fill_params(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* op
 		if ((int)in.dataset >= ctx->DataSets.num) return fail(VVM_E_INVALID_ARG, "script reads a dataset the context does not provide");
 		const vvm_dataset_meta& ds = ctx->DataSets.data[in.dataset];
 		const uint32_t idx = ds.InputRegisterTypeOffsets[in.type] + in.reg;
-		if ((int)idx >= ds.InputRegisters.num) return fail(VVM_E_INVALID_ARG, "input register index past InputRegisters.num");
+		if ((int)idx >= ds.InputRegisters.num || !ds.InputRegisters.data) return fail(VVM_E_INVALID_ARG, "input register index past InputRegisters.num");
+		if (i < lp.input_used.size() && lp.input_used[i] && !ds.InputRegisters.data[idx])
+			return fail(VVM_E_INVALID_ARG, "an input stream the script reads is a null pointer");
 		const uint64_t stride = (in.type == 2) ? 2 : 4;
 		in_ptrs[i] = (uint64_t)(uintptr_t)ds.InputRegisters.data[idx] + (uint64_t)(int64_t)ds.InstanceOffset * stride;
 	}
@@ -391,7 +397,7 @@ int fill_params(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* op
 		if ((int)dsi >= ctx->DataSets.num || ty > 2) return fail(VVM_E_INVALID_ARG, "script writes a dataset the context does not provide");
 		const vvm_dataset_meta& ds = ctx->DataSets.data[dsi];
 		const uint32_t idx = ds.OutputRegisterTypeOffsets[ty] + s.out_dst[i];
-		if ((int)idx >= ds.OutputRegisters.num) return fail(VVM_E_INVALID_ARG, "output register index past OutputRegisters.num");
+		if ((int)idx >= ds.OutputRegisters.num || !ds.OutputRegisters.data) return fail(VVM_E_INVALID_ARG, "output register index past OutputRegisters.num");
 		const uint64_t stride = (ty == 2) ? 2 : 4;
 		if (!ds.OutputRegisters.data[idx]) continue;
 		const uint64_t addr = (uint64_t)(uintptr_t)ds.OutputRegisters.data[idx] + (uint64_t)(int64_t)ds.InstanceOffset * stride;

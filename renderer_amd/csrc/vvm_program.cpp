@@ -482,12 +482,14 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 	lp.full_kernel = heavy || lp.uses_ids;      // (the ID instructions are compiled into the full kernels only)
 	lp.uses_perlin = uses_perlin;
 
+	lp.input_used.assign(I, 0);
 	auto operand = [&](uint16_t r) -> uint32_t {
 		if (r == VVM_INVALID_REG) return VVM_OPND(VVM_OPC_NONE, 0);
 		if (r < T) return VVM_OPND(VVM_OPC_VREG, place[r]);
 		if (r < T + C) return (r - T < VVM_MAX_UNIFORMS) ? VVM_OPND(VVM_OPC_UNIF, r - T) : VVM_OPND(VVM_OPC_CONST, r - T);
 		if (r < T + C + I) {
 			const uint32_t i = r - (T + C);
+			lp.input_used[i] = 1;
 			if (input_vreg[i] >= 0) return VVM_OPND(VVM_OPC_VREG, (uint32_t)input_vreg[i]);
 			return VVM_OPND(lp.inputs[i].type == 2 ? VVM_OPC_NOADV_HALF : VVM_OPC_NOADV, i);
 		}

@@ -52,6 +52,7 @@ struct LinkedProgram {
 	uint32_t pass_dataset = 0;               // the dataset this program compacts and writes
 	uint32_t bytes_in_per_instance = 0, bytes_out_per_instance = 0;
 	uint32_t num_prefetched_inputs = 0;
+	std::vector<uint8_t> input_used;   // per remapped input: some instruction of this program reads it
 	std::vector<int32_t> load_list;    // remapped input index per load slot (8 per load instruction), -1 = unused slot
 	std::vector<int32_t> out_list;     // output serial index per output-list entry (staging order), -1 = nothing is written,
 	                                   // -2 = the ID register of update_id

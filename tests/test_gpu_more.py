@@ -587,3 +587,26 @@ def test_noise_call_that_only_a_second_dataset_needs():
     assert got[1] == ref[1] == n and got_more[0][1] == ref_more[0][1] and 0 < got_more[0][1] < n
     m = got_more[0][1]
     assert np.array_equal(_bits(got_more[0][0][0][:m]), _bits(ref_more[0][0][0][:m]))
+
+
+def test_null_streams_and_short_constant_tables_are_refused_before_any_launch():
+    be = abi.load_hip_backend()
+    w = scripts.fountain()
+    n = 1000
+    ins = scripts.fountain_streams_np(0, n)
+    ds = _DeviceStreams(be, ins, 8, n)
+    st = VectorVMState(w.script.blob, be)
+    try:
+        ok = st.frame([abi.DataSet(ds.ins, ds.outs, 0)], n, [w.constants])
+        assert st.exec(ok) == n
+        broken = list(ds.ins); broken[3] = 0
+        with pytest.raises(abi.VVMError) as e:
+            st.exec(st.frame([abi.DataSet(broken, ds.outs, 0)], n, [w.constants]))
+        assert e.value.code == abi.VVM_E_INVALID_ARG and "null" in str(e.value)
+        with pytest.raises(abi.VVMError) as e:
+            st.exec(st.frame([abi.DataSet(ds.ins, ds.outs, 0)], n, [w.constants[:8]]))
+        assert e.value.code == abi.VVM_E_INVALID_ARG and "constant" in str(e.value)
+        assert st.exec(ok) == n                              # the state is still usable
+    finally:
+        st.close()
+        ds.free()
