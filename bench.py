@@ -7,7 +7,9 @@ A step is one Exec of the fountain update script (8 float32 streams in, 8 out, k
 batch of synthetic particles that is already resident in HBM.  At N = 1 the batch is 64 Mi particles
 (BASELINE.json configs[1]); at N > 1 every rank runs the same-sized shard of a larger emitter (weak scaling), with
 exec_index / random streams based at the shard's first global instance, and every step ends with the all-gather
-of the per-rank survivor counts (RCCL) from which each rank's global acquireindex offset follows.
+of the per-rank survivor counts (RCCL) from which each rank's global acquireindex offset follows.  The all-gather
+runs on a stream of its own behind the copy of the count, so the next step's Exec (which needs only the local
+count) does not wait for the other ranks.
 
 Rank 0 prints ONE JSON line.  `roofline` prices the interpreter kernel against HBM: algorithmic bytes per launch
 (4 bytes x (input streams x instances + output streams x survivors)) over the kernel's mean duration, which is
@@ -125,6 +127,8 @@ def main():
     ap.add_argument("--width", default="auto", choices=["auto", "4", "8"], help="instances per lane of the kernel (auto: the library's choice)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse the multi-rank path on one GPU: all ranks then share device 0)")
+    ap.add_argument("--collective-at-one", action="store_true",
+                    help="rehearsal on a one-GPU box: run the multi-rank step (count copy, all-gather on its own stream) with a single rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -136,10 +140,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    distributed = world > 1 or args.collective_at_one
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -171,22 +179,37 @@ def main():
     stream = torch_stream.cuda_stream
     flags = {"auto": 0, "4": abi.VVM_EXEC_NO_EIGHT_WIDE, "8": abi.VVM_EXEC_FORCE_EIGHT_WIDE}[args.width]
     opt = abi.ExecOptions(0, first if first < 2 ** 31 else 0, first if first < 2 ** 31 else 0, stream, flags)
-    counts_dev = torch.zeros(1, dtype=torch.int32, device=dev)
-    gathered = torch.zeros(world, dtype=torch.int32, device=dev)
+    # The exchange of a step runs beside the next step's Exec: the count is copied on the Exec's stream, the all-gather waits for
+    # that copy on a stream of its own.  Two sets of buffers alternate; a set is written again only after the all-gather that read
+    # it two steps earlier has finished (an event the Exec's stream waits for, long past by then).
+    coll_stream = torch.cuda.Stream(device=dev)
+    counts_dev = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(2)]
+    gathered = [torch.zeros(world, dtype=torch.int32, device=dev) for _ in range(2)]
+    counted = [torch.cuda.Event() for _ in range(2)]
+    exchanged = [torch.cuda.Event() for _ in range(2)]
+    steps_done = [0]
 
     def step():
+        k = steps_done[0] & 1
+        steps_done[0] += 1
         with torch.cuda.stream(torch_stream):
             state.exec_async(frame, opt)
             if distributed:
                 # the path's one exchange: every rank's survivor count, for the global acquireindex offsets
-                state.copy_counts(counts_dev.data_ptr(), stream)
-                if args.backend == "nccl":
-                    dist.all_gather_into_tensor(gathered, counts_dev)
-                else:      # rehearsal: gloo gathers host tensors
-                    torch_stream.synchronize()
-                    parts = [torch.zeros(1, dtype=torch.int32) for _ in range(world)]
-                    dist.all_gather(parts, counts_dev.cpu())
-                    gathered.copy_(torch.cat(parts))
+                torch_stream.wait_event(exchanged[k])
+                state.copy_counts(counts_dev[k].data_ptr(), stream)
+                counted[k].record(torch_stream)
+        if distributed:
+            if args.backend == "nccl":
+                with torch.cuda.stream(coll_stream):
+                    coll_stream.wait_event(counted[k])
+                    dist.all_gather_into_tensor(gathered[k], counts_dev[k])
+                    exchanged[k].record(coll_stream)
+            else:      # rehearsal: gloo gathers host tensors
+                torch_stream.synchronize()
+                parts = [torch.zeros(1, dtype=torch.int32) for _ in range(world)]
+                dist.all_gather(parts, counts_dev[k].cpu())
+                gathered[k].copy_(torch.cat(parts))
 
     for _ in range(args.warmup):
         step()
@@ -212,9 +235,10 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        offs = global_offsets(gathered.tolist())
-        assert int(gathered[rank].item()) == survivors
-        assert offs[rank] == sum(gathered.tolist()[:rank])
+        last = gathered[(steps_done[0] - 1) & 1].tolist()
+        offs = global_offsets(last)
+        assert last[rank] == survivors, (last, rank, survivors)
+        assert offs[rank] == sum(last[:rank])
 
     # what a plain device-to-device copy of the same sixteen streams sustains on this box, for scale (not a bound the kernel is
     # priced against: `peak` stays the HBM peak)
