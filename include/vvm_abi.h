@@ -205,7 +205,11 @@ enum {
 	 * VVM_EIGHT_WIDE_MIN_INSTANCES instances runs with eight instances per lane instead of four: half the interpreter
 	 * overhead per instance.  The results are the same either way. */
 	VVM_EXEC_NO_EIGHT_WIDE = 1u << 1,    /* never */
-	VVM_EXEC_FORCE_EIGHT_WIDE = 1u << 2  /* whenever the script allows it, whatever the size (tests) */
+	VVM_EXEC_FORCE_EIGHT_WIDE = 1u << 2, /* whenever the script allows it, whatever the size (tests) */
+	/* The per-Exec parameter block (descriptor, constants, stream addresses) of a single Exec normally reaches the kernel as a
+	 * kernel argument when it fits 1 KB, and otherwise through a host-to-device copy enqueued ahead of the launch.  This flag
+	 * takes the copy whatever the size (tests / comparison; the environment variable VVM_NO_INLINE_PARAMS does the same). */
+	VVM_EXEC_PARAMS_IN_MEMORY = 1u << 3
 };
 #define VVM_EIGHT_WIDE_MIN_INSTANCES (256 * 1024)
 

@@ -18,6 +18,7 @@ VVM_EXTFN_HOST_CALLBACK, VVM_EXTFN_PERLIN3, VVM_EXTFN_CURL_NOISE3 = 0, 1, 2
 VVM_EXEC_NO_VGPR_WIDE = 1
 VVM_EXEC_NO_EIGHT_WIDE = 2
 VVM_EXEC_FORCE_EIGHT_WIDE = 4
+VVM_EXEC_PARAMS_IN_MEMORY = 8
 
 STATUS_NAMES = {0: "VVM_OK", 1: "VVM_E_INVALID_ARG", 2: "VVM_E_EXTFN_MISMATCH", 3: "VVM_E_NO_BYTECODE",
                 4: "VVM_E_UNSUPPORTED_OP", 5: "VVM_E_BAD_BLOB", 6: "VVM_E_HIP", 7: "VVM_E_RCCL", 8: "VVM_E_TOO_LARGE"}

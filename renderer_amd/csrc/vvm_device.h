@@ -111,8 +111,11 @@ struct VvmExecDesc {
 };
 
 enum : uint32_t {
-	VVM_DESC_USES_PERLIN = 1u << 0
+	VVM_DESC_USES_PERLIN = 1u << 0,
+	VVM_DESC_RELATIVE    = 1u << 1     // consts, in_ptrs, load_ptrs, out_list hold byte offsets from the descriptor, not addresses
 };
+// Largest parameter block (descriptor + tables) that is handed to the kernel as a kernel argument instead of through device memory.
+#define VVM_INLINE_PARAM_BYTES 1024u
 
 // Launch-wide words in device memory; the last block to leave a launch re-arms them for the next one.
 //

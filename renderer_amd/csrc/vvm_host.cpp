@@ -152,6 +152,7 @@ struct vvm_state {
 	int32_t*  d_id_scratch = nullptr;   uint32_t id_scratch_capacity = 0;
 	int32_t   id_num_free_start = 0, id_num_spawned_start = 0;
 	uint32_t  last_width = 0;          // instances per lane of the kernel the last Exec ran on
+	int       device = -1;             // ordinal of the device that holds the state's memory (the one current at vvm_alloc_state)
 };
 
 namespace {
@@ -212,6 +213,8 @@ struct PreparedExec {
 };
 
 int g_page_kb = 64;      // vm.PageSizeInKB, VectorVMRuntime.cpp:44-50
+// VVM_NO_INLINE_PARAMS: every parameter block goes through device memory (to measure what the kernel-argument route saves)
+const bool g_no_inline_params = getenv("VVM_NO_INLINE_PARAMS") != nullptr;
 
 // The reference's chunking (VectorVMRuntime.cpp:2210-2261), which also fills ctx->Internal.
 void reference_chunking(const vvm::ThawedScript& s, vvm_exec_context* ctx, uint32_t& chunk_instances, uint32_t& num_chunks)
@@ -224,7 +227,9 @@ void reference_chunking(const vvm::ThawedScript& s, vvm_exec_context* ctx, uint3
 	uint32_t total_loops = ((uint32_t)ctx->NumInstances + 3u) >> 2;
 	if (total_loops < 1) total_loops = 1;
 	const size_t per_loop = 16u * (size_t)s.num_temps + s.max_output_dataset;
-	const size_t avail = page - overhead;
+	// (unsigned as in the reference: a page smaller than the overhead wraps to "everything fits"; a page exactly as large as
+	// the overhead would divide by zero there and counts as one byte here)
+	const size_t avail = page != overhead ? page - overhead : 1;
 	const size_t need = (((size_t)total_loops + 3) & ~(size_t)3) * per_loop;
 	uint32_t chunks = 1, max_loops = total_loops;
 	if (avail < need) {
@@ -334,10 +339,12 @@ int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, P
 	return VVM_OK;
 }
 
-// Fills one parameter block at `host` that will live at device address `dev`.
+// Fills one parameter block at `host` that will live at device address `dev`; dev = null: the block goes to the kernel as a
+// kernel argument, and the fields that point into the block hold offsets from its start (VVM_DESC_RELATIVE).
 int fill_params(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, const PreparedExec& pe, uint8_t* host,
-                uint8_t* dev, unsigned long long* d_status, uint32_t first_tile, int32_t* d_counts = nullptr)
+                uint8_t* dev_block, unsigned long long* d_status, uint32_t first_tile, int32_t* d_counts = nullptr)
 {
+	const uintptr_t dev = (uintptr_t)dev_block;
 	const vvm::ThawedScript& s = st->script;
 	const vvm::LinkedProgram& lp = *pe.lp;
 	VvmExecDesc* d = (VvmExecDesc*)host;
@@ -347,6 +354,7 @@ int fill_params(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* op
 	d->in_ptrs = (const uint64_t*)(dev + pe.off_in);
 	d->load_ptrs = (const uint64_t*)(dev + pe.off_load);
 	d->out_list = (const uint64_t*)(dev + pe.off_out);
+	if (!dev_block && lp.uses_ids) return fail(VVM_E_INVALID_ARG, "internal: a script with ID instructions needs its parameter block in device memory");
 	d->status = d_status;
 	d->counts = d_counts ? d_counts : st->d_counts;
 	if (lp.uses_perlin && !st->d_perlin) return fail(VVM_E_INVALID_ARG, "internal: the noise table of this state was not uploaded");
@@ -358,7 +366,7 @@ int fill_params(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* op
 	d->rand_seed_lo = opt ? (uint32_t)opt->RandSeed : 0;
 	d->rand_seed_hi = opt ? (uint32_t)(opt->RandSeed >> 32) : 0;
 	d->rand_instance_base = opt ? opt->RandInstanceBase : 0;
-	d->flags = lp.uses_perlin ? VVM_DESC_USES_PERLIN : 0;
+	d->flags = (lp.uses_perlin ? VVM_DESC_USES_PERLIN : 0) | (dev_block ? 0 : VVM_DESC_RELATIVE);
 	d->num_unif = std::min<uint32_t>((s.num_consts + 3u) & ~3u, VVM_MAX_UNIFORMS);
 
 	uint32_t* consts = (uint32_t*)(host + pe.off_consts);                                               // RT.cpp:2204-2207
@@ -427,7 +435,7 @@ int fill_params(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* op
 		ids->chunk_instances = pe.chunk_instances;
 		ids->num_instances = (uint32_t)ctx->NumInstances;
 		ids->num_chunks = pe.num_chunks;
-		d->ids = (const VvmIdDesc*)(dev + pe.off_ids);
+		d->ids = (const VvmIdDesc*)(dev + pe.off_ids);      // (dev is an address here: checked above)
 		for (size_t k = 0; k < lp.out_list.size(); ++k)
 			if (lp.out_list[k] == -2) {
 				out_list[k] = (uint64_t)(uintptr_t)d->ids | VVM_OUT_UPDATE_ID;
@@ -482,6 +490,7 @@ VVM_API vvm_state* vvm_alloc_state(const uint8_t* blob, size_t num_bytes)
 	if (rc != VVM_OK) { fail(rc, err); delete st; return nullptr; }
 	auto bail = [&](hipError_t e, const char* where) -> vvm_state* { hip_fail(e, where); vvm_free_state(st); return nullptr; };
 	if (ensure_device_info() != VVM_OK) { vvm_free_state(st); return nullptr; }
+	if (hipGetDevice(&st->device) != hipSuccess) { fail(VVM_E_HIP, "hipGetDevice"); vvm_free_state(st); return nullptr; }
 	if (upload_code(st->wide, &st->d_code_wide) != VVM_OK) { vvm_free_state(st); return nullptr; }
 	if (link_more_passes(st->script, false, st->wide, st->wide_more, st->d_code_wide_more) != VVM_OK) { vvm_free_state(st); return nullptr; }
 	hipError_t e;
@@ -529,6 +538,11 @@ VVM_API int vvm_exec_async(vvm_exec_context* ctx, const vvm_exec_options* opt)
 {
 	if (!ctx || !ctx->VVMState) return fail(VVM_E_INVALID_ARG, "null context or state");
 	vvm_state* st = ctx->VVMState;
+	{   // the state's code, tables and launch words live on one device: the Exec has to be issued with that device current
+		int dev = -1;
+		HIP_TRY(hipGetDevice(&dev));
+		if (dev != st->device) return fail(VVM_E_INVALID_ARG, "the state was allocated on another device than the one that is current");
+	}
 	PreparedExec pe;
 	int rc = prepare(st, ctx, opt, pe);
 	if (rc != VVM_OK) return rc;
@@ -563,8 +577,6 @@ VVM_API int vvm_exec_async(vvm_exec_context* ctx, const vvm_exec_options* opt)
 			rc = prepare(st, ctx, opt, pe, pass);
 			if (rc != VVM_OK) return rc;
 		}
-		rc = st->ring.reserve(pe.bytes);
-		if (rc != VVM_OK) return rc;
 		if (pe.lp->uses_ids) {
 			const vvm_dataset_meta& ds = ctx->DataSets.data[pe.lp->id_dataset];
 			st->id_num_free_start = *ds.NumFreeIDs;
@@ -584,24 +596,38 @@ VVM_API int vvm_exec_async(vvm_exec_context* ctx, const vvm_exec_options* opt)
 				HIP_TRY(hipMemcpyAsync(st->d_counts + ncounts, st->h_counts + ncounts + 1, 4, hipMemcpyHostToDevice, stream));
 			}
 		}
-		int slot = 0;
-		rc = st->ring.acquire(slot);
-		if (rc != VVM_OK) return rc;
-		rc = fill_params(st, ctx, opt, pe, st->ring.host[slot], st->ring.dev[slot], st->d_status, 0);
-		if (rc != VVM_OK) return rc;
-		HIP_TRY(hipMemcpyAsync(st->ring.dev[slot], st->ring.host[slot], pe.bytes, hipMemcpyHostToDevice, stream));
+		// A small block travels as a kernel argument; a larger one, or one whose ID descriptor other kernels read, through a slot
+		// of the ring (pinned copy, device copy, one host-to-device copy ahead of the launch).
+		const bool inline_block = pe.bytes <= VVM_INLINE_PARAM_BYTES && !pe.lp->uses_ids && !g_no_inline_params && !(opt && (opt->Flags & VVM_EXEC_PARAMS_IN_MEMORY));
+		int slot = -1;
+		alignas(64) uint8_t local_block[VVM_INLINE_PARAM_BYTES];
+		if (inline_block) {
+			rc = fill_params(st, ctx, opt, pe, local_block, nullptr, st->d_status, 0);
+			if (rc != VVM_OK) return rc;
+		} else {
+			rc = st->ring.reserve(pe.bytes);
+			if (rc != VVM_OK) return rc;
+			rc = st->ring.acquire(slot);
+			if (rc != VVM_OK) return rc;
+			rc = fill_params(st, ctx, opt, pe, st->ring.host[slot], st->ring.dev[slot], st->d_status, 0);
+			if (rc != VVM_OK) return rc;
+			HIP_TRY(hipMemcpyAsync(st->ring.dev[slot], st->ring.host[slot], pe.bytes, hipMemcpyHostToDevice, stream));
+		}
 		if (timed && pass == 0) HIP_TRY(hipEventRecord(st->ev_start[st->ev_used], stream));
-		const int lrc = vvm_launch_exec_kernel((int)pe.instances_per_lane, (const VvmExecDesc*)st->ring.dev[slot], 1, pe.tiles, st->d_launch,
+		const int lrc = vvm_launch_exec_kernel((int)pe.instances_per_lane, inline_block ? nullptr : (const VvmExecDesc*)st->ring.dev[slot], 1, pe.tiles, st->d_launch,
 		                                       pe.lp->many_registers ? 1 : 0, pe.lp->lds_spill_slots, pe.lp->full_kernel ? 1 : 0,
-		                                       grid_for(pe.tiles, pe.instances_per_lane, pe.lp->full_kernel, pe.lp->many_registers), stream);
+		                                       grid_for(pe.tiles, pe.instances_per_lane, pe.lp->full_kernel, pe.lp->many_registers), stream,
+		                                       inline_block ? local_block : nullptr, inline_block ? (uint32_t)pe.bytes : 0u);
 		if (lrc != 0) return hip_fail((hipError_t)lrc, "kernel launch");
 		if (timed && pass + 1 == num_passes) { HIP_TRY(hipEventRecord(st->ev_stop[st->ev_used], stream)); st->ev_used++; }
 		if (pe.lp->uses_ids && pe.lp->updates_ids) {
 			const int mrc = vvm_launch_max_id_kernel((const VvmIdDesc*)(st->ring.dev[slot] + pe.off_ids), pe.num_chunks, stream);
 			if (mrc != 0) return hip_fail((hipError_t)mrc, "MaxUsedID kernel launch");
 		}
-		HIP_TRY(hipEventRecord(st->ring.done[slot], stream));
-		st->ring.pending[slot] = true;
+		if (slot >= 0) {
+			HIP_TRY(hipEventRecord(st->ring.done[slot], stream));
+			st->ring.pending[slot] = true;
+		}
 	}
 	// (the survivor counts and the launch words come back in vvm_exec_finish: of several Execs queued on a state only the last
 	// one's are reported, and two copies per Exec were a fifth of the host's time per call)
@@ -672,6 +698,7 @@ struct BatchWorkspace {
 	VvmLaunchState* d_launch[8] = {};
 	VvmLaunchState* h_launch = nullptr;
 	hipStream_t stream = nullptr;
+	int device = -1;      // the workspace belongs to the device of the first batch (one process drives one GPU)
 };
 BatchWorkspace g_batch;
 }  // namespace
@@ -683,6 +710,12 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 	std::lock_guard<std::mutex> lock(g_batch.mutex);
 	int rc = ensure_device_info();
 	if (rc != VVM_OK) return rc;
+	{
+		int dev = -1;
+		HIP_TRY(hipGetDevice(&dev));
+		if (g_batch.device < 0) g_batch.device = dev;
+		if (dev != g_batch.device) return fail(VVM_E_INVALID_ARG, "vvm_exec_batch serves one device per process; it was first used with another device current");
+	}
 	static uint64_t batch_counter = 0;
 	const uint64_t stamp = ++batch_counter;      // (under the workspace mutex)
 	const bool report = getenv("VVM_DEBUG_STATS") != nullptr;
@@ -707,6 +740,7 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 		size_t table_bytes = 0;
 		for (int i = slice.first; i < slice.first + slice.count; ++i) {
 			if (!ctxs[i].VVMState) return fail(VVM_E_INVALID_ARG, "null state in batch");
+			if (ctxs[i].VVMState->device != g_batch.device) return fail(VVM_E_INVALID_ARG, "a state of the batch was allocated on another device than the one that is current");
 			if (ctxs[i].VVMState->batch_stamp == stamp) return fail(VVM_E_INVALID_ARG, "a state appears twice in one batch (one Exec at a time per state)");
 			ctxs[i].VVMState->batch_stamp = stamp;
 			rc = prepare(ctxs[i].VVMState, &ctxs[i], opts ? &opts[i] : nullptr, pes[(size_t)i]);
@@ -817,7 +851,7 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 			const vvm::LinkedProgram& lp = *pe0.lp;
 			const int lrc = vvm_launch_exec_kernel((int)pe0.instances_per_lane, (const VvmExecDesc*)(g_batch.dev + grp.desc_off), (uint32_t)grp.members.size(), grp.tiles,
 			                                       g_batch.d_launch[g], lp.many_registers ? 1 : 0, grp.spill, lp.full_kernel ? 1 : 0,
-			                                       grid_for(grp.tiles, pe0.instances_per_lane, lp.full_kernel, lp.many_registers), g_batch.stream);
+			                                       grid_for(grp.tiles, pe0.instances_per_lane, lp.full_kernel, lp.many_registers), g_batch.stream, nullptr, 0);
 			if (lrc != 0) { (void)hipStreamSynchronize(g_batch.stream); return hip_fail((hipError_t)lrc, "batched kernel launch"); }
 			HIP_TRY(hipMemcpyAsync(&g_batch.h_launch[(size_t)sl * 8 + g], g_batch.d_launch[g], 80, hipMemcpyDeviceToHost, g_batch.stream));
 		}

@@ -8,8 +8,11 @@ extern "C" {
 // Enqueue the interpreter over `total_tiles` tiles described by `descs` (device memory).  instances_per_lane is 8, 4 or 1;
 // many_registers != 0 selects the kernels with 32 resident registers plus lds_spill_slots registers in LDS; full != 0 the
 // kernels that also implement the transcendental ops, the noise built-ins and the ID instructions.
+// A launch of one Exec may hand its parameter block over as a kernel argument instead: descs = null, inline_block = the block
+// as filled on the host with VVM_DESC_RELATIVE set, inline_bytes <= VVM_INLINE_PARAM_BYTES (copied before the call returns).
 int vvm_launch_exec_kernel(int instances_per_lane, const VvmExecDesc* descs, uint32_t num_execs, uint32_t total_tiles,
-                           VvmLaunchState* ls, int many_registers, uint32_t lds_spill_slots, int full, uint32_t grid, hipStream_t stream);
+                           VvmLaunchState* ls, int many_registers, uint32_t lds_spill_slots, int full, uint32_t grid, hipStream_t stream,
+                           const void* inline_block, uint32_t inline_bytes);
 // update_id's MaxUsedID pass over an Exec that has run (same stream).
 int vvm_launch_max_id_kernel(const VvmIdDesc* ids, uint32_t num_chunks, hipStream_t stream);
 int vvm_kernel_max_dynamic_lds(void);

@@ -20,6 +20,7 @@
 #include <stddef.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "../../include/vvm_abi.h"
 #include "vvm_device.h"
@@ -477,8 +478,12 @@ DEV bool nin_is(uint32_t nin, uint32_t n) { asm volatile("" : "+s"(nin)); return
 // scalar load: a value kept in a scalar register for the whole tile costs more than the occasional load.)
 #define DESC_U32(dp, field) sload32((dp), offsetof(VvmExecDesc, field) / 4)
 #define DESC_PTR(dp, field) sload64((dp), offsetof(VvmExecDesc, field) / 8)
+// the tables that travel with the descriptor (consts, in_ptrs, load_ptrs, out_list): their fields hold offsets from the
+// descriptor when the block came as a kernel argument, whose address the host does not know (VVM_DESC_RELATIVE)
+#define DESC_TABLE(c, field) (DESC_PTR((c).dp, field) + (c).rel)
 struct Ctx {
 	const void*     dp;           // the Exec's VvmExecDesc
+	uint64_t        rel;          // what the descriptor's table fields are relative to (0: they are addresses)
 	const uint32_t* consts;
 	const uint64_t* out_list;
 	const uint8_t*  perlin_lds;
@@ -891,9 +896,9 @@ template <int V> DEV void fetch_slow(const Ctx& c, uint32_t o, float (&out)[V])
 	const uint32_t cls = VVM_OPND_CLS(o), idx = VVM_OPND_IDX(o);
 	uint32_t u = 0;
 	if (cls == VVM_OPC_CONST) u = sload32(c.consts, idx);
-	else if (cls == VVM_OPC_NOADV) u = sload32((const void*)sload64((const void*)DESC_PTR(c.dp, in_ptrs), idx), 0);      // element [InstanceOffset], VectorVMRuntime.cpp:381-401
+	else if (cls == VVM_OPC_NOADV) u = sload32((const void*)sload64((const void*)DESC_TABLE(c, in_ptrs), idx), 0);      // element [InstanceOffset], VectorVMRuntime.cpp:381-401
 	else if (cls == VVM_OPC_NOADV_HALF) {                                                     // converted once, like VectorVMRuntime.cpp:388-394
-		const uint64_t a = sload64((const void*)DESC_PTR(c.dp, in_ptrs), idx);
+		const uint64_t a = sload64((const void*)DESC_TABLE(c, in_ptrs), idx);
 		const uint32_t w = sload32((const void*)(a & ~3ull), 0);
 		u = fbits(load_half((a & 2ull) ? (w >> 16) : (w & 0xFFFFu)));
 	}
@@ -914,12 +919,16 @@ template <int V, bool SPILL> DEV void fetch(CREGS, uint32_t uni, const Ctx& c, u
 }
 
 struct KernelEnv {
-	const VvmExecDesc* descs;
+	const VvmExecDesc* descs;      // null: the launch has one Exec, whose parameter block is `block` below
 	uint32_t num_execs;
 	uint32_t total_tiles;
 	VvmLaunchState* ls;
 	uint32_t lds_spill_slots;
 	uint32_t debug_skip;     // bring-up aid (VVM_DEBUG_SKIP): bit 0 tiles, 1 stream loads, 2 tile-0 look-back word, 3 stream stores, 4 counts, 5 look-back (assume no deaths)
+	// A single Exec's parameter block (descriptor and tables, VVM_DESC_RELATIVE) rides in the kernel-argument segment: no
+	// host-to-device copy ahead of the launch (a copy is a launch of its own on the stream, and cost more than half of the
+	// 13 us between two Execs).  The kernel never names this member; it reads the segment through scalar loads.
+	alignas(64) uint8_t block[VVM_INLINE_PARAM_BYTES];
 };
 
 // ------------------------------------------------------------------------------------------------------
@@ -964,7 +973,7 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 		const uint32_t cnt_ = ((W0) >> 16) & 0xFFu, dst_ = (W0) >> 24; \
 		_Pragma("unroll") for (int j = 7; j >= 0; --j) REG_WRITE(dst_ + min((uint32_t)j, cnt_ - 1u), (ST)[j]); \
 	} while (0)
-	const void* load_ptrs = (const void*)DESC_PTR(c.dp, load_ptrs);
+	const void* load_ptrs = (const void*)DESC_TABLE(c, load_ptrs);
 	uint32_t pc0 = 0;
 	for (;; ++pc0) {
 		const uint32_t w0 = sload32(prog, pc0 * 4 + 0);
@@ -1417,6 +1426,10 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (V == 8 || (V == 4 && SPILL
 	const uint32_t tag = SCALAR(__hip_atomic_load((gu32*)&env.ls->epoch, RLX_AGENT)) & 0x3FFFFFFFu;
 	bool perlin_ready = false;
 	uint32_t resolves = 0;
+	// where the descriptors are, and what the table fields of a descriptor are relative to (see KernelEnv::block)
+	const uint64_t block_addr = (uint64_t)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(KernelEnv, block);
+	const VvmExecDesc* descs = env.descs ? env.descs : (const VvmExecDesc*)block_addr;
+	const uint64_t rel = env.descs ? 0ull : block_addr;
 
 	if (wave == 0) lds_ctrl[LC_STATS + (lane & 7u)] = 0;
 	// A tile is claimed when the workgroup is ready to start it, never ahead of time: the look-back of a tile waits for the
@@ -1450,11 +1463,11 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (V == 8 || (V == 4 && SPILL
 			uint32_t lo = 0, hi = env.num_execs;
 			while (hi - lo > 1) {
 				const uint32_t mid = (lo + hi) >> 1;
-				if (sload32(env.descs + mid, offsetof(VvmExecDesc, first_tile) / 4) <= ticket) lo = mid; else hi = mid;
+				if (sload32(descs + mid, offsetof(VvmExecDesc, first_tile) / 4) <= ticket) lo = mid; else hi = mid;
 			}
 			e = lo;
 		}
-		const void* dp = env.descs + e;
+		const void* dp = (const void*)(descs + e);
 		const uint32_t num_instances = DESC_U32(dp, num_instances);
 		const uint32_t tile_local = ticket - DESC_U32(dp, first_tile);
 		const uint32_t tile_first = tile_local * (VVM_BLOCK_THREADS * V);
@@ -1468,7 +1481,7 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (V == 8 || (V == 4 && SPILL
 		}
 
 		Ctx c;
-		c.dp = dp; c.consts = (const uint32_t*)DESC_PTR(dp, consts); c.out_list = (const uint64_t*)DESC_PTR(dp, out_list);
+		c.dp = dp; c.rel = rel; c.consts = (const uint32_t*)DESC_TABLE(c, consts); c.out_list = (const uint64_t*)DESC_TABLE(c, out_list);
 		c.perlin_lds = lds_perlin; c.spill = lds_spill; c.tid = tid; c.wave = wave;
 		c.inst0 = tile_first + tid * lane_stride<V>();
 		c.num_instances = num_instances;
@@ -1480,7 +1493,7 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (V == 8 || (V == 4 && SPILL
 	}
 	if (pend.active) {
 		Ctx c;
-		c.dp = nullptr; c.consts = nullptr; c.out_list = nullptr; c.perlin_lds = lds_perlin; c.spill = lds_spill;
+		c.dp = nullptr; c.rel = 0; c.consts = nullptr; c.out_list = nullptr; c.perlin_lds = lds_perlin; c.spill = lds_spill;
 		c.tid = tid; c.wave = wave; c.inst0 = 0; c.num_instances = 0; c.tile_first = 0; c.valid = 0; c.phase = 0;
 		const u64 none[VVM_LB_WORDS_PER_LANE] = {};
 		resolve_tile<V>(pend, c, lds_ctrl, resolves, tag, env.ls, dbgw, none, false);
@@ -1534,9 +1547,16 @@ extern "C" int vvm_launch_max_id_kernel(const VvmIdDesc* idp, uint32_t num_chunk
 
 // ---- host-callable launcher --------------------------------------------------------------------------
 extern "C" int vvm_launch_exec_kernel(int instances_per_lane, const VvmExecDesc* descs, uint32_t num_execs, uint32_t total_tiles,
-                                      VvmLaunchState* ls, int many_registers, uint32_t lds_spill_slots, int full, uint32_t grid, hipStream_t stream)
+                                      VvmLaunchState* ls, int many_registers, uint32_t lds_spill_slots, int full, uint32_t grid, hipStream_t stream,
+                                      const void* inline_block, uint32_t inline_bytes)
 {
 	KernelEnv env;
+	if (inline_block) {
+		if (descs || num_execs != 1 || inline_bytes > VVM_INLINE_PARAM_BYTES) return (int)hipErrorInvalidValue;
+		memcpy(env.block, inline_block, inline_bytes);
+	} else if (!descs) {
+		return (int)hipErrorInvalidValue;
+	}
 	env.descs = descs; env.num_execs = num_execs; env.total_tiles = total_tiles; env.ls = ls; env.lds_spill_slots = lds_spill_slots;
 	{ const char* dbg = getenv("VVM_DEBUG_SKIP"); env.debug_skip = dbg ? (uint32_t)strtoul(dbg, nullptr, 0) : 0u; }
 	const size_t lds_bytes = (instances_per_lane == 8 ? LDS_SPILL_OFF(8) : instances_per_lane == 4 ? LDS_SPILL_OFF(4) : LDS_SPILL_OFF(1)) +

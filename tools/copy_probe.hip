@@ -40,13 +40,21 @@ template <int NS, int CH> void run(size_t stagger, int grid)
 	printf("%d+%d streams, %d x 4 KB per stream and trip, stagger %7zu, grid %6d%s: %.3f ms  %.0f GB/s\n", NS, NS, CH, stagger, g,
 		grid > 0 ? " (persistent)" : " (one trip)  ", ms, 2.0 * total / ms / 1e6);
 }
-int main()
+int main(int argc, char**)
 {
 	const size_t maxStagger = 1 << 20;
 	CK(hipMalloc((void**)&base, 2 * total + 16 * maxStagger));
 	CK(hipMemset(base, 0, 2 * total + 16 * maxStagger));
 	CK(hipEventCreate(&ea)); CK(hipEventCreate(&eb));
+	const bool wide = argc > 1;	// any argument: the larger pieces per trip only
 	const size_t st[] = {0, 4352, 36864};
+	if (wide) {
+		for (size_t s : st) {
+			run<8, 2>(s, 0); run<8, 4>(s, 0); run<8, 2>(s, 512); run<8, 4>(s, 256); run<8, 4>(s, 512); run<8, 4>(s, 768); run<8, 4>(s, 1024);
+			run<4, 4>(s, 0); run<4, 8>(s, 0); run<4, 8>(s, 512);
+		}
+		return 0;
+	}
 	for (size_t s : st) {
 		run<1, 1>(s, 0); run<2, 1>(s, 0); run<4, 1>(s, 0); run<8, 1>(s, 0);
 		run<8, 2>(s, 0); run<8, 1>(s, 1024); run<8, 2>(s, 512); run<8, 2>(s, 1024);
