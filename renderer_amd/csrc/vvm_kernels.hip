@@ -371,17 +371,26 @@ DEV float rand01(uint32_t r) { return bitsf((r >> 9) | 0x3F800000u) - 1.0f; }
 // Per lane the case differs, so instead of a switch (sixteen masked regions per call) the two terms are selected: bit h of
 // each constant says whether the first term is y (else x), whether it is negated, whether the second is y (else z), whether
 // it is negated.  a - b and -a + b are the IEEE sums a + (-b) and (-a) + b, so the result is bit-identical to the switch.
+// Each constant carries its sixteen bits twice, so that the bit-field extract (which takes bit h mod 32) needs no h & 15; the
+// extract is signed, one bit wide: 0 or all ones, which selects the term as a bit mask (two instructions per choice instead of
+// shift, and, compare, select).
+#define BITOP3(a, b, c, table) ((uint32_t)__builtin_amdgcn_bitop3_b32((int)(a), (int)(b), (int)(c), (table)))
 DEV float p_grad3(uint32_t h, float x, float y, float z)
 {
-	h &= 15u;
-	const uint32_t first = fbits(((0xCA44u >> h) & 1u) ? y : x) ^ (((0xEC78u >> h) & 1u) << 31);
-	const uint32_t second = fbits(((0x30AAu >> h) & 1u) ? y : z) ^ (((0x8FA0u >> h) & 1u) << 31);
+	const uint32_t first_is_y = (uint32_t)__builtin_amdgcn_sbfe((int)0xCA44CA44u, h, 1u), first_neg = (uint32_t)__builtin_amdgcn_sbfe((int)0xEC78EC78u, h, 1u);
+	const uint32_t second_is_y = (uint32_t)__builtin_amdgcn_sbfe((int)0x30AA30AAu, h, 1u), second_neg = (uint32_t)__builtin_amdgcn_sbfe((int)0x8FA08FA0u, h, 1u);
+	// any function of three bit operands is one instruction on this target: the table byte is the function applied to 0xF0, 0xCC, 0xAA
+	const uint32_t first = BITOP3(BITOP3(first_is_y, fbits(y), fbits(x), 0xCA), first_neg, 0x80000000u, 0x78);        // (m & y | ~m & x) ^ (neg & sign bit)
+	const uint32_t second = BITOP3(BITOP3(second_is_y, fbits(y), fbits(z), 0xCA), second_neg, 0x80000000u, 0x78);
 	return bitsf(first) + bitsf(second);
 }
 DEV float p_smooth(float x) { return x * x * x * (x * (x * 6.0f - 15.0f) + 10.0f); }          // UnrealMath.cpp:3605-3608
 DEV float p_lerp(float a, float b, float t) { return a + t * (b - a); }                       // UnrealMathUtility.h:1187-1190
 
-__device__ __noinline__ float perlin3(const uint8_t* P, float px, float py, float pz)                             // UnrealMath.cpp:3658-3699
+// The permutation table is named as an LDS address: through a generic pointer every one of the fourteen lookups of an
+// evaluation paid a 64-bit address, a null test and a select on top of the read (42 of 282 instructions).
+typedef const __attribute__((address_space(3))) uint8_t* lds_u8p;
+__device__ __noinline__ float perlin3(lds_u8p P, float px, float py, float pz)                             // UnrealMath.cpp:3658-3699
 {
 	const float xf = floorf(px), yf = floorf(py), zf = floorf(pz);
 	const int xi = (int)xf & 255, yi = (int)yf & 255, zi = (int)zf & 255;
@@ -399,7 +408,7 @@ __device__ __noinline__ float perlin3(const uint8_t* P, float px, float py, floa
 }
 
 // curl of three Perlin potentials at fixed offsets, central differences with step 1/64
-__device__ __noinline__ void curl_noise3(const uint8_t* P, float x, float y, float z, float& ox, float& oy, float& oz)
+__device__ __noinline__ void curl_noise3(lds_u8p P, float x, float y, float z, float& ox, float& oy, float& oz)
 {
 	const float e = 0.015625f, inv2e = 32.0f;
 	const float o1x = 31.416f, o1y = -47.853f, o1z = 12.793f;
@@ -416,7 +425,7 @@ __device__ __noinline__ void curl_noise3(const uint8_t* P, float x, float y, flo
 }
 
 // one component of curl_noise3 (0 = x, 1 = y, 2 = z): four Perlin evaluations, same arithmetic as the full form
-__device__ __noinline__ float curl_noise3_component(const uint8_t* P, float x, float y, float z, uint32_t which)
+__device__ __noinline__ float curl_noise3_component(lds_u8p P, float x, float y, float z, uint32_t which)
 {
 	const float e = 0.015625f, inv2e = 32.0f;
 	const float o1x = 31.416f, o1y = -47.853f, o1z = 12.793f;
@@ -1149,8 +1158,8 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 					// aux = built-in id, aux2 = which output this device instruction produces (VectorVMRuntime.cpp:1450-1464 lists the
 					// operands as inputs then outputs; the linker emits one instruction per output in use)
 					if constexpr (FULL) {
-						if (aux == VVM_EXTFN_PERLIN3) { _Pragma("unroll") LANES r[k] = perlin3(c.perlin_lds, A, B, C); }
-						else { _Pragma("unroll") LANES r[k] = curl_noise3_component(c.perlin_lds, A, B, C, aux2); }
+						if (aux == VVM_EXTFN_PERLIN3) { _Pragma("unroll") LANES r[k] = perlin3((lds_u8p)c.perlin_lds, A, B, C); }
+						else { _Pragma("unroll") LANES r[k] = curl_noise3_component((lds_u8p)c.perlin_lds, A, B, C, aux2); }
 					}
 					break;
 				default: { _Pragma("unroll") LANES r[k] = 0.0f; } break;
