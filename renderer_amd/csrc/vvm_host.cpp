@@ -656,8 +656,10 @@ VVM_API int vvm_exec_finish(vvm_exec_context* ctx)
 		if (getenv("VVM_DEBUG_STATS"))
 			fprintf(stderr, "vvm stats (cumulative): lookbacks %llu rounds %llu polls %llu clocks/16 %llu | ticket %llu load %llu interp %llu tiles %llu\n", ls->stats[0], ls->stats[1], ls->stats[2], ls->stats[3], ls->stats[4], ls->stats[5], ls->stats[6], ls->stats[7]);
 		if (ls->pad != 0) {
+			const bool lds_base = ls->pad == 2;
 			(void)reset_launch_state(st->d_launch);
 			if (st->d_status) (void)hipMemset(st->d_status, 0, (size_t)st->status_capacity * 8);
+			if (lds_base) return fail(VVM_E_HIP, "the kernel's dynamic LDS does not start at address 0 (the noise tables are addressed absolutely)");
 			return fail(VVM_E_HIP, "look-back timed out inside the kernel (a tile never published its count)");
 		}
 	}

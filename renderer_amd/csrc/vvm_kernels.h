@@ -17,5 +17,5 @@ int vvm_launch_exec_kernel(int instances_per_lane, const VvmExecDesc* descs, uin
 int vvm_launch_max_id_kernel(const VvmIdDesc* ids, uint32_t num_chunks, hipStream_t stream);
 int vvm_kernel_max_dynamic_lds(void);
 uint32_t vvm_kernel_resident_registers(int instances_per_lane, int many_registers);
-uint32_t vvm_kernel_lds_fixed_bytes(int instances_per_lane);
+uint32_t vvm_kernel_lds_fixed_bytes(int instances_per_lane, int full);
 }

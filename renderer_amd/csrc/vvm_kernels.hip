@@ -101,17 +101,21 @@ template <typename VEC> __device__ __forceinline__ VEC vset(VEC v, uint32_t i, f
 // LDS carve (dynamic region only, every offset a multiple of 16)
 //   [0, 256)      control words (uint32), see the LC_ constants
 //   [256, 768)    Perlin permutation table
-//   [768, 896)    unused
-//   [896, ...)    output staging: VVM_STAGE_SLOTS slots of one tile's worth of 32-bit values, then one sink dword per thread,
+//   kernels with the noise built-ins (FULL) only:
+//   [768, 1280)   the same table as gradient selectors: (entry & 15) * 16, the byte offset of the entry's row below
+//   [1280, 1536)  sixteen gradient rows of four dwords (see p_grad3)
+//   S = 896, FULL: 1664
+//   [S, ...)      output staging: VVM_STAGE_SLOTS slots of one tile's worth of 32-bit values, then one sink dword per thread,
 //                 then one dword per thread with the lane's acquireindex result (kept for update_id)
 //   then          register spill slots
 #define LDS_PERLIN_OFF      256
-#define LDS_STAGE_META_OFF  768
-#define LDS_STAGE_OFF       896
-#define LDS_STAGE_SINK_OFF(V) (LDS_STAGE_OFF + VVM_STAGE_SLOTS * VVM_BLOCK_THREADS * (V) * 4u)
-#define LDS_STAGE_KEEP_OFF(V) (LDS_STAGE_SINK_OFF(V) + VVM_BLOCK_THREADS * 4u)
+#define LDS_PERLIN_SEL_OFF  768
+#define LDS_PERLIN_GRAD_OFF 1280
+#define LDS_STAGE_OFF(FULL)   ((FULL) ? 1664u : 896u)
+#define LDS_STAGE_SINK_OFF(V, FULL) (LDS_STAGE_OFF(FULL) + VVM_STAGE_SLOTS * VVM_BLOCK_THREADS * (V) * 4u)
+#define LDS_STAGE_KEEP_OFF(V, FULL) (LDS_STAGE_SINK_OFF(V, FULL) + VVM_BLOCK_THREADS * 4u)
 #define LDS_STAGE_BYTES(V)  (VVM_STAGE_SLOTS * VVM_BLOCK_THREADS * (V) * 4u + 2u * VVM_BLOCK_THREADS * 4u)
-#define LDS_SPILL_OFF(V)    (LDS_STAGE_OFF + LDS_STAGE_BYTES(V))
+#define LDS_SPILL_OFF(V, FULL) (LDS_STAGE_OFF(FULL) + LDS_STAGE_BYTES(V))
 
 DEV uint32_t fbits(float f) { return __float_as_uint(f); }
 DEV float    bitsf(uint32_t u) { return __uint_as_float(u); }
@@ -371,17 +375,36 @@ DEV float rand01(uint32_t r) { return bitsf((r >> 9) | 0x3F800000u) - 1.0f; }
 // Per lane the case differs, so instead of a switch (sixteen masked regions per call) the two terms are selected: bit h of
 // each constant says whether the first term is y (else x), whether it is negated, whether the second is y (else z), whether
 // it is negated.  a - b and -a + b are the IEEE sums a + (-b) and (-a) + b, so the result is bit-identical to the switch.
-// Each constant carries its sixteen bits twice, so that the bit-field extract (which takes bit h mod 32) needs no h & 15; the
-// extract is signed, one bit wide: 0 or all ones, which selects the term as a bit mask (two instructions per choice instead of
-// shift, and, compare, select).
+// What the hash chooses is tabulated per workgroup in LDS: row h & 15 holds {first is y (all ones) else x, sign bit if the first
+// term is negated, second is y else z, sign bit if the second is negated}, built from the four bit sets below by perlin_rows;
+// a second copy of the permutation table holds the rows' byte offsets, so a corner costs two LDS reads, two selects, two sign
+// flips and the sum.  (Extracting the four choices from the bit sets per corner took four more instructions, a quarter of
+// an evaluation.)
 #define BITOP3(a, b, c, table) ((uint32_t)__builtin_amdgcn_bitop3_b32((int)(a), (int)(b), (int)(c), (table)))
-DEV float p_grad3(uint32_t h, float x, float y, float z)
+typedef const __attribute__((address_space(3))) uint8_t* lds_u8p;
+typedef uint32_t lds_row __attribute__((ext_vector_type(4)));
+// The noise tables are addressed by their absolute LDS offsets (a lookup is then one read whose address is the index itself,
+// the table's offset riding in the instruction).  That holds because these kernels declare no static LDS, so the dynamic
+// region starts at LDS address 0; the kernel checks it where it fills the tables and reports a launch error otherwise.
+#define PERLIN_LDS ((lds_u8p)(unsigned int)LDS_PERLIN_OFF)
+DEV lds_row perlin_row(uint32_t h)
 {
-	const uint32_t first_is_y = (uint32_t)__builtin_amdgcn_sbfe((int)0xCA44CA44u, h, 1u), first_neg = (uint32_t)__builtin_amdgcn_sbfe((int)0xEC78EC78u, h, 1u);
-	const uint32_t second_is_y = (uint32_t)__builtin_amdgcn_sbfe((int)0x30AA30AAu, h, 1u), second_neg = (uint32_t)__builtin_amdgcn_sbfe((int)0x8FA08FA0u, h, 1u);
-	// any function of three bit operands is one instruction on this target: the table byte is the function applied to 0xF0, 0xCC, 0xAA
-	const uint32_t first = BITOP3(BITOP3(first_is_y, fbits(y), fbits(x), 0xCA), first_neg, 0x80000000u, 0x78);        // (m & y | ~m & x) ^ (neg & sign bit)
-	const uint32_t second = BITOP3(BITOP3(second_is_y, fbits(y), fbits(z), 0xCA), second_neg, 0x80000000u, 0x78);
+	lds_row r;
+	r.x = (uint32_t)__builtin_amdgcn_sbfe((int)0xCA44u, h, 1u);
+	r.y = ((0xEC78u >> h) & 1u) << 31;
+	r.z = (uint32_t)__builtin_amdgcn_sbfe((int)0x30AAu, h, 1u);
+	r.w = ((0x8FA0u >> h) & 1u) << 31;
+	return r;
+}
+// any function of three bit operands is one instruction on this target: the table byte is the function applied to 0xF0, 0xCC, 0xAA
+// (0xCA: a & b | ~a & c)
+DEV float p_grad3(uint32_t corner, float x, float y, float z)
+{
+	const lds_u8p P = PERLIN_LDS;
+	const uint32_t row = P[(LDS_PERLIN_SEL_OFF - LDS_PERLIN_OFF) + corner];
+	const lds_row g = *(const __attribute__((address_space(3))) lds_row*)(P + (LDS_PERLIN_GRAD_OFF - LDS_PERLIN_OFF) + row);
+	const uint32_t first = BITOP3(g.x, fbits(y), fbits(x), 0xCA) ^ g.y;
+	const uint32_t second = BITOP3(g.z, fbits(y), fbits(z), 0xCA) ^ g.w;
 	return bitsf(first) + bitsf(second);
 }
 DEV float p_smooth(float x) { return x * x * x * (x * (x * 6.0f - 15.0f) + 10.0f); }          // UnrealMath.cpp:3605-3608
@@ -389,9 +412,9 @@ DEV float p_lerp(float a, float b, float t) { return a + t * (b - a); }         
 
 // The permutation table is named as an LDS address: through a generic pointer every one of the fourteen lookups of an
 // evaluation paid a 64-bit address, a null test and a select on top of the read (42 of 282 instructions).
-typedef const __attribute__((address_space(3))) uint8_t* lds_u8p;
-__device__ __noinline__ float perlin3(lds_u8p P, float px, float py, float pz)                             // UnrealMath.cpp:3658-3699
+__device__ __noinline__ float perlin3(float px, float py, float pz)                             // UnrealMath.cpp:3658-3699
 {
+	const lds_u8p P = PERLIN_LDS;
 	const float xf = floorf(px), yf = floorf(py), zf = floorf(pz);
 	const int xi = (int)xf & 255, yi = (int)yf & 255, zi = (int)zf & 255;
 	const float x = px - xf, y = py - yf, z = pz - zf;
@@ -400,47 +423,47 @@ __device__ __noinline__ float perlin3(lds_u8p P, float px, float py, float pz)  
 	const int b = P[xi + 1] + yi, ba = P[b] + zi, bb = P[b + 1] + zi;
 	const float u = p_smooth(x), v = p_smooth(y), w = p_smooth(z);
 	const float r = 0.97f * p_lerp(
-		p_lerp(p_lerp(p_grad3(P[aa], x, y, z), p_grad3(P[ba], xm, y, z), u),
-		       p_lerp(p_grad3(P[ab], x, ym, z), p_grad3(P[bb], xm, ym, z), u), v),
-		p_lerp(p_lerp(p_grad3(P[aa + 1], x, y, zm), p_grad3(P[ba + 1], xm, y, zm), u),
-		       p_lerp(p_grad3(P[ab + 1], x, ym, zm), p_grad3(P[bb + 1], xm, ym, zm), u), v), w);
+		p_lerp(p_lerp(p_grad3(aa, x, y, z), p_grad3(ba, xm, y, z), u),
+		       p_lerp(p_grad3(ab, x, ym, z), p_grad3(bb, xm, ym, z), u), v),
+		p_lerp(p_lerp(p_grad3(aa + 1, x, y, zm), p_grad3(ba + 1, xm, y, zm), u),
+		       p_lerp(p_grad3(ab + 1, x, ym, zm), p_grad3(bb + 1, xm, ym, zm), u), v), w);
 	return r < -1.0f ? -1.0f : (r < 1.0f ? r : 1.0f);
 }
 
 // curl of three Perlin potentials at fixed offsets, central differences with step 1/64
-__device__ __noinline__ void curl_noise3(lds_u8p P, float x, float y, float z, float& ox, float& oy, float& oz)
+__device__ __noinline__ void curl_noise3(float x, float y, float z, float& ox, float& oy, float& oz)
 {
 	const float e = 0.015625f, inv2e = 32.0f;
 	const float o1x = 31.416f, o1y = -47.853f, o1z = 12.793f;
 	const float o2x = -233.145f, o2y = -113.408f, o2z = -185.31f;
-	const float p2_dy = perlin3(P, x + o2x, (y + e) + o2y, z + o2z) - perlin3(P, x + o2x, (y - e) + o2y, z + o2z);
-	const float p1_dz = perlin3(P, x + o1x, y + o1y, (z + e) + o1z) - perlin3(P, x + o1x, y + o1y, (z - e) + o1z);
-	const float p0_dz = perlin3(P, x, y, z + e) - perlin3(P, x, y, z - e);
-	const float p2_dx = perlin3(P, (x + e) + o2x, y + o2y, z + o2z) - perlin3(P, (x - e) + o2x, y + o2y, z + o2z);
-	const float p1_dx = perlin3(P, (x + e) + o1x, y + o1y, z + o1z) - perlin3(P, (x - e) + o1x, y + o1y, z + o1z);
-	const float p0_dy = perlin3(P, x, y + e, z) - perlin3(P, x, y - e, z);
+	const float p2_dy = perlin3(x + o2x, (y + e) + o2y, z + o2z) - perlin3(x + o2x, (y - e) + o2y, z + o2z);
+	const float p1_dz = perlin3(x + o1x, y + o1y, (z + e) + o1z) - perlin3(x + o1x, y + o1y, (z - e) + o1z);
+	const float p0_dz = perlin3(x, y, z + e) - perlin3(x, y, z - e);
+	const float p2_dx = perlin3((x + e) + o2x, y + o2y, z + o2z) - perlin3((x - e) + o2x, y + o2y, z + o2z);
+	const float p1_dx = perlin3((x + e) + o1x, y + o1y, z + o1z) - perlin3((x - e) + o1x, y + o1y, z + o1z);
+	const float p0_dy = perlin3(x, y + e, z) - perlin3(x, y - e, z);
 	ox = (p2_dy - p1_dz) * inv2e;
 	oy = (p0_dz - p2_dx) * inv2e;
 	oz = (p1_dx - p0_dy) * inv2e;
 }
 
 // one component of curl_noise3 (0 = x, 1 = y, 2 = z): four Perlin evaluations, same arithmetic as the full form
-__device__ __noinline__ float curl_noise3_component(lds_u8p P, float x, float y, float z, uint32_t which)
+__device__ __noinline__ float curl_noise3_component(float x, float y, float z, uint32_t which)
 {
 	const float e = 0.015625f, inv2e = 32.0f;
 	const float o1x = 31.416f, o1y = -47.853f, o1z = 12.793f;
 	const float o2x = -233.145f, o2y = -113.408f, o2z = -185.31f;
 	if (which == 0) {
-		const float p2_dy = perlin3(P, x + o2x, (y + e) + o2y, z + o2z) - perlin3(P, x + o2x, (y - e) + o2y, z + o2z);
-		const float p1_dz = perlin3(P, x + o1x, y + o1y, (z + e) + o1z) - perlin3(P, x + o1x, y + o1y, (z - e) + o1z);
+		const float p2_dy = perlin3(x + o2x, (y + e) + o2y, z + o2z) - perlin3(x + o2x, (y - e) + o2y, z + o2z);
+		const float p1_dz = perlin3(x + o1x, y + o1y, (z + e) + o1z) - perlin3(x + o1x, y + o1y, (z - e) + o1z);
 		return (p2_dy - p1_dz) * inv2e;
 	} else if (which == 1) {
-		const float p0_dz = perlin3(P, x, y, z + e) - perlin3(P, x, y, z - e);
-		const float p2_dx = perlin3(P, (x + e) + o2x, y + o2y, z + o2z) - perlin3(P, (x - e) + o2x, y + o2y, z + o2z);
+		const float p0_dz = perlin3(x, y, z + e) - perlin3(x, y, z - e);
+		const float p2_dx = perlin3((x + e) + o2x, y + o2y, z + o2z) - perlin3((x - e) + o2x, y + o2y, z + o2z);
 		return (p0_dz - p2_dx) * inv2e;
 	}
-	const float p1_dx = perlin3(P, (x + e) + o1x, y + o1y, z + o1z) - perlin3(P, (x - e) + o1x, y + o1y, z + o1z);
-	const float p0_dy = perlin3(P, x, y + e, z) - perlin3(P, x, y - e, z);
+	const float p1_dx = perlin3((x + e) + o1x, y + o1y, z + o1z) - perlin3((x - e) + o1x, y + o1y, z + o1z);
+	const float p0_dy = perlin3(x, y + e, z) - perlin3(x, y - e, z);
 	return (p1_dx - p0_dy) * inv2e;
 }
 
@@ -495,7 +518,6 @@ struct Ctx {
 	uint64_t        rel;          // what the descriptor's table fields are relative to (0: they are addresses)
 	const uint32_t* consts;
 	const uint64_t* out_list;
-	const uint8_t*  perlin_lds;
 	float*          spill;        // LDS, [slot][thread] (V floats per thread and slot)
 	uint32_t tid;
 	uint32_t wave;                // tid / 64 as a scalar
@@ -885,8 +907,8 @@ template <int V, bool FULL> DEV void store_tile(Pending& p, const Ctx& c, unsign
 		sload64x8(p.out_list, STAGED_FIRST(p.stage_end), entry);
 		StoreArgs a;
 		a.i0 = c.tid * lane_stride<V>(); a.off4 = 4ull * p.base; a.rec4 = 4u * p.total; a.base = p.base; a.tile_first = p.tile_local * (VVM_BLOCK_THREADS * V);
-		a.keep_word = (const uint32_t*)(lds + LDS_STAGE_KEEP_OFF(V)) + c.tid;
-		const float* src = (const float*)(lds + LDS_STAGE_OFF) + a.i0;
+		a.keep_word = (const uint32_t*)(lds + LDS_STAGE_KEEP_OFF(V, FULL)) + c.tid;
+		const float* src = (const float*)(lds + LDS_STAGE_OFF(FULL)) + a.i0;
 		if (entry[0] & VVM_OUT_GROUP16) store_slots<V, true, FULL>(entry, n_staged, src, a);
 		else store_slots<V, false, FULL>(entry, n_staged, src, a);
 	}
@@ -1158,8 +1180,8 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 					// aux = built-in id, aux2 = which output this device instruction produces (VectorVMRuntime.cpp:1450-1464 lists the
 					// operands as inputs then outputs; the linker emits one instruction per output in use)
 					if constexpr (FULL) {
-						if (aux == VVM_EXTFN_PERLIN3) { _Pragma("unroll") LANES r[k] = perlin3((lds_u8p)c.perlin_lds, A, B, C); }
-						else { _Pragma("unroll") LANES r[k] = curl_noise3_component((lds_u8p)c.perlin_lds, A, B, C, aux2); }
+						if (aux == VVM_EXTFN_PERLIN3) { _Pragma("unroll") LANES r[k] = perlin3(A, B, C); }
+						else { _Pragma("unroll") LANES r[k] = curl_noise3_component(A, B, C, aux2); }
 					}
 					break;
 				default: { _Pragma("unroll") LANES r[k] = 0.0f; } break;
@@ -1349,13 +1371,13 @@ leave_run:
 			const uint32_t slot_index = o4 | (o5 << 16);
 			float v[V];
 			fetch<V, SPILL>(RARGS, uni, c, o0, v);
-			float* slot = (float*)(lds + LDS_STAGE_OFF) + (slot_index & (VVM_STAGE_SLOTS - 1u)) * (VVM_BLOCK_THREADS * V) + c.tid * V;
+			float* slot = (float*)(lds + LDS_STAGE_OFF(FULL)) + (slot_index & (VVM_STAGE_SLOTS - 1u)) * (VVM_BLOCK_THREADS * V) + c.tid * V;
 			if constexpr (V >= 4) { f4a x; x.x = v[0]; x.y = v[1]; x.z = v[2]; x.w = v[3]; *(f4a*)slot = x; }
 			else slot[0] = v[0];
 			uint32_t exists = 0;
 #pragma unroll
 			for (int k = 0; k < V; ++k) exists |= ((c.inst0 + slot_offset<V>(k) < c.num_instances) ? 1u : 0u) << k;
-			((uint32_t*)(lds + LDS_STAGE_KEEP_OFF(V)))[c.tid] = t_rank | (t_keep << 16) | (exists << 24);
+			((uint32_t*)(lds + LDS_STAGE_KEEP_OFF(V, FULL)))[c.tid] = t_rank | (t_keep << 16) | (exists << 24);
 			stage_end = max(stage_end, slot_index + 1u);      // (the group's last slot: outputs staged after this one lie below it)
 			continue;
 		}
@@ -1368,8 +1390,8 @@ leave_run:
 			const bool all_alive = (t_total == VVM_BLOCK_THREADS * V);
 			const uint32_t kind = op - VVM_DOP_OUTPUT32;          // 0: 32-bit value  1: float -> half  2: low 16 bits as they are  3: half bits -> float
 			const uint32_t first_slot = o4 | (o5 << 16);
-			float* slot = (float*)(lds + LDS_STAGE_OFF) + (first_slot & (VVM_STAGE_SLOTS - 1u)) * (VVM_BLOCK_THREADS * V);
-			float* sink = (float*)(lds + LDS_STAGE_SINK_OFF(V)) + c.tid;
+			float* slot = (float*)(lds + LDS_STAGE_OFF(FULL)) + (first_slot & (VVM_STAGE_SLOTS - 1u)) * (VVM_BLOCK_THREADS * V);
+			float* sink = (float*)(lds + LDS_STAGE_SINK_OFF(V, FULL)) + c.tid;
 			uint64_t srcs = (uint64_t)o0 | ((uint64_t)o1 << 16) | ((uint64_t)o2 << 32);
 			for (uint32_t j = 0; j < aux; ++j, srcs >>= 16, slot += VVM_BLOCK_THREADS * V) {
 				float v[V];
@@ -1422,7 +1444,7 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (V == 8 || (V == 4 && SPILL
 	const uint32_t dbgw = DBG ? env.debug_skip : 0u;
 	uint32_t* lds_ctrl = (uint32_t*)lds;
 	uint8_t* lds_perlin = lds + LDS_PERLIN_OFF;
-	float* lds_spill = (float*)(lds + LDS_SPILL_OFF(V));
+	float* lds_spill = (float*)(lds + LDS_SPILL_OFF(V, FULL));
 	Pending pend;
 	pend.active = false; pend.unresolved = false; pend.last = false; pend.total = 0; pend.base = 0; pend.stage_end = 0; pend.tile_local = 0;
 	pend.status = nullptr; pend.out_list = nullptr;
@@ -1484,14 +1506,21 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (V == 8 || (V == 4 && SPILL
 
 		if (FULL && (DESC_U32(dp, flags) & VVM_DESC_USES_PERLIN) && !perlin_ready) {
 			const uint8_t* perlin = (const uint8_t*)DESC_PTR(dp, perlin);
-			for (uint32_t i = tid; i < 512; i += VVM_BLOCK_THREADS) lds_perlin[i] = perlin[i];
+			for (uint32_t i = tid; i < 512; i += VVM_BLOCK_THREADS) {
+				const uint8_t h = perlin[i];
+				lds_perlin[i] = h;
+				lds_perlin[(LDS_PERLIN_SEL_OFF - LDS_PERLIN_OFF) + i] = (uint8_t)((h & 15u) << 4);
+			}
+			((lds_row*)(lds + LDS_PERLIN_GRAD_OFF))[tid & 15u] = perlin_row(tid & 15u);      // (every thread writes: no per-lane branch)
+			// the noise functions address these tables absolutely (see PERLIN_LDS); wave-uniform test, every thread stores the same word
+			if ((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)lds != 0u) __hip_atomic_store((gu32*)&env.ls->pad, 2u, RLX_AGENT);
 			perlin_ready = true;
 			__syncthreads();
 		}
 
 		Ctx c;
 		c.dp = dp; c.rel = rel; c.consts = (const uint32_t*)DESC_TABLE(c, consts); c.out_list = (const uint64_t*)DESC_TABLE(c, out_list);
-		c.perlin_lds = lds_perlin; c.spill = lds_spill; c.tid = tid; c.wave = wave;
+		c.spill = lds_spill; c.tid = tid; c.wave = wave;
 		c.inst0 = tile_first + tid * lane_stride<V>();
 		c.num_instances = num_instances;
 		c.tile_first = tile_first;
@@ -1502,7 +1531,7 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (V == 8 || (V == 4 && SPILL
 	}
 	if (pend.active) {
 		Ctx c;
-		c.dp = nullptr; c.rel = 0; c.consts = nullptr; c.out_list = nullptr; c.perlin_lds = lds_perlin; c.spill = lds_spill;
+		c.dp = nullptr; c.rel = 0; c.consts = nullptr; c.out_list = nullptr; c.spill = lds_spill;
 		c.tid = tid; c.wave = wave; c.inst0 = 0; c.num_instances = 0; c.tile_first = 0; c.valid = 0; c.phase = 0;
 		const u64 none[VVM_LB_WORDS_PER_LANE] = {};
 		resolve_tile<V>(pend, c, lds_ctrl, resolves, tag, env.ls, dbgw, none, false);
@@ -1568,7 +1597,7 @@ extern "C" int vvm_launch_exec_kernel(int instances_per_lane, const VvmExecDesc*
 	}
 	env.descs = descs; env.num_execs = num_execs; env.total_tiles = total_tiles; env.ls = ls; env.lds_spill_slots = lds_spill_slots;
 	{ const char* dbg = getenv("VVM_DEBUG_SKIP"); env.debug_skip = dbg ? (uint32_t)strtoul(dbg, nullptr, 0) : 0u; }
-	const size_t lds_bytes = (instances_per_lane == 8 ? LDS_SPILL_OFF(8) : instances_per_lane == 4 ? LDS_SPILL_OFF(4) : LDS_SPILL_OFF(1)) +
+	const size_t lds_bytes = (instances_per_lane == 8 ? LDS_SPILL_OFF(8, full != 0) : instances_per_lane == 4 ? LDS_SPILL_OFF(4, full != 0) : LDS_SPILL_OFF(1, full != 0)) +
 	                         (size_t)lds_spill_slots * VVM_BLOCK_THREADS * 4u * (size_t)instances_per_lane;
 	const bool spill = many_registers != 0;      // the kernels with 32 resident registers and LDS register slots
 #ifdef VVM_EXPERIMENT_ONE_KERNEL
@@ -1613,4 +1642,4 @@ extern "C" uint32_t vvm_kernel_resident_registers(int instances_per_lane, int ma
 	if (instances_per_lane == 1) return RegTraits<1, true>::RV;
 	return many_registers ? RegTraits<4, true>::RV : RegTraits<4, false>::RV;
 }
-extern "C" uint32_t vvm_kernel_lds_fixed_bytes(int instances_per_lane) { return instances_per_lane == 4 ? LDS_SPILL_OFF(4) : LDS_SPILL_OFF(1); }
+extern "C" uint32_t vvm_kernel_lds_fixed_bytes(int instances_per_lane, int full) { return instances_per_lane == 4 ? LDS_SPILL_OFF(4, full != 0) : LDS_SPILL_OFF(1, full != 0); }

@@ -207,7 +207,7 @@ static int decode(const ThawedScript& s, std::vector<Decoded>& out, std::string&
 
 // ---- linker ------------------------------------------------------------------------------------------
 static const uint32_t kMaxSpillWide = 11;      // LDS register slots of the 4-instances-per-lane kernel (4 KB each per workgroup; two
-                                               // workgroups per CU must fit: 2 x (36 KB + 11 x 4 KB) = 160 KB)
+                                               // workgroups per CU must fit: 2 x (36 KB + 11 x 4 KB) = 160 KB; exactly: fixed part 35 712 bytes, 36 480 with the noise tables)
 static const uint32_t kMaxSpillNarrow = 128;   // 1 KB each
 
 // Packs the per-lane registers of a linked program by live range.  The program is straight-line code that every tile runs from
