@@ -728,7 +728,10 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 	// The batch is cut into slices of consecutive Execs; a slice is filled, uploaded and launched while the kernels of the
 	// slices before it run, so that most of the host's work on the parameter blocks is hidden behind the GPU.  Within a slice
 	// the Execs are grouped by kernel shape (instances per lane, register tier, full), one launch per group.
-	const int num_slices = n >= 4096 ? 4 : n >= 1024 ? 2 : 1;
+	// The first slice is the smallest (the GPU idles while it is filled), and each later one is as large as all before it together:
+	// filling an Exec's block takes the host about half the time the GPU needs for the Exec, so the fill stays ahead.
+	const int num_slices = n >= 4096 ? 4 : n >= 1024 ? 3 : 1;
+	auto slice_end = [&](int sl) { return sl + 1 == num_slices ? n : (int)(((int64_t)n << sl) >> (num_slices - 1)); };      // n/8, n/4, n/2, n
 	struct Group { int key; std::vector<int> members; uint32_t tiles = 0; uint32_t spill = 0; size_t desc_off = 0; };
 	struct Slice { int first = 0, count = 0; std::vector<Group> groups; size_t region_off = 0, region_bytes = 0; };
 	std::vector<Slice> slices((size_t)num_slices);
@@ -737,8 +740,8 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 	size_t total_needed = 0;
 	for (int sl = 0; sl < num_slices; ++sl) {
 		Slice& slice = slices[(size_t)sl];
-		slice.first = (int)((int64_t)n * sl / num_slices);
-		slice.count = (int)((int64_t)n * (sl + 1) / num_slices) - slice.first;
+		slice.first = sl == 0 ? 0 : slice_end(sl - 1);
+		slice.count = slice_end(sl) - slice.first;
 		size_t table_bytes = 0;
 		for (int i = slice.first; i < slice.first + slice.count; ++i) {
 			if (!ctxs[i].VVMState) return fail(VVM_E_INVALID_ARG, "null state in batch");
