@@ -249,7 +249,7 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 VVM_API const int32_t* vvm_state_device_counts(const vvm_state* state);
 VVM_API int32_t        vvm_state_max_output_dataset(const vvm_state* state);
 
-/* Introspection of the linked program (tests, DESIGN numbers). */
+/* Introspection of the linked program (tests, reported register and byte counts). */
 typedef struct vvm_program_info {
 	uint32_t NumTempRegisters, NumConstBuffers, NumInputBuffers, NumOutputBuffers;
 	uint32_t NumInstructions;       /* linked device instructions */
