@@ -700,6 +700,10 @@ struct BatchWorkspace {
 	VvmLaunchState* d_launch[8] = {};
 	VvmLaunchState* h_launch = nullptr;
 	hipStream_t stream = nullptr;
+	// The parameter blocks of a slice are uploaded on a stream of their own, so that the copy runs beside the kernels of the slice
+	// before; the kernels' stream waits for the slice's event.  (On one stream every upload sat between two kernels.)
+	hipStream_t upload_stream = nullptr;
+	hipEvent_t uploaded[4] = {};
 	int device = -1;      // the workspace belongs to the device of the first batch (one process drives one GPU)
 };
 BatchWorkspace g_batch;
@@ -774,6 +778,9 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 	}
 	const auto t_prepared = now();
 	if (!g_batch.stream) HIP_TRY(hipStreamCreateWithFlags(&g_batch.stream, hipStreamNonBlocking));
+	if (!g_batch.upload_stream) HIP_TRY(hipStreamCreateWithFlags(&g_batch.upload_stream, hipStreamNonBlocking));
+	for (int sl = 0; sl < num_slices; ++sl)
+		if (!g_batch.uploaded[sl]) HIP_TRY(hipEventCreateWithFlags(&g_batch.uploaded[sl], hipEventDisableTiming));
 	if (total_tiles > g_batch.status_capacity) {
 		if (g_batch.d_status) (void)hipFree(g_batch.d_status);
 		g_batch.status_capacity = total_tiles + total_tiles / 4 + 1024;
@@ -834,7 +841,7 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 				scratch.resize(pe.bytes);
 				rc = fill_params(st, &ctxs[i], opts ? &opts[i] : nullptr, pe, scratch.data(), dev_block, g_batch.d_status + status_off, first_tile,
 				                 g_batch.d_counts + counts_off[(size_t)i]);
-				if (rc != VVM_OK) { (void)hipStreamSynchronize(g_batch.stream); return rc; }
+				if (rc != VVM_OK) { (void)hipStreamSynchronize(g_batch.upload_stream); (void)hipStreamSynchronize(g_batch.stream); return rc; }
 				st->last_width = pe.instances_per_lane;
 				memcpy(g_batch.host + desc_off, scratch.data(), sizeof(VvmExecDesc));
 				memcpy(g_batch.host + table_off, scratch.data(), pe.bytes);
@@ -848,7 +855,9 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 		fill_us += us(t_slice, now());
 		parameter_bytes += table_off - slice.region_off;
 		if (slice.count == 0) continue;
-		HIP_TRY(hipMemcpyAsync(g_batch.dev + slice.region_off, g_batch.host + slice.region_off, table_off - slice.region_off, hipMemcpyHostToDevice, g_batch.stream));
+		HIP_TRY(hipMemcpyAsync(g_batch.dev + slice.region_off, g_batch.host + slice.region_off, table_off - slice.region_off, hipMemcpyHostToDevice, g_batch.upload_stream));
+		HIP_TRY(hipEventRecord(g_batch.uploaded[sl], g_batch.upload_stream));
+		HIP_TRY(hipStreamWaitEvent(g_batch.stream, g_batch.uploaded[sl], 0));
 		for (size_t g = 0; g < slice.groups.size(); ++g) {
 			const Group& grp = slice.groups[g];
 			if (grp.tiles == 0) continue;
