@@ -704,6 +704,7 @@ struct BatchWorkspace {
 	// before; the kernels' stream waits for the slice's event.  (On one stream every upload sat between two kernels.)
 	hipStream_t upload_stream = nullptr;
 	hipEvent_t uploaded[4] = {};
+	hipEvent_t finished[4] = {};      // per slice, behind its kernels and the read-back of its counts
 	int device = -1;      // the workspace belongs to the device of the first batch (one process drives one GPU)
 };
 BatchWorkspace g_batch;
@@ -780,7 +781,10 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 	if (!g_batch.stream) HIP_TRY(hipStreamCreateWithFlags(&g_batch.stream, hipStreamNonBlocking));
 	if (!g_batch.upload_stream) HIP_TRY(hipStreamCreateWithFlags(&g_batch.upload_stream, hipStreamNonBlocking));
 	for (int sl = 0; sl < num_slices; ++sl)
-		if (!g_batch.uploaded[sl]) HIP_TRY(hipEventCreateWithFlags(&g_batch.uploaded[sl], hipEventDisableTiming));
+		if (!g_batch.uploaded[sl]) {
+			HIP_TRY(hipEventCreateWithFlags(&g_batch.uploaded[sl], hipEventDisableTiming));
+			HIP_TRY(hipEventCreateWithFlags(&g_batch.finished[sl], hipEventDisableTiming));
+		}
 	if (total_tiles > g_batch.status_capacity) {
 		if (g_batch.d_status) (void)hipFree(g_batch.d_status);
 		g_batch.status_capacity = total_tiles + total_tiles / 4 + 1024;
@@ -869,8 +873,12 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 			if (lrc != 0) { (void)hipStreamSynchronize(g_batch.stream); return hip_fail((hipError_t)lrc, "batched kernel launch"); }
 			HIP_TRY(hipMemcpyAsync(&g_batch.h_launch[(size_t)sl * 8 + g], g_batch.d_launch[g], 80, hipMemcpyDeviceToHost, g_batch.stream));
 		}
+		// the slice's counts come back behind its kernels, so that the host can hand them to the contexts while later slices run
+		const size_t c0 = counts_off[(size_t)slice.first];
+		const size_t c1 = slice.first + slice.count < n ? counts_off[(size_t)(slice.first + slice.count)] : total_counts;
+		if (c1 > c0) HIP_TRY(hipMemcpyAsync(g_batch.h_counts + c0, g_batch.d_counts + c0, (c1 - c0) * 4, hipMemcpyDeviceToHost, g_batch.stream));
+		HIP_TRY(hipEventRecord(g_batch.finished[sl], g_batch.stream));
 	}
-	if (total_counts) HIP_TRY(hipMemcpyAsync(g_batch.h_counts, g_batch.d_counts, total_counts * 4, hipMemcpyDeviceToHost, g_batch.stream));
 	for (int i = 0; i < n; ++i) {
 		if (!single[(size_t)i]) continue;
 		vvm_exec_options o = opts ? opts[i] : vvm_exec_options{};
@@ -879,30 +887,36 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 		if (rc != VVM_OK) { (void)hipStreamSynchronize(g_batch.stream); return rc; }
 	}
 	const auto t_enqueued = now();
-	HIP_TRY(hipStreamSynchronize(g_batch.stream));
-	if (report)
-		fprintf(stderr, "vvm batch host phases (us): prepare %.0f  fill %.0f (of %.0f in %d slices, launches in between)  wait %.0f  (%d Execs, %zu parameter bytes)\n",
-		        us(t_begin, t_prepared), fill_us, us(t_prepared, t_enqueued), num_slices, us(t_enqueued, now()), n, parameter_bytes);
-	for (int i = 0; i < n; ++i) {
-		if (single[(size_t)i]) continue;
-		vvm_state* st = ctxs[i].VVMState;
-		const size_t ncounts = std::max<uint32_t>(st->script.max_output_dataset, 1);
-		memcpy(st->h_counts, g_batch.h_counts + counts_off[(size_t)i], ncounts * 4);
-	}
-	for (int sl = 0; sl < num_slices; ++sl)
-		for (size_t g = 0; g < slices[(size_t)sl].groups.size(); ++g)
-			if (slices[(size_t)sl].groups[g].tiles && g_batch.h_launch[(size_t)sl * 8 + g].pad != 0) {
+	double wait_us = 0.0;
+	for (int sl = 0; sl < num_slices; ++sl) {
+		const Slice& slice = slices[(size_t)sl];
+		if (slice.count == 0) continue;
+		const auto t_wait = now();
+		HIP_TRY(hipEventSynchronize(g_batch.finished[sl]));
+		wait_us += us(t_wait, now());
+		for (size_t g = 0; g < slice.groups.size(); ++g)
+			if (slice.groups[g].tiles && g_batch.h_launch[(size_t)sl * 8 + g].pad != 0) {
+				(void)hipStreamSynchronize(g_batch.stream);
 				for (size_t k = 0; k < 8; ++k) if (g_batch.d_launch[k]) (void)reset_launch_state(g_batch.d_launch[k]);
 				(void)hipMemset(g_batch.d_status, 0, (size_t)g_batch.status_capacity * 8);
 				return fail(VVM_E_HIP, "look-back timed out inside the batched kernel");
 			}
-	for (int i = 0; i < n; ++i) {
-		if (single[(size_t)i]) {
-			rc = vvm_exec_finish(&ctxs[i]);
-			if (rc != VVM_OK) return rc;
-		} else {
-			write_back_counts(ctxs[i].VVMState, &ctxs[i], ctxs[i].NumInstances > 0);
+		for (int i = slice.first; i < slice.first + slice.count; ++i) {
+			if (single[(size_t)i]) continue;
+			vvm_state* st = ctxs[i].VVMState;
+			const size_t ncounts = std::max<uint32_t>(st->script.max_output_dataset, 1);
+			memcpy(st->h_counts, g_batch.h_counts + counts_off[(size_t)i], ncounts * 4);
+			write_back_counts(st, &ctxs[i], ctxs[i].NumInstances > 0);
 		}
+	}
+	HIP_TRY(hipStreamSynchronize(g_batch.stream));      // (the Execs that took launches of their own)
+	if (report)
+		fprintf(stderr, "vvm batch host phases (us): prepare %.0f  fill %.0f (of %.0f in %d slices, launches in between)  wait %.0f, write-back %.0f  (%d Execs, %zu parameter bytes)\n",
+		        us(t_begin, t_prepared), fill_us, us(t_prepared, t_enqueued), num_slices, wait_us, us(t_enqueued, now()) - wait_us, n, parameter_bytes);
+	for (int i = 0; i < n; ++i) {
+		if (!single[(size_t)i]) continue;
+		rc = vvm_exec_finish(&ctxs[i]);
+		if (rc != VVM_OK) return rc;
 	}
 	return VVM_OK;
 }
