@@ -127,6 +127,7 @@ struct vvm_state {
 	unsigned long long* d_status = nullptr;
 	uint32_t status_capacity = 0;          // tiles
 	int32_t* d_counts = nullptr;
+	bool counts_in_launch = false;         // d_counts lies in the spare words of *d_launch: counts and launch words come back in one copy
 	int32_t* h_counts = nullptr;           // pinned: counts, then the launch error word
 	ParamRing ring;
 	hipStream_t stream = nullptr;
@@ -503,8 +504,14 @@ VVM_API vvm_state* vvm_alloc_state(const uint8_t* blob, size_t num_bytes)
 	if ((e = hipMalloc((void**)&st->d_launch, sizeof(VvmLaunchState))) != hipSuccess) return bail(e, "hipMalloc(launch state)");
 	if ((e = reset_launch_state(st->d_launch)) != hipSuccess) return bail(e, "reset(launch state)");
 	const size_t ncounts = std::max<uint32_t>(st->script.max_output_dataset, 1) + 4;
-	if ((e = hipMalloc((void**)&st->d_counts, ncounts * 4)) != hipSuccess) return bail(e, "hipMalloc(counts)");
-	if ((e = hipMemset(st->d_counts, 0, ncounts * 4)) != hipSuccess) return bail(e, "hipMemset(counts)");
+	if (ncounts * 4 <= sizeof(((VvmLaunchState*)nullptr)->reserved)) {
+		// (a synchronous Exec of a small emitter is bound by the round trips of the call: one copy back instead of two is 4 of 25 us)
+		st->d_counts = (int32_t*)((uint8_t*)st->d_launch + offsetof(VvmLaunchState, reserved));      // zeroed with the launch words
+		st->counts_in_launch = true;
+	} else {
+		if ((e = hipMalloc((void**)&st->d_counts, ncounts * 4)) != hipSuccess) return bail(e, "hipMalloc(counts)");
+		if ((e = hipMemset(st->d_counts, 0, ncounts * 4)) != hipSuccess) return bail(e, "hipMemset(counts)");
+	}
 	if ((e = hipHostMalloc((void**)&st->h_counts, ncounts * 4 + sizeof(VvmLaunchState), hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc(counts)");
 	memset(st->h_counts, 0, ncounts * 4 + sizeof(VvmLaunchState));
 	if ((e = hipStreamCreateWithFlags(&st->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
@@ -524,7 +531,7 @@ VVM_API void vvm_free_state(vvm_state* st)
 	if (st->d_perlin) (void)hipFree(st->d_perlin);
 	if (st->d_launch) (void)hipFree(st->d_launch);
 	if (st->d_status) (void)hipFree(st->d_status);
-	if (st->d_counts) (void)hipFree(st->d_counts);
+	if (st->d_counts && !st->counts_in_launch) (void)hipFree(st->d_counts);
 	if (st->d_chunk_prefix) (void)hipFree(st->d_chunk_prefix);
 	if (st->d_id_scratch) (void)hipFree(st->d_id_scratch);
 	if (st->h_counts) (void)hipHostFree(st->h_counts);
@@ -641,12 +648,18 @@ VVM_API int vvm_exec_finish(vvm_exec_context* ctx)
 	vvm_state* st = ctx->VVMState;
 	const bool ran = ctx->NumInstances > 0;
 	if (st->last_stream) {
-		if (st->results_pending) {
-			const size_t nc = std::max<uint32_t>(st->script.max_output_dataset, 1);
-			HIP_TRY(hipMemcpyAsync(st->h_counts, st->d_counts, (nc + 1) * 4, hipMemcpyDeviceToHost, st->last_stream));     // (and the MaxUsedID word)
-			HIP_TRY(hipMemcpyAsync(st->h_counts + nc + 4, st->d_launch, 80, hipMemcpyDeviceToHost, st->last_stream));     // the words up to and including stats[]
+		const size_t nc = std::max<uint32_t>(st->script.max_output_dataset, 1);
+		const bool pending = st->results_pending;
+		if (pending) {
+			if (st->counts_in_launch) {      // the launch words up to and including stats[], then the counts and the MaxUsedID word behind them
+				HIP_TRY(hipMemcpyAsync(st->h_counts + nc + 4, st->d_launch, offsetof(VvmLaunchState, reserved) + (nc + 1) * 4, hipMemcpyDeviceToHost, st->last_stream));
+			} else {
+				HIP_TRY(hipMemcpyAsync(st->h_counts, st->d_counts, (nc + 1) * 4, hipMemcpyDeviceToHost, st->last_stream));     // (and the MaxUsedID word)
+				HIP_TRY(hipMemcpyAsync(st->h_counts + nc + 4, st->d_launch, 80, hipMemcpyDeviceToHost, st->last_stream));     // the words up to and including stats[]
+			}
 		}
 		HIP_TRY(hipStreamSynchronize(st->last_stream));
+		if (pending && st->counts_in_launch) memcpy(st->h_counts, (const uint8_t*)(st->h_counts + nc + 4) + offsetof(VvmLaunchState, reserved), (nc + 1) * 4);
 	}
 	st->results_pending = false;
 	st->in_flight = false;
