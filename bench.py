@@ -7,9 +7,9 @@ A step is one Exec of the fountain update script (8 float32 streams in, 8 out, k
 batch of synthetic particles that is already resident in HBM.  At N = 1 the batch is 64 Mi particles
 (BASELINE.json configs[1]); at N > 1 every rank runs the same-sized shard of a larger emitter (weak scaling), with
 exec_index / random streams based at the shard's first global instance, and every step ends with the all-gather
-of the per-rank survivor counts (RCCL) from which each rank's global acquireindex offset follows.  The all-gather
-runs on a stream of its own behind the copy of the count, so the next step's Exec (which needs only the local
-count) does not wait for the other ranks.
+of the per-rank survivor counts (RCCL) from which each rank's global acquireindex offset follows.  The Exec leaves
+its count in the buffer the all-gather reads (vvm_exec_options.DeviceCounts), and the all-gather runs on a stream
+of its own, so the next step's Exec (which needs only the local count) does not wait for the other ranks.
 
 Rank 0 prints ONE JSON line.  `roofline` prices the interpreter kernel against HBM: algorithmic bytes per launch
 (4 bytes x (input streams x instances + output streams x survivors)) over the kernel's mean duration, which is
@@ -178,9 +178,10 @@ def main():
     torch_stream = torch.cuda.Stream(device=dev)
     stream = torch_stream.cuda_stream
     flags = {"auto": 0, "4": abi.VVM_EXEC_NO_EIGHT_WIDE, "8": abi.VVM_EXEC_FORCE_EIGHT_WIDE}[args.width]
-    opt = abi.ExecOptions(0, first if first < 2 ** 31 else 0, first if first < 2 ** 31 else 0, stream, flags)
-    # The exchange of a step runs beside the next step's Exec: the count is copied on the Exec's stream, the all-gather waits for
-    # that copy on a stream of its own.  Two sets of buffers alternate; a set is written again only after the all-gather that read
+    base = first if first < 2 ** 31 else 0
+    opt = abi.ExecOptions(0, base, base, stream, flags)
+    # The exchange of a step runs beside the next step's Exec: the Exec writes its count into the step's buffer, the all-gather waits
+    # for the Exec on a stream of its own.  Two sets of buffers alternate; a set is written again only after the all-gather that read
     # it two steps earlier has finished (an event the Exec's stream waits for, long past by then).
     coll_stream = torch.cuda.Stream(device=dev)
     counts_dev = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(2)]
@@ -189,16 +190,20 @@ def main():
     exchanged = [torch.cuda.Event() for _ in range(2)]
     steps_done = [0]
 
+    # (the Exec leaves its survivor count in the buffer the all-gather reads: vvm_exec_options.DeviceCounts, no copy in between)
+    opts = [abi.ExecOptions(0, base, base, stream, flags, counts_dev[k].data_ptr()) for k in range(2)]
+
     def step():
         k = steps_done[0] & 1
         steps_done[0] += 1
         with torch.cuda.stream(torch_stream):
-            state.exec_async(frame, opt)
             if distributed:
                 # the path's one exchange: every rank's survivor count, for the global acquireindex offsets
                 torch_stream.wait_event(exchanged[k])
-                state.copy_counts(counts_dev[k].data_ptr(), stream)
+                state.exec_async(frame, opts[k])
                 counted[k].record(torch_stream)
+            else:
+                state.exec_async(frame, opt)
         if distributed:
             if args.backend == "nccl":
                 with torch.cuda.stream(coll_stream):

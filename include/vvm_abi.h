@@ -197,6 +197,10 @@ typedef struct vvm_exec_options {
 	int32_t  RandInstanceBase;  /* added to the instance index that keys the generator (shard-invariant streams) */
 	void*    Stream;            /* hipStream_t to enqueue on; NULL = the state's own stream */
 	uint32_t Flags;             /* VVM_EXEC_* */
+	int32_t* DeviceCounts;      /* device memory, MaxOutputDataSet ints, or NULL: where the Exec leaves the survivor count of every
+	                             * dataset it runs acquireindex for, instead of the state's own words (vvm_state_device_counts). For
+	                             * callers that hand the counts on device-side (the multi-GPU all-gather) without a copy in between.
+	                             * Ignored for scripts with ID instructions and by vvm_exec_batch. */
 } vvm_exec_options;
 
 enum {

@@ -109,7 +109,7 @@ class ExecContext(C.Structure):
 
 class ExecOptions(C.Structure):
     _fields_ = [("RandSeed", C.c_uint64), ("ExecIndexBase", C.c_int32), ("RandInstanceBase", C.c_int32),
-                ("Stream", C.c_void_p), ("Flags", C.c_uint32)]
+                ("Stream", C.c_void_p), ("Flags", C.c_uint32), ("DeviceCounts", C.c_void_p)]
 
 
 class ProgramInfo(C.Structure):

@@ -127,6 +127,8 @@ struct vvm_state {
 	unsigned long long* d_status = nullptr;
 	uint32_t status_capacity = 0;          // tiles
 	int32_t* d_counts = nullptr;
+	int32_t* counts_src = nullptr;         // where the last Exec left its counts: d_counts, or the caller's vvm_exec_options::DeviceCounts
+	bool any_ids = false;                  // some pass of the script has update_id / acquire_id
 	bool counts_in_launch = false;         // d_counts lies in the spare words of *d_launch: counts and launch words come back in one copy
 	int32_t* h_counts = nullptr;           // pinned: counts, then the launch error word
 	ParamRing ring;
@@ -357,7 +359,7 @@ int fill_params(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* op
 	d->out_list = (const uint64_t*)(dev + pe.off_out);
 	if (!dev_block && lp.uses_ids) return fail(VVM_E_INVALID_ARG, "internal: a script with ID instructions needs its parameter block in device memory");
 	d->status = d_status;
-	d->counts = d_counts ? d_counts : st->d_counts;
+	d->counts = d_counts ? d_counts : (opt && opt->DeviceCounts && !st->any_ids) ? opt->DeviceCounts : st->d_counts;
 	if (lp.uses_perlin && !st->d_perlin) return fail(VVM_E_INVALID_ARG, "internal: the noise table of this state was not uploaded");
 	d->perlin = st->d_perlin;
 	d->num_instances = (uint32_t)ctx->NumInstances;
@@ -495,6 +497,8 @@ VVM_API vvm_state* vvm_alloc_state(const uint8_t* blob, size_t num_bytes)
 	if (upload_code(st->wide, &st->d_code_wide) != VVM_OK) { vvm_free_state(st); return nullptr; }
 	if (link_more_passes(st->script, false, st->wide, st->wide_more, st->d_code_wide_more) != VVM_OK) { vvm_free_state(st); return nullptr; }
 	hipError_t e;
+	st->any_ids = st->wide.uses_ids;
+	for (const vvm::LinkedProgram& more : st->wide_more) st->any_ids = st->any_ids || more.uses_ids;
 	bool any_perlin = st->wide.uses_perlin;      // (a pass links only what its dataset needs: any of them may be the one with the noise call)
 	for (const vvm::LinkedProgram& more : st->wide_more) any_perlin = any_perlin || more.uses_perlin;
 	if (any_perlin) {
@@ -558,8 +562,11 @@ VVM_API int vvm_exec_async(vvm_exec_context* ctx, const vvm_exec_options* opt)
 	st->last_stream = stream;
 	st->in_flight = true;
 	st->last_width = pe.instances_per_lane;
+	int32_t* const caller_counts = (opt && opt->DeviceCounts && !st->any_ids) ? opt->DeviceCounts : nullptr;
+	st->counts_src = caller_counts ? caller_counts : st->d_counts;
 	if (pe.tiles == 0) {     // nothing to run: zero chunks in the reference too (RT.cpp:2277)
 		if (st->results_pending) { HIP_TRY(hipStreamSynchronize(stream)); st->results_pending = false; }
+		if (caller_counts) HIP_TRY(hipMemsetAsync(caller_counts, 0, 4 * (size_t)std::max<uint32_t>(st->script.max_output_dataset, 1), stream));
 		st->h_counts[0] = 0;
 		for (uint32_t i = 0; i < st->script.max_output_dataset; ++i) st->h_counts[i] = 0;
 		return VVM_OK;
@@ -651,7 +658,10 @@ VVM_API int vvm_exec_finish(vvm_exec_context* ctx)
 		const size_t nc = std::max<uint32_t>(st->script.max_output_dataset, 1);
 		const bool pending = st->results_pending;
 		if (pending) {
-			if (st->counts_in_launch) {      // the launch words up to and including stats[], then the counts and the MaxUsedID word behind them
+			if (st->counts_src && st->counts_src != st->d_counts) {      // counts left with the caller
+				HIP_TRY(hipMemcpyAsync(st->h_counts, st->counts_src, nc * 4, hipMemcpyDeviceToHost, st->last_stream));
+				HIP_TRY(hipMemcpyAsync(st->h_counts + nc + 4, st->d_launch, 80, hipMemcpyDeviceToHost, st->last_stream));
+			} else if (st->counts_in_launch) {      // the launch words up to and including stats[], then the counts and the MaxUsedID word behind them
 				HIP_TRY(hipMemcpyAsync(st->h_counts + nc + 4, st->d_launch, offsetof(VvmLaunchState, reserved) + (nc + 1) * 4, hipMemcpyDeviceToHost, st->last_stream));
 			} else {
 				HIP_TRY(hipMemcpyAsync(st->h_counts, st->d_counts, (nc + 1) * 4, hipMemcpyDeviceToHost, st->last_stream));     // (and the MaxUsedID word)
@@ -659,7 +669,7 @@ VVM_API int vvm_exec_finish(vvm_exec_context* ctx)
 			}
 		}
 		HIP_TRY(hipStreamSynchronize(st->last_stream));
-		if (pending && st->counts_in_launch) memcpy(st->h_counts, (const uint8_t*)(st->h_counts + nc + 4) + offsetof(VvmLaunchState, reserved), (nc + 1) * 4);
+		if (pending && st->counts_in_launch && !(st->counts_src && st->counts_src != st->d_counts)) memcpy(st->h_counts, (const uint8_t*)(st->h_counts + nc + 4) + offsetof(VvmLaunchState, reserved), (nc + 1) * 4);
 	}
 	st->results_pending = false;
 	st->in_flight = false;
@@ -896,6 +906,7 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 		if (!single[(size_t)i]) continue;
 		vvm_exec_options o = opts ? opts[i] : vvm_exec_options{};
 		o.Stream = g_batch.stream;
+		o.DeviceCounts = nullptr;      // (a batch keeps every Exec's counts in its own array)
 		rc = vvm_exec_async(&ctxs[i], &o);
 		if (rc != VVM_OK) { (void)hipStreamSynchronize(g_batch.stream); return rc; }
 	}

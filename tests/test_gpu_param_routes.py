@@ -41,3 +41,18 @@ def test_transcendental_both_routes():
     mem, mem_n, _ = run_hip(w.script, [w.constants], ins, [f32] * 4, n, ext_fns=w.ext_fns, flags=IN_MEMORY)
     assert arg_n == mem_n == n
     _same(arg, mem, arg_n)
+
+
+@pytest.mark.parametrize("n", [0, 1, 4099, 300_000])
+@pytest.mark.parametrize("kill_half", [False, True])
+def test_counts_left_in_the_callers_device_buffer(n, kill_half):
+    """vvm_exec_options.DeviceCounts: the Exec writes the survivor count there (what the multi-GPU all-gather reads), the call
+    still reports it through the context, and the streams are the same as without."""
+    w = scripts.fountain()
+    ins = scripts.fountain_streams_np(0, max(n, 1), age_fraction=0.5, kill_half=kill_half)
+    plain, plain_n, _ = run_hip(w.script, [w.constants], ins, [f32] * 8, n)
+    counts = []
+    got, got_n, _ = run_hip(w.script, [w.constants], ins, [f32] * 8, n, device_counts=counts, repeat=2)
+    assert got_n == plain_n
+    assert counts[0] == plain_n and all(c == -1 for c in counts[1:])
+    _same(got, plain, got_n)

@@ -88,9 +88,11 @@ def run_hip(script: BuiltScript, const_tables: Sequence[bytes], inputs: Sequence
             seed: int = 0, exec_index_base: int = 0, rand_instance_base: int = 0, flags: int = 0,
             out_fill: int = 0xCD, repeat: int = 1, ids: Optional[IdState] = None, page_kb: int = 64,
             more_datasets: Sequence[Sequence] = (), more_results: Optional[list] = None,
-            batch_with: Optional[Sequence] = None) -> Tuple[List[np.ndarray], int, abi.ProgramInfo]:
+            batch_with: Optional[Sequence] = None, device_counts: Optional[list] = None) -> Tuple[List[np.ndarray], int, abi.ProgramInfo]:
     """Same contract as run_oracle, through the C ABI of libvvm_hip.so with streams in device memory.
-    batch_with: call frames of other emitters; the Exec then runs as the middle member of one vvm_exec_batch call with them."""
+    batch_with: call frames of other emitters; the Exec then runs as the middle member of one vvm_exec_batch call with them.
+    device_counts: a list; the Exec gets a buffer of eight ints (filled with -1) as vvm_exec_options.DeviceCounts, whose contents
+    after the Exec are appended to the list."""
     be = abi.load_hip_backend()
     L = be.lib
     total = instance_offset + n + PAD
@@ -137,6 +139,12 @@ def run_hip(script: BuiltScript, const_tables: Sequence[bytes], inputs: Sequence
         try:
             frame = abi.CallFrame(state, [ds] + more_ds, n, const_tables, ext_fns)
             opt = abi.ExecOptions(seed, exec_index_base, rand_instance_base, None, flags)
+            if device_counts is not None:
+                p = L.vvm_device_alloc(32)
+                assert p, be.error_text()
+                dev_ids.append(p)
+                be._check(L.vvm_device_memset(p, 0xFF, 32), "memset")
+                opt.DeviceCounts = p
             for _ in range(repeat):
                 if batch_with is None:
                     be.exec_ex(frame, opt)
@@ -147,6 +155,10 @@ def run_hip(script: BuiltScript, const_tables: Sequence[bytes], inputs: Sequence
                     be.exec_batch(others[:half] + [frame] + others[half:], [plain] * half + [opt] + [plain] * (len(others) - half))
             surv = frame.survivors(0)
             info = be.info(state)
+            if device_counts is not None:
+                h = np.empty(8, dtype=np.int32)
+                be._check(L.vvm_device_download(h.ctypes.data, opt.DeviceCounts, h.nbytes), "download")
+                device_counts.extend(int(v) for v in h)
             if more_results is not None:
                 for i, (ptrs, dts) in enumerate(zip(more_dev, more_datasets)):
                     hs = []
