@@ -1593,7 +1593,7 @@ extern "C" int vvm_launch_exec_kernel(int instances_per_lane, const VvmExecDesc*
                                       VvmLaunchState* ls, int many_registers, uint32_t lds_spill_slots, int full, uint32_t grid, hipStream_t stream,
                                       const void* inline_block, uint32_t inline_bytes)
 {
-	KernelEnv env;
+	KernelEnv env = {};      // (the unused part of the block travels too: no indeterminate bytes in the kernel arguments)
 	if (inline_block) {
 		if (descs || num_execs != 1 || inline_bytes > VVM_INLINE_PARAM_BYTES) return (int)hipErrorInvalidValue;
 		memcpy(env.block, inline_block, inline_bytes);
