@@ -138,5 +138,6 @@ struct VvmLaunchState {
 };
 
 // look-back word: tag[34:64) | flag[32:34) | value[0:32)
+#define VVM_MAX_LAUNCH_TAG 0x3FFFFFFFu
 #define VVM_LB_AGGREGATE 1ull
 #define VVM_LB_INCLUSIVE 2ull

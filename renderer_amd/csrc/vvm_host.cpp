@@ -631,7 +631,7 @@ VVM_API int vvm_exec_async(vvm_exec_context* ctx, const vvm_exec_options* opt)
 		const int lrc = vvm_launch_exec_kernel((int)pe.instances_per_lane, inline_block ? nullptr : (const VvmExecDesc*)st->ring.dev[slot], 1, pe.tiles, st->d_launch,
 		                                       pe.lp->many_registers ? 1 : 0, pe.lp->lds_spill_slots, pe.lp->full_kernel ? 1 : 0,
 		                                       grid_for(pe.tiles, pe.instances_per_lane, pe.lp->full_kernel, pe.lp->many_registers), stream,
-		                                       inline_block ? local_block : nullptr, inline_block ? (uint32_t)pe.bytes : 0u);
+		                                       inline_block ? local_block : nullptr, inline_block ? (uint32_t)pe.bytes : 0u, 0u);
 		if (lrc != 0) return hip_fail((hipError_t)lrc, "kernel launch");
 		if (timed && pass + 1 == num_passes) { HIP_TRY(hipEventRecord(st->ev_stop[st->ev_used], stream)); st->ev_used++; }
 		if (pe.lp->uses_ids && pe.lp->updates_ids) {
@@ -722,6 +722,12 @@ struct BatchWorkspace {
 	int32_t* d_counts = nullptr; int32_t* h_counts = nullptr; size_t counts_capacity = 0;   // survivor counts of all Execs of a batch
 	VvmLaunchState* d_launch[8] = {};
 	VvmLaunchState* h_launch = nullptr;
+	// Every launch of a batch tags its look-back words with a number drawn from this counter.  The launches share d_status, at
+	// offsets that move from call to call, through one set of launch words per kernel shape: with each set counting its own
+	// epochs, a word written through one set could carry the tag another set reaches later, and a tile that polls before its
+	// predecessor has published would take that stale count.  One counter per array rules it out: a tag is never used twice
+	// between two clears of the array.
+	uint32_t next_tag = 1;
 	hipStream_t stream = nullptr;
 	// The parameter blocks of a slice are uploaded on a stream of their own, so that the copy runs beside the kernels of the slice
 	// before; the kernels' stream waits for the slice's event.  (On one stream every upload sat between two kernels.)
@@ -890,9 +896,14 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 			if (grp.tiles == 0) continue;
 			const PreparedExec& pe0 = pes[(size_t)grp.members[0]];
 			const vvm::LinkedProgram& lp = *pe0.lp;
+			if (g_batch.next_tag > VVM_MAX_LAUNCH_TAG) {      // the tags start over: behind the launches so far, no word may keep an old one
+				HIP_TRY(hipMemsetAsync(g_batch.d_status, 0, (size_t)g_batch.status_capacity * 8, g_batch.stream));
+				g_batch.next_tag = 1;
+			}
+			const uint32_t launch_tag = g_batch.next_tag++;
 			const int lrc = vvm_launch_exec_kernel((int)pe0.instances_per_lane, (const VvmExecDesc*)(g_batch.dev + grp.desc_off), (uint32_t)grp.members.size(), grp.tiles,
 			                                       g_batch.d_launch[g], lp.many_registers ? 1 : 0, grp.spill, lp.full_kernel ? 1 : 0,
-			                                       grid_for(grp.tiles, pe0.instances_per_lane, lp.full_kernel, lp.many_registers), g_batch.stream, nullptr, 0);
+			                                       grid_for(grp.tiles, pe0.instances_per_lane, lp.full_kernel, lp.many_registers), g_batch.stream, nullptr, 0, launch_tag);
 			if (lrc != 0) { (void)hipStreamSynchronize(g_batch.stream); return hip_fail((hipError_t)lrc, "batched kernel launch"); }
 			HIP_TRY(hipMemcpyAsync(&g_batch.h_launch[(size_t)sl * 8 + g], g_batch.d_launch[g], 80, hipMemcpyDeviceToHost, g_batch.stream));
 		}

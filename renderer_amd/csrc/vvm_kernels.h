@@ -10,9 +10,11 @@ extern "C" {
 // kernels that also implement the transcendental ops, the noise built-ins and the ID instructions.
 // A launch of one Exec may hand its parameter block over as a kernel argument instead: descs = null, inline_block = the block
 // as filled on the host with VVM_DESC_RELATIVE set, inline_bytes <= VVM_INLINE_PARAM_BYTES (copied before the call returns).
+// tag: 0 = the look-back words of this launch are tagged with the epoch kept in `ls`; otherwise the tag itself, 1..VVM_MAX_LAUNCH_TAG
+// (for launches that share one array of look-back words through several sets of launch words).
 int vvm_launch_exec_kernel(int instances_per_lane, const VvmExecDesc* descs, uint32_t num_execs, uint32_t total_tiles,
                            VvmLaunchState* ls, int many_registers, uint32_t lds_spill_slots, int full, uint32_t grid, hipStream_t stream,
-                           const void* inline_block, uint32_t inline_bytes);
+                           const void* inline_block, uint32_t inline_bytes, uint32_t tag);
 // update_id's MaxUsedID pass over an Exec that has run (same stream).
 int vvm_launch_max_id_kernel(const VvmIdDesc* ids, uint32_t num_chunks, hipStream_t stream);
 int vvm_kernel_max_dynamic_lds(void);

@@ -737,6 +737,10 @@ template <int HALVES> DEV uint3 acquire_rank_and_publish(uint32_t keep_bits, con
 	const uint32_t total0 = SCALAR(total[0]);
 	const uint32_t all = (HALVES == 2) ? total0 + SCALAR(total[1]) : total0;
 	if (c.wave == 0 && !(tile_local == 0 && (dbg & 4u))) {
+		// test hook (debug instantiations only): odd tiles publish their count about 50 us late, so that the tiles behind them
+		// poll words that this launch has not written yet and a word left by an earlier launch would be taken if its tag matched
+		if ((dbg & 1024u) && (tile_local & 1u))
+			for (int i = 0; i < 16; ++i) __builtin_amdgcn_s_sleep(127);
 		// the first tile's count is its inclusive prefix already
 		const u64 flag = (tile_local == 0) ? VVM_LB_INCLUSIVE : VVM_LB_AGGREGATE;
 		store_u64_first_lane(status + tile_local, ((u64)tag << 34) | (flag << 32) | all, lane);
@@ -955,7 +959,13 @@ struct KernelEnv {
 	uint32_t total_tiles;
 	VvmLaunchState* ls;
 	uint32_t lds_spill_slots;
-	uint32_t debug_skip;     // bring-up aid (VVM_DEBUG_SKIP): bit 0 tiles, 1 stream loads, 2 tile-0 look-back word, 3 stream stores, 4 counts, 5 look-back (assume no deaths)
+	uint32_t debug_skip;     // bring-up aid (VVM_DEBUG_SKIP): bit 0 tiles, 1 stream loads, 2 tile-0 look-back word, 3 stream stores, 4 counts, 5 look-back (assume no deaths),
+	                         // bit 10: odd tiles publish their count late (test hook)
+	// Tag that makes a look-back word valid for this launch.  0: the epoch word of `ls`, which advances with every launch made
+	// through these launch words (a state's launches: its look-back words are only ever written through its own launch words).
+	// Launches that share one array of look-back words but not one set of launch words (a batch) get their tags from the
+	// host, one counter per array, so that no word written earlier can carry the tag of a later launch.
+	uint32_t tag;
 	// A single Exec's parameter block (descriptor and tables, VVM_DESC_RELATIVE) rides in the kernel-argument segment: no
 	// host-to-device copy ahead of the launch (a copy is a launch of its own on the stream, and cost more than half of the
 	// 13 us between two Execs).  The kernel never names this member; it reads the segment through scalar loads.
@@ -1454,7 +1464,7 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (V == 8 || (V == 4 && SPILL
 	// gridDim.x counters are in use
 	const uint32_t classes = min(gridDim.x, VVM_TICKET_CLASSES);
 	const uint32_t cls = blockIdx.x % classes;
-	const uint32_t tag = SCALAR(__hip_atomic_load((gu32*)&env.ls->epoch, RLX_AGENT)) & 0x3FFFFFFFu;
+	const uint32_t tag = env.tag ? env.tag : (SCALAR(__hip_atomic_load((gu32*)&env.ls->epoch, RLX_AGENT)) & 0x3FFFFFFFu);
 	bool perlin_ready = false;
 	uint32_t resolves = 0;
 	// (where the descriptors are, and what the table fields of a descriptor are relative to, see KernelEnv::block: per tile, below)
@@ -1553,9 +1563,11 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (V == 8 || (V == 4 && SPILL
 			}
 		const uint32_t n = fetch_add_first_lane((gu32*)&env.ls->done, 1u, lane);
 		if (n + 1 == gridDim.x) {      // (every lane of the wave stores the same values)
-			uint32_t next = (tag + 1u) & 0x3FFFFFFFu;
-			if (next == 0) next = 1;
-			__hip_atomic_store((gu32*)&env.ls->epoch, next, RLX_AGENT);
+			if (!env.tag) {
+				uint32_t next = (tag + 1u) & 0x3FFFFFFFu;
+				if (next == 0) next = 1;
+				__hip_atomic_store((gu32*)&env.ls->epoch, next, RLX_AGENT);
+			}
 			__hip_atomic_store((gu32*)&env.ls->done, 0u, RLX_AGENT);
 			for (uint32_t x = 0; x < VVM_TICKET_CLASSES; ++x)
 				__hip_atomic_store((gu32*)&env.ls->tickets[x * (VVM_TICKET_STRIDE_BYTES / 4u)], 0u, RLX_AGENT);
@@ -1591,8 +1603,9 @@ extern "C" int vvm_launch_max_id_kernel(const VvmIdDesc* idp, uint32_t num_chunk
 // ---- host-callable launcher --------------------------------------------------------------------------
 extern "C" int vvm_launch_exec_kernel(int instances_per_lane, const VvmExecDesc* descs, uint32_t num_execs, uint32_t total_tiles,
                                       VvmLaunchState* ls, int many_registers, uint32_t lds_spill_slots, int full, uint32_t grid, hipStream_t stream,
-                                      const void* inline_block, uint32_t inline_bytes)
+                                      const void* inline_block, uint32_t inline_bytes, uint32_t tag)
 {
+	if (tag > VVM_MAX_LAUNCH_TAG) return (int)hipErrorInvalidValue;
 	KernelEnv env = {};      // (the unused part of the block travels too: no indeterminate bytes in the kernel arguments)
 	if (inline_block) {
 		if (descs || num_execs != 1 || inline_bytes > VVM_INLINE_PARAM_BYTES) return (int)hipErrorInvalidValue;
@@ -1600,7 +1613,7 @@ extern "C" int vvm_launch_exec_kernel(int instances_per_lane, const VvmExecDesc*
 	} else if (!descs) {
 		return (int)hipErrorInvalidValue;
 	}
-	env.descs = descs; env.num_execs = num_execs; env.total_tiles = total_tiles; env.ls = ls; env.lds_spill_slots = lds_spill_slots;
+	env.descs = descs; env.num_execs = num_execs; env.total_tiles = total_tiles; env.ls = ls; env.lds_spill_slots = lds_spill_slots; env.tag = tag;
 	{ const char* dbg = getenv("VVM_DEBUG_SKIP"); env.debug_skip = dbg ? (uint32_t)strtoul(dbg, nullptr, 0) : 0u; }
 	const size_t lds_bytes = (instances_per_lane == 8 ? LDS_SPILL_OFF(8, full != 0) : instances_per_lane == 4 ? LDS_SPILL_OFF(4, full != 0) : LDS_SPILL_OFF(1, full != 0)) +
 	                         (size_t)lds_spill_slots * VVM_BLOCK_THREADS * 4u * (size_t)instances_per_lane;
