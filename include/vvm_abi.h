@@ -236,9 +236,26 @@ VVM_API int vvm_exec_ex(vvm_exec_context* ctx, const vvm_exec_options* opt);
 /* Enqueue-only form of vvm_exec_ex and its completion. Between the two calls the context, its dataset
  * array and the state must stay alive and untouched. vvm_exec_finish blocks on the stream, then writes
  * DataSetAccessIndex. Several vvm_exec_async calls on one state may be queued before one finish; the
- * finish reports the counts of the LAST one. */
+ * finish reports the counts of the LAST one.  Scripts with update_id / acquire_id are the exception: the
+ * dataset's NumFreeIDs / MaxUsedID / NumSpawnedIDs are host words read at enqueue and written by the
+ * finish, so a second vvm_exec_async before the finish returns VVM_E_INVALID_ARG. */
 VVM_API int vvm_exec_async(vvm_exec_context* ctx, const vvm_exec_options* opt);
 VVM_API int vvm_exec_finish(vvm_exec_context* ctx);
+
+/* vvm_exec_ex for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc): same arguments, same results, but the call makes no hipMalloc / hipFree / hipHostMalloc and creates no stream
+ * or event.  The launch words, survivor counts and look-back words of the Exec live in an array that is part of the library's
+ * code object (1 MiB + 4.25 KiB per device, held from the library's first use on that device until the process ends) instead
+ * of in buffers sized per Exec.  Limits, each refused with a message (vvm_last_error):
+ *   - at most 131072 tiles: 128 Mi instances at four instances per lane, 256 Mi at eight (VVM_E_TOO_LARGE);
+ *   - the script's parameter block (constants, stream addresses) fits the 1 KB that travels as a kernel argument: about
+ *     40 streams and constants together (VVM_E_TOO_LARGE);
+ *   - no update_id / acquire_id (their scratch is sized per Exec), no VVM_EXEC_NO_VGPR_WIDE before a vvm_exec_ex has used it on
+ *     the state (VVM_E_UNSUPPORTED_OP).
+ * Every call on a device shares that device's array: calls that overlap in time on one device (two threads, or a queued
+ * vvm_exec_async of any state that also used this entry point) race; the call is synchronous, so calls from one thread never do.
+ * No counterpart in the reference, whose Exec mallocs its batch memory on every call (VectorVMRuntime.cpp:2268, 2302). */
+VVM_API int vvm_exec_noalloc(vvm_exec_context* ctx, const vvm_exec_options* opt);
 
 /* Many independent Execs (one state each, e.g. one per emitter) in one call: one kernel launch per kernel shape (a batch of 1024
  * Execs or more is cut into up to four slices that are filled and launched one after the other, so that filling the parameter
@@ -247,9 +264,10 @@ VVM_API int vvm_exec_finish(vvm_exec_context* ctx);
  * array of n.  No counterpart in the reference, which runs one Exec per call (VectorVMRuntime.cpp:2182). */
 VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_options* opts);
 
-/* Device pointer (int32[MaxOutputDataSet]) to the survivor counts of the last Exec of this state;
- * valid after the Exec's kernel has run on its stream. Lets a multi-GPU caller all-gather the
- * counts without a host round trip. */
+/* Device pointer (int32[MaxOutputDataSet]) to the survivor counts of the last vvm_exec* call made on this state
+ * (the caller's vvm_exec_options.DeviceCounts when that was given); valid after the Exec's kernel has run on its
+ * stream. Lets a multi-GPU caller all-gather the counts without a host round trip.  After vvm_exec_batch the counts of
+ * the batch's Execs are only in the contexts (DataSetAccessIndex): this pointer then still names an earlier Exec's. */
 VVM_API const int32_t* vvm_state_device_counts(const vvm_state* state);
 VVM_API int32_t        vvm_state_max_output_dataset(const vvm_state* state);
 

@@ -256,6 +256,8 @@ class HipBackend(Backend):
         L = lib
         L.vvm_exec_ex.restype = C.c_int
         L.vvm_exec_ex.argtypes = [C.POINTER(ExecContext), C.POINTER(ExecOptions)]
+        L.vvm_exec_noalloc.restype = C.c_int
+        L.vvm_exec_noalloc.argtypes = [C.POINTER(ExecContext), C.POINTER(ExecOptions)]
         L.vvm_exec_async.restype = C.c_int
         L.vvm_exec_async.argtypes = [C.POINTER(ExecContext), C.POINTER(ExecOptions)]
         L.vvm_exec_finish.restype = C.c_int
@@ -307,6 +309,10 @@ class HipBackend(Backend):
 
     def exec_ex(self, frame: CallFrame, opt: Optional[ExecOptions] = None) -> None:
         self._check(self.lib.vvm_exec_ex(C.byref(frame.ctx), C.byref(opt) if opt is not None else None), "vvm_exec_ex")
+
+    def exec_noalloc(self, frame: CallFrame, opt: Optional[ExecOptions] = None) -> None:
+        """vvm_exec_ex without any allocation: the Exec works in the device's scratch array (limits in include/vvm_abi.h)."""
+        self._check(self.lib.vvm_exec_noalloc(C.byref(frame.ctx), C.byref(opt) if opt is not None else None), "vvm_exec_noalloc")
 
     def exec_async(self, frame: CallFrame, opt: Optional[ExecOptions] = None) -> None:
         self._check(self.lib.vvm_exec_async(C.byref(frame.ctx), C.byref(opt) if opt is not None else None), "vvm_exec_async")

@@ -11,7 +11,7 @@
 //   SetupBatchStatePtrs                            :315-443     -> host packs stream addresses (InstanceOffset applied)
 //   chunk loop                                     :2276-2295   -> ONE kernel launch (vvm_kernels.hip)
 //   DataSetAccessIndex = count - 1                 :2305-2308   -> host, after the 4-byte-per-dataset read-back
-#include <hip/hip_runtime_api.h>
+#include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <chrono>
@@ -88,12 +88,24 @@ struct ParamRing {
 	}
 };
 
+// Working memory of vvm_exec_noalloc, the entry point for callers that must not allocate: the launch words (with the survivor
+// counts in their spare words) and one look-back word per tile.  The array is part of the code object, so every device the
+// library runs on holds a copy of its own from the moment the code object is loaded there until the process ends.  Its name is
+// only a handle on the host: the address on a device comes from hipGetSymbolAddress with that device current (ensure_device_info),
+// and that address is what host code passes on.
+#define VVM_NOALLOC_MAX_TILES 131072u
+#define VVM_NOALLOC_STATUS_OFF ((sizeof(VvmLaunchState) + 255u) & ~(size_t)255u)
+#define VVM_NOALLOC_SCRATCH_BYTES (VVM_NOALLOC_STATUS_OFF + 8u * (size_t)VVM_NOALLOC_MAX_TILES)
+static __device__ __align__(256) unsigned char scratch[VVM_NOALLOC_SCRATCH_BYTES];
+
 struct DeviceInfo {
 	int num_cus = 256;
 	bool ready[64] = {};      // per device ordinal: the kernels' LDS limit has been raised there
+	uint8_t* scratch_ptr[64] = {};      // per device ordinal: where that device's copy of `scratch` lies
 };
 DeviceInfo g_dev;
 std::mutex g_dev_mutex;
+hipError_t reset_launch_state(VvmLaunchState* d);
 
 int ensure_device_info()
 {
@@ -106,6 +118,12 @@ int ensure_device_info()
 	HIP_TRY(hipGetDeviceProperties(&prop, dev));
 	g_dev.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 	(void)vvm_kernel_max_dynamic_lds();      // (a function attribute belongs to the device that is current)
+	uint8_t* ptr = nullptr;
+	HIP_TRY(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
+	if (!ptr) return fail(VVM_E_HIP, "hipGetSymbolAddress(scratch) returned no address");
+	HIP_TRY(hipMemset(ptr, 0, VVM_NOALLOC_SCRATCH_BYTES));      // tag 0 is never valid
+	HIP_TRY(reset_launch_state((VvmLaunchState*)ptr));
+	g_dev.scratch_ptr[dev] = ptr;
 	g_dev.ready[dev] = true;
 	return VVM_OK;
 }
@@ -127,7 +145,13 @@ struct vvm_state {
 	unsigned long long* d_status = nullptr;
 	uint32_t status_capacity = 0;          // tiles
 	int32_t* d_counts = nullptr;
-	int32_t* counts_src = nullptr;         // where the last Exec left its counts: d_counts, or the caller's vvm_exec_options::DeviceCounts
+	int32_t* counts_src = nullptr;         // where the last Exec left its counts: d_counts, the caller's vvm_exec_options::DeviceCounts, or the device's scratch
+	// what the last enqueued Exec ran on: the state's own launch words, look-back words and counts, or (vvm_exec_noalloc) the device's scratch
+	VvmLaunchState* cur_launch = nullptr;
+	unsigned long long* cur_status = nullptr;
+	size_t cur_status_words = 0;
+	int32_t* cur_counts = nullptr;
+	bool cur_counts_in_launch = false;
 	bool any_ids = false;                  // some pass of the script has update_id / acquire_id
 	bool counts_in_launch = false;         // d_counts lies in the spare words of *d_launch: counts and launch words come back in one copy
 	int32_t* h_counts = nullptr;           // pinned: counts, then the launch error word
@@ -272,6 +296,9 @@ int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, P
 	if (s.bytecode.empty()) return fail(VVM_E_NO_BYTECODE, "state has no bytecode");                    // RT.cpp:2264-2267
 	if (ctx->NumInstances < 0) return fail(VVM_E_INVALID_ARG, "negative NumInstances");
 	if (ctx->DataSets.num < 0 || (ctx->DataSets.num > 0 && !ctx->DataSets.data)) return fail(VVM_E_INVALID_ARG, "DataSets view is null");
+	if (s.num_ext_fns > 0 && !ctx->ExtFunctionTable.data) return fail(VVM_E_INVALID_ARG, "ExtFunctionTable view is null");
+	if (ctx->ConstantTableCount < 0 || (ctx->ConstantTableCount > 0 && (!ctx->ConstantTableNumBytes || !ctx->ConstantTableData)))
+		return fail(VVM_E_INVALID_ARG, "ConstantTableData / ConstantTableNumBytes is null");
 	const bool narrow = opt && (opt->Flags & VVM_EXEC_NO_VGPR_WIDE);
 	if (narrow && st->wide.instances_per_lane != 1) {
 		if (!st->narrow_ready) {
@@ -498,6 +525,8 @@ VVM_API vvm_state* vvm_alloc_state(const uint8_t* blob, size_t num_bytes)
 	if (link_more_passes(st->script, false, st->wide, st->wide_more, st->d_code_wide_more) != VVM_OK) { vvm_free_state(st); return nullptr; }
 	hipError_t e;
 	st->any_ids = st->wide.uses_ids;
+	st->const_table.reserve(st->script.num_consts);      // (filled by the first Exec; reserved here so that no Exec allocates for them)
+	st->const_dword.reserve(st->script.num_consts);
 	for (const vvm::LinkedProgram& more : st->wide_more) st->any_ids = st->any_ids || more.uses_ids;
 	bool any_perlin = st->wide.uses_perlin;      // (a pass links only what its dataset needs: any of them may be the one with the noise call)
 	for (const vvm::LinkedProgram& more : st->wide_more) any_perlin = any_perlin || more.uses_perlin;
@@ -545,7 +574,9 @@ VVM_API void vvm_free_state(vvm_state* st)
 	delete st;
 }
 
-VVM_API int vvm_exec_async(vvm_exec_context* ctx, const vvm_exec_options* opt)
+// Enqueues one Exec.  no_alloc: the Exec works in the device's scratch array instead of the state's own buffers and refuses
+// whatever would need an allocation (vvm_exec_noalloc).
+static int exec_enqueue(vvm_exec_context* ctx, const vvm_exec_options* opt, bool no_alloc)
 {
 	if (!ctx || !ctx->VVMState) return fail(VVM_E_INVALID_ARG, "null context or state");
 	vvm_state* st = ctx->VVMState;
@@ -554,16 +585,42 @@ VVM_API int vvm_exec_async(vvm_exec_context* ctx, const vvm_exec_options* opt)
 		HIP_TRY(hipGetDevice(&dev));
 		if (dev != st->device) return fail(VVM_E_INVALID_ARG, "the state was allocated on another device than the one that is current");
 	}
+	if (st->any_ids && st->results_pending)      // (the dataset's counters are read here and written back by the finish: see include/vvm_abi.h)
+		return fail(VVM_E_INVALID_ARG, "a script with update_id / acquire_id takes one Exec at a time: finish the queued Exec first");
+	if (no_alloc) {
+		if (st->any_ids) return fail(VVM_E_UNSUPPORTED_OP, "vvm_exec_noalloc: scripts with update_id / acquire_id need buffers sized per Exec");
+		if ((opt && (opt->Flags & VVM_EXEC_NO_VGPR_WIDE)) && st->wide.instances_per_lane != 1 && !st->narrow_ready)
+			return fail(VVM_E_UNSUPPORTED_OP, "vvm_exec_noalloc: the one-instance-per-lane program of this state has not been linked yet");
+		if ((size_t)std::max<uint32_t>(st->script.max_output_dataset, 1) + 4 > sizeof(((VvmLaunchState*)nullptr)->reserved) / 4)
+			return fail(VVM_E_TOO_LARGE, "vvm_exec_noalloc: too many output datasets for the scratch array's count words");
+	}
 	PreparedExec pe;
 	int rc = prepare(st, ctx, opt, pe);
 	if (rc != VVM_OK) return rc;
+	uint8_t* const scratch_ptr = no_alloc ? g_dev.scratch_ptr[st->device] : nullptr;
+	if (no_alloc) {
+		if (!scratch_ptr) return fail(VVM_E_HIP, "vvm_exec_noalloc: the scratch array of this device has no address");
+		const uint32_t lanes = pe.instances_per_lane;
+		if (pe.tiles > VVM_NOALLOC_MAX_TILES) {
+			char msg[192];
+			snprintf(msg, sizeof msg, "vvm_exec_noalloc: %d instances are %u tiles at %u instances per lane; the scratch array holds look-back words for %u tiles",
+			         ctx->NumInstances, pe.tiles, lanes, VVM_NOALLOC_MAX_TILES);
+			return fail(VVM_E_TOO_LARGE, msg);
+		}
+	}
 	hipStream_t stream = (opt && opt->Stream) ? (hipStream_t)opt->Stream : st->stream;
 	if (st->last_stream && st->last_stream != stream) HIP_TRY(hipStreamSynchronize(st->last_stream));
 	st->last_stream = stream;
 	st->in_flight = true;
 	st->last_width = pe.instances_per_lane;
 	int32_t* const caller_counts = (opt && opt->DeviceCounts && !st->any_ids) ? opt->DeviceCounts : nullptr;
-	st->counts_src = caller_counts ? caller_counts : st->d_counts;
+	// the launch words, look-back words and counts this Exec runs on
+	VvmLaunchState* const d_launch = no_alloc ? (VvmLaunchState*)scratch_ptr : st->d_launch;
+	int32_t* const own_counts = no_alloc ? (int32_t*)(scratch_ptr + offsetof(VvmLaunchState, reserved)) : st->d_counts;
+	st->counts_src = caller_counts ? caller_counts : own_counts;
+	st->cur_launch = d_launch;
+	st->cur_counts = own_counts;
+	st->cur_counts_in_launch = no_alloc ? true : st->counts_in_launch;
 	if (pe.tiles == 0) {     // nothing to run: zero chunks in the reference too (RT.cpp:2277)
 		if (st->results_pending) { HIP_TRY(hipStreamSynchronize(stream)); st->results_pending = false; }
 		if (caller_counts) HIP_TRY(hipMemsetAsync(caller_counts, 0, 4 * (size_t)std::max<uint32_t>(st->script.max_output_dataset, 1), stream));
@@ -571,10 +628,15 @@ VVM_API int vvm_exec_async(vvm_exec_context* ctx, const vvm_exec_options* opt)
 		for (uint32_t i = 0; i < st->script.max_output_dataset; ++i) st->h_counts[i] = 0;
 		return VVM_OK;
 	}
-	rc = ensure_status(st, pe.tiles);
-	if (rc != VVM_OK) return rc;
+	if (!no_alloc) {
+		rc = ensure_status(st, pe.tiles);
+		if (rc != VVM_OK) return rc;
+	}
+	unsigned long long* const d_status = no_alloc ? (unsigned long long*)(scratch_ptr + VVM_NOALLOC_STATUS_OFF) : st->d_status;
+	st->cur_status = d_status;
+	st->cur_status_words = no_alloc ? (size_t)VVM_NOALLOC_MAX_TILES : (size_t)st->status_capacity;
 	const size_t ncounts = std::max<uint32_t>(st->script.max_output_dataset, 1);
-	const bool timed = st->timing && st->ev_used < 4096;
+	const bool timed = st->timing && st->ev_used < 4096 && (!no_alloc || st->ev_used < st->ev_start.size());      // (no new events without allocating)
 	if (timed) {
 		if (st->ev_used == st->ev_start.size()) {
 			hipEvent_t a = nullptr, b = nullptr;
@@ -612,11 +674,13 @@ VVM_API int vvm_exec_async(vvm_exec_context* ctx, const vvm_exec_options* opt)
 		}
 		// A small block travels as a kernel argument; a larger one, or one whose ID descriptor other kernels read, through a slot
 		// of the ring (pinned copy, device copy, one host-to-device copy ahead of the launch).
-		const bool inline_block = pe.bytes <= VVM_INLINE_PARAM_BYTES && !pe.lp->uses_ids && !g_no_inline_params && !(opt && (opt->Flags & VVM_EXEC_PARAMS_IN_MEMORY));
+		const bool fits_inline = pe.bytes <= VVM_INLINE_PARAM_BYTES && !pe.lp->uses_ids;
+		if (no_alloc && !fits_inline) return fail(VVM_E_TOO_LARGE, "vvm_exec_noalloc: the script's parameter block (constants, stream addresses) exceeds the 1 KB that travels as a kernel argument");
+		const bool inline_block = fits_inline && (no_alloc || (!g_no_inline_params && !(opt && (opt->Flags & VVM_EXEC_PARAMS_IN_MEMORY))));
 		int slot = -1;
 		alignas(64) uint8_t local_block[VVM_INLINE_PARAM_BYTES];
 		if (inline_block) {
-			rc = fill_params(st, ctx, opt, pe, local_block, nullptr, st->d_status, 0);
+			rc = fill_params(st, ctx, opt, pe, local_block, nullptr, d_status, 0, no_alloc ? st->counts_src : nullptr);
 			if (rc != VVM_OK) return rc;
 		} else {
 			rc = st->ring.reserve(pe.bytes);
@@ -628,7 +692,7 @@ VVM_API int vvm_exec_async(vvm_exec_context* ctx, const vvm_exec_options* opt)
 			HIP_TRY(hipMemcpyAsync(st->ring.dev[slot], st->ring.host[slot], pe.bytes, hipMemcpyHostToDevice, stream));
 		}
 		if (timed && pass == 0) HIP_TRY(hipEventRecord(st->ev_start[st->ev_used], stream));
-		const int lrc = vvm_launch_exec_kernel((int)pe.instances_per_lane, inline_block ? nullptr : (const VvmExecDesc*)st->ring.dev[slot], 1, pe.tiles, st->d_launch,
+		const int lrc = vvm_launch_exec_kernel((int)pe.instances_per_lane, inline_block ? nullptr : (const VvmExecDesc*)st->ring.dev[slot], 1, pe.tiles, d_launch,
 		                                       pe.lp->many_registers ? 1 : 0, pe.lp->lds_spill_slots, pe.lp->full_kernel ? 1 : 0,
 		                                       grid_for(pe.tiles, pe.instances_per_lane, pe.lp->full_kernel, pe.lp->many_registers), stream,
 		                                       inline_block ? local_block : nullptr, inline_block ? (uint32_t)pe.bytes : 0u, 0u);
@@ -657,19 +721,20 @@ VVM_API int vvm_exec_finish(vvm_exec_context* ctx)
 	if (st->last_stream) {
 		const size_t nc = std::max<uint32_t>(st->script.max_output_dataset, 1);
 		const bool pending = st->results_pending;
+		const bool with_caller = st->counts_src && st->counts_src != st->cur_counts;      // counts left with the caller
 		if (pending) {
-			if (st->counts_src && st->counts_src != st->d_counts) {      // counts left with the caller
+			if (with_caller) {
 				HIP_TRY(hipMemcpyAsync(st->h_counts, st->counts_src, nc * 4, hipMemcpyDeviceToHost, st->last_stream));
-				HIP_TRY(hipMemcpyAsync(st->h_counts + nc + 4, st->d_launch, 80, hipMemcpyDeviceToHost, st->last_stream));
-			} else if (st->counts_in_launch) {      // the launch words up to and including stats[], then the counts and the MaxUsedID word behind them
-				HIP_TRY(hipMemcpyAsync(st->h_counts + nc + 4, st->d_launch, offsetof(VvmLaunchState, reserved) + (nc + 1) * 4, hipMemcpyDeviceToHost, st->last_stream));
+				HIP_TRY(hipMemcpyAsync(st->h_counts + nc + 4, st->cur_launch, 80, hipMemcpyDeviceToHost, st->last_stream));
+			} else if (st->cur_counts_in_launch) {      // the launch words up to and including stats[], then the counts and the MaxUsedID word behind them
+				HIP_TRY(hipMemcpyAsync(st->h_counts + nc + 4, st->cur_launch, offsetof(VvmLaunchState, reserved) + (nc + 1) * 4, hipMemcpyDeviceToHost, st->last_stream));
 			} else {
-				HIP_TRY(hipMemcpyAsync(st->h_counts, st->d_counts, (nc + 1) * 4, hipMemcpyDeviceToHost, st->last_stream));     // (and the MaxUsedID word)
-				HIP_TRY(hipMemcpyAsync(st->h_counts + nc + 4, st->d_launch, 80, hipMemcpyDeviceToHost, st->last_stream));     // the words up to and including stats[]
+				HIP_TRY(hipMemcpyAsync(st->h_counts, st->cur_counts, (nc + 1) * 4, hipMemcpyDeviceToHost, st->last_stream));     // (and the MaxUsedID word)
+				HIP_TRY(hipMemcpyAsync(st->h_counts + nc + 4, st->cur_launch, 80, hipMemcpyDeviceToHost, st->last_stream));     // the words up to and including stats[]
 			}
 		}
 		HIP_TRY(hipStreamSynchronize(st->last_stream));
-		if (pending && st->counts_in_launch && !(st->counts_src && st->counts_src != st->d_counts)) memcpy(st->h_counts, (const uint8_t*)(st->h_counts + nc + 4) + offsetof(VvmLaunchState, reserved), (nc + 1) * 4);
+		if (pending && st->cur_counts_in_launch && !with_caller) memcpy(st->h_counts, (const uint8_t*)(st->h_counts + nc + 4) + offsetof(VvmLaunchState, reserved), (nc + 1) * 4);
 	}
 	st->results_pending = false;
 	st->in_flight = false;
@@ -680,8 +745,8 @@ VVM_API int vvm_exec_finish(vvm_exec_context* ctx)
 			fprintf(stderr, "vvm stats (cumulative): lookbacks %llu rounds %llu polls %llu clocks/16 %llu | ticket %llu load %llu interp %llu tiles %llu\n", ls->stats[0], ls->stats[1], ls->stats[2], ls->stats[3], ls->stats[4], ls->stats[5], ls->stats[6], ls->stats[7]);
 		if (ls->pad != 0) {
 			const bool lds_base = ls->pad == 2;
-			(void)reset_launch_state(st->d_launch);
-			if (st->d_status) (void)hipMemset(st->d_status, 0, (size_t)st->status_capacity * 8);
+			(void)reset_launch_state(st->cur_launch);
+			if (st->cur_status) (void)hipMemset(st->cur_status, 0, st->cur_status_words * 8);
 			if (lds_base) return fail(VVM_E_HIP, "the kernel's dynamic LDS does not start at address 0 (the noise tables are addressed absolutely)");
 			return fail(VVM_E_HIP, "look-back timed out inside the kernel (a tile never published its count)");
 		}
@@ -702,6 +767,15 @@ VVM_API int vvm_exec_finish(vvm_exec_context* ctx)
 		}
 	}
 	return write_back_counts(st, ctx, ran);
+}
+
+VVM_API int vvm_exec_async(vvm_exec_context* ctx, const vvm_exec_options* opt) { return exec_enqueue(ctx, opt, false); }
+
+VVM_API int vvm_exec_noalloc(vvm_exec_context* ctx, const vvm_exec_options* opt)
+{
+	int rc = exec_enqueue(ctx, opt, true);
+	if (rc != VVM_OK) return rc;
+	return vvm_exec_finish(ctx);
 }
 
 VVM_API int vvm_exec_ex(vvm_exec_context* ctx, const vvm_exec_options* opt)
@@ -958,7 +1032,7 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 
 // --- introspection / helpers ------------------------------------------------------------------------
 VVM_API int32_t vvm_state_last_exec_width(const vvm_state* st) { return st ? (int32_t)st->last_width : 0; }
-VVM_API const int32_t* vvm_state_device_counts(const vvm_state* st) { return st ? st->d_counts : nullptr; }
+VVM_API const int32_t* vvm_state_device_counts(const vvm_state* st) { return st ? (st->counts_src ? st->counts_src : st->d_counts) : nullptr; }
 VVM_API int32_t vvm_state_max_output_dataset(const vvm_state* st) { return st ? (int32_t)st->script.max_output_dataset : 0; }
 
 static void fill_info(const vvm::ThawedScript& s, const vvm::LinkedProgram& lp, vvm_program_info* out)
@@ -1053,7 +1127,7 @@ VVM_API int vvm_state_copy_counts(vvm_state* st, void* dst_device, void* stream)
 {
 	if (!st || !dst_device) return fail(VVM_E_INVALID_ARG, "null argument");
 	const size_t ncounts = std::max<uint32_t>(st->script.max_output_dataset, 1);
-	HIP_TRY(hipMemcpyAsync(dst_device, st->d_counts, ncounts * 4, hipMemcpyDeviceToDevice, stream ? (hipStream_t)stream : st->stream));
+	HIP_TRY(hipMemcpyAsync(dst_device, st->counts_src ? st->counts_src : st->d_counts, ncounts * 4, hipMemcpyDeviceToDevice, stream ? (hipStream_t)stream : st->stream));
 	return VVM_OK;
 }
 

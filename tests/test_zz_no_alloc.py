@@ -1,0 +1,83 @@
+"""vvm_exec_noalloc (the entry point that allocates nothing) against vvm_exec_ex, through the C ABI: bit-identical streams and
+counts on two calls in a row, the second with a smaller input, so that the second call finds the first one's words in the
+device's scratch array."""
+import numpy as np
+import pytest
+
+from renderer_amd import abi, scripts
+from renderer_amd.runtime import VectorVMState
+from vm_harness import PAD
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+class _Streams:
+    def __init__(self, be, arrays, n, outs=8):
+        self.be, self.n = be, n
+        self.ins, self.outs = [], []
+        for a in arrays:
+            buf = np.zeros(n + PAD, f32)
+            buf[:n] = a[:n]
+            p = be.lib.vvm_device_alloc(buf.nbytes)
+            assert p
+            be._check(be.lib.vvm_device_upload(p, buf.ctypes.data, buf.nbytes), "upload")
+            self.ins.append(p)
+        for _ in range(outs):
+            p = be.lib.vvm_device_alloc((n + PAD) * 4)
+            assert p
+            be._check(be.lib.vvm_device_memset(p, 0xCD, (n + PAD) * 4), "memset")
+            self.outs.append(p)
+
+    def download(self, k):
+        h = np.empty(self.n + PAD, np.uint32)
+        self.be._check(self.be.lib.vvm_device_download(h.ctypes.data, self.outs[k], h.nbytes), "download")
+        return h
+
+    def free(self):
+        for p in self.ins + self.outs:
+            self.be.lib.vvm_device_free(p)
+
+
+def test_no_alloc_entry_point_equals_exec_ex():
+    be = abi.load_hip_backend()
+    w = scripts.fountain()
+    st_ref, st_new = VectorVMState(w.script.blob, be), VectorVMState(w.script.blob, be)
+    held = []
+    try:
+        for n, width in ((300_000, 8), (70_001, 4)):          # the second call is smaller, and runs on the other kernel width
+            host = scripts.fountain_streams_np(n, n, kill_half=True)
+            a, b = _Streams(be, host, n), _Streams(be, host, n)
+            held += [a, b]
+            fa = st_ref.frame([abi.DataSet(a.ins, a.outs, 0)], n, [w.constants])
+            fb = st_new.frame([abi.DataSet(b.ins, b.outs, 0)], n, [w.constants])
+            be.exec_ex(fa, abi.ExecOptions(7, 0, 0, None, 0))
+            be.exec_noalloc(fb, abi.ExecOptions(7, 0, 0, None, 0))
+            assert st_new.last_exec_width() == st_ref.last_exec_width() == width
+            surv = fa.survivors(0)
+            assert fb.survivors(0) == surv and 0 < surv < n
+            for k in range(8):
+                got, want = b.download(k), a.download(k)
+                assert np.array_equal(got, want), "n = %d, stream %d" % (n, k)          # (the untouched tail included)
+            ia, ib = fa.ctx.Internal, fb.ctx.Internal
+            assert (ia.MaxChunksPerBatch, ia.MaxInstancesPerChunk) == (ib.MaxChunksPerBatch, ib.MaxInstancesPerChunk)
+    finally:
+        st_ref.close()
+        st_new.close()
+        for s in held:
+            s.free()
+
+
+def test_no_alloc_entry_point_refuses_what_does_not_fit():
+    be = abi.load_hip_backend()
+    w = scripts.fountain()
+    st = VectorVMState(w.script.blob, be)
+    s = _Streams(be, scripts.fountain_streams_np(0, 64), 64)
+    try:
+        frame = st.frame([abi.DataSet(s.ins, s.outs, 0)], 300_000_000, [w.constants])          # 146485 tiles of 2048: refused before any launch
+        with pytest.raises(abi.VVMError) as e:
+            be.exec_noalloc(frame)
+        assert e.value.code == abi.VVM_E_TOO_LARGE and "131072" in str(e.value)
+    finally:
+        st.close()
+        s.free()
