@@ -86,7 +86,7 @@ def operand_streams(name: str, n_in: int, n: int = 4096, seed: int = 1234) -> Li
 # The rest call a math library whose GPU build differs from glibc, or a hardware estimate; the bound is stated in ULP of the
 # oracle's result (None = relative bound, see REL_TOLERANCE).
 ULP_TOLERANCE: Dict[str, int] = {
-    "tan": 4, "atan": 2, "exp2": 2, "log2": 2,           # libm-class functions: glibc on the CPU, the device math library on the GPU
+    "tan": 2, "atan": 2, "exp2": 2, "log2": 2,           # libm-class functions: glibc on the CPU, the device math library on the GPU
 }
 REL_TOLERANCE: Dict[str, float] = {
     "rcp": 2.0 ** -11,      # both sides are reciprocal ESTIMATES (rcpps: 1.5 * 2^-12 relative; the GPU's estimate is 1 ulp)

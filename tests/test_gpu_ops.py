@@ -42,11 +42,13 @@ def _compare(name, got, ref):
 
 
 def _domain(name, ins):
-    """The libm-class functions are compared where they are well conditioned."""
+    """The operand streams are raw bit patterns; tan gets several periods around zero instead of arguments up to 1e38 (whose
+    reduction mod pi is a property of the math library, not of the executor), exp2 its whole finite range."""
     if name == "tan":
-        return [np.clip(np.nan_to_num(ins[0], nan=0.3, posinf=1.0, neginf=-1.0), -1.5, 1.5).astype(f32)]
+        x = np.nan_to_num(ins[0], nan=0.3, posinf=1.0, neginf=-1.0)
+        return [np.where(np.abs(x) > 20.0, np.fmod(x, f32(20.0)), x).astype(f32)]
     if name in ("exp2",):
-        return [np.clip(np.nan_to_num(ins[0], nan=0.3, posinf=1.0, neginf=-1.0), -100, 100).astype(f32)]
+        return [np.clip(np.nan_to_num(ins[0], nan=0.3, posinf=1.0, neginf=-1.0), -150, 128).astype(f32)]
     if name in ("sin", "cos", "sin_cos"):
         # the oracle's range reduction multiplies by 4/pi and converts to int32: keep below 2^31 * pi / 4 as the reference's
         # own tests do (UnrealMathTest.cpp:1395-1397 sample [-2pi, 2pi]); edge values beyond are still compared when finite

@@ -55,6 +55,34 @@ def main():
         ops[name] = {"max_ulp_on_finite_results": worst, "test_bound_ulp": op_cases.ULP_TOLERANCE.get(name, 0),
                      "note": "relative bound 2^-11, both sides are estimates" if name in op_cases.REL_TOLERANCE else ""}
     report["single_ops"] = ops
+
+    # the libm-class functions over their whole useful domains (glibc on the host, the device math library on the GPU): nothing is
+    # clipped away, inputs whose results differ by more than the bound are listed
+    rng = np.random.default_rng(2024)
+    half_pi = float(np.float32(np.pi / 2))
+    domains = {
+        "tan": [np.linspace(-half_pi + 1e-4, half_pi - 1e-4, 400_000), rng.uniform(-20.0, 20.0, 400_000),
+                half_pi - np.geomspace(1e-7, 1e-2, 50_000), -half_pi + np.geomspace(1e-7, 1e-2, 50_000), rng.uniform(-1e4, 1e4, 100_000)],
+        "exp2": [np.linspace(-150.0, 128.0, 600_000), rng.uniform(-1.0, 1.0, 200_000), np.arange(-150, 129, dtype=np.float64), rng.uniform(-1000, 1000, 100_000)],
+        "log2": [np.geomspace(1e-45, 3e38, 600_000), rng.uniform(0.5, 2.0, 300_000)],
+        "atan": [np.linspace(-50.0, 50.0, 400_000), np.geomspace(1e-30, 1e30, 200_000), -np.geomspace(1e-30, 1e30, 200_000)],
+    }
+    wide = {}
+    for name, parts in domains.items():
+        x = np.concatenate(parts).astype(f32)
+        script, n_in, n_out = op_cases.single_op_script(name)
+        r, _, _ = run_oracle(script, [op_cases.ALL_ONES], [x], [f32], len(x))
+        g, _, _ = run_hip(script, [op_cases.ALL_ONES], [x], [f32], len(x))
+        d = ulp_diff(g[0][:len(x)], r[0][:len(x)])
+        fin = np.isfinite(r[0][:len(x)])
+        d = np.where(fin, d, 0)
+        bound = op_cases.ULP_TOLERANCE[name]
+        over = np.nonzero(d > bound)[0]
+        worst = np.argsort(d)[-5:][::-1]
+        wide[name] = {"inputs": int(len(x)), "max_ulp": int(d.max()), "bound_ulp": bound, "above_bound": int(over.size),
+                      "histogram_0_1_2_3_ge4": [int(v) for v in np.bincount(np.minimum(d, 4).astype(np.int64), minlength=5)],
+                      "worst_inputs": [{"x": float(x[i]), "gpu": float(g[0][i]), "oracle": float(r[0][i]), "ulp": int(d[i])} for i in worst if d[i] > 0]}
+    report["libm_class_wide_domains"] = wide
     print(json.dumps(report))
 
 
