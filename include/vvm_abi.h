@@ -264,6 +264,28 @@ VVM_API int vvm_exec_noalloc(vvm_exec_context* ctx, const vvm_exec_options* opt)
  * array of n.  No counterpart in the reference, which runs one Exec per call (VectorVMRuntime.cpp:2182). */
 VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_options* opts);
 
+/* A batch that is kept from tick to tick.  vvm_exec_batch validates, sizes and fills the parameter blocks of all its Execs on
+ * every call; an emitter set that persists pays that once here: vvm_batch_create does it and keeps the blocks in device memory,
+ * vvm_batch_exec runs the batch again and touches only what the caller says has changed since the handle's last call:
+ *   VVM_BATCH_CHANGED_INSTANCES  NumInstances of some contexts (tile counts; an Exec that moves to another kernel re-plans the batch)
+ *   VVM_BATCH_CHANGED_CONSTANTS  contents of constant tables (the tables' addresses and sizes are read again as well)
+ *   VVM_BATCH_CHANGED_STREAMS    stream addresses, InstanceOffset, DataSets arrays, ID tables: every block is filled again.
+ *                                (A caller that ping-pongs two sets of streams keeps one handle per set and alternates.)
+ *   0                            nothing: no host work on the blocks and no upload at all.
+ * The `ctxs` array (and what it points to) must stay where it is until vvm_batch_destroy; the options are copied.  Results land in
+ * the contexts exactly as with vvm_exec_batch, and a state may be used by other calls between two vvm_batch_exec calls (one Exec
+ * at a time per state, as always).  One call at a time per handle; handles are independent of each other and of vvm_exec_batch.
+ * No counterpart in the reference, which runs one Exec per call (VectorVMRuntime.cpp:2182). */
+typedef struct vvm_batch vvm_batch;
+enum {
+	VVM_BATCH_CHANGED_INSTANCES = 1u << 0,
+	VVM_BATCH_CHANGED_CONSTANTS = 1u << 1,
+	VVM_BATCH_CHANGED_STREAMS   = 1u << 2
+};
+VVM_API vvm_batch* vvm_batch_create(vvm_exec_context* ctxs, int32_t n, const vvm_exec_options* opts);
+VVM_API int        vvm_batch_exec(vvm_batch* batch, uint32_t changed);
+VVM_API void       vvm_batch_destroy(vvm_batch* batch);
+
 /* Device pointer (int32[MaxOutputDataSet]) to the survivor counts of the last vvm_exec* call made on this state
  * (the caller's vvm_exec_options.DeviceCounts when that was given); valid after the Exec's kernel has run on its
  * stream. Lets a multi-GPU caller all-gather the counts without a host round trip.  After vvm_exec_batch the counts of

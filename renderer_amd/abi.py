@@ -19,6 +19,7 @@ VVM_EXEC_NO_VGPR_WIDE = 1
 VVM_EXEC_NO_EIGHT_WIDE = 2
 VVM_EXEC_FORCE_EIGHT_WIDE = 4
 VVM_EXEC_PARAMS_IN_MEMORY = 8
+VVM_BATCH_CHANGED_INSTANCES, VVM_BATCH_CHANGED_CONSTANTS, VVM_BATCH_CHANGED_STREAMS = 1, 2, 4
 
 STATUS_NAMES = {0: "VVM_OK", 1: "VVM_E_INVALID_ARG", 2: "VVM_E_EXTFN_MISMATCH", 3: "VVM_E_NO_BYTECODE",
                 4: "VVM_E_UNSUPPORTED_OP", 5: "VVM_E_BAD_BLOB", 6: "VVM_E_HIP", 7: "VVM_E_RCCL", 8: "VVM_E_TOO_LARGE"}
@@ -264,6 +265,12 @@ class HipBackend(Backend):
         L.vvm_exec_finish.argtypes = [C.POINTER(ExecContext)]
         L.vvm_exec_batch.restype = C.c_int
         L.vvm_exec_batch.argtypes = [C.POINTER(ExecContext), C.c_int32, C.POINTER(ExecOptions)]
+        L.vvm_batch_create.restype = C.c_void_p
+        L.vvm_batch_create.argtypes = [C.POINTER(ExecContext), C.c_int32, C.POINTER(ExecOptions)]
+        L.vvm_batch_exec.restype = C.c_int
+        L.vvm_batch_exec.argtypes = [C.c_void_p, C.c_uint32]
+        L.vvm_batch_destroy.restype = None
+        L.vvm_batch_destroy.argtypes = [C.c_void_p]
         L.vvm_state_device_counts.restype = C.c_void_p
         L.vvm_state_device_counts.argtypes = [C.c_void_p]
         L.vvm_state_max_output_dataset.restype = C.c_int32
@@ -337,6 +344,19 @@ class HipBackend(Backend):
 
     def exec_batch_packed(self, arr, oarr=None) -> None:
         self._check(self.lib.vvm_exec_batch(arr, len(arr), oarr), "vvm_exec_batch")
+
+    def batch_create(self, arr, oarr=None) -> int:
+        """vvm_batch_create over the packed arrays of pack_batch (which must outlive the handle)."""
+        h = self.lib.vvm_batch_create(arr, len(arr), oarr)
+        if not h:
+            raise VVMError(VVM_E_INVALID_ARG, "vvm_batch_create", self.error_text())
+        return h
+
+    def batch_exec(self, handle: int, changed: int = 0) -> None:
+        self._check(self.lib.vvm_batch_exec(handle, changed), "vvm_batch_exec")
+
+    def batch_destroy(self, handle: int) -> None:
+        self.lib.vvm_batch_destroy(handle)
 
     def inspect_blob(self, blob: bytes) -> ProgramInfo:
         """Thaw + link only (no device needed); raises VVMError with the linker's message on a bad script."""

@@ -1,5 +1,7 @@
-"""Stale look-back words in vvm_exec_batch, constructed on purpose.  Run as a program in a fresh process (the test in
-test_gpu_batch_tags.py does that): what the words and the launch words hold then is known.
+"""Stale look-back words in vvm_exec_batch, constructed on purpose.  Run as a program in a fresh process: what the batch
+workspace's words and launch words hold then is known.  (tests/test_gpu_batch_tags.py builds the same situation inside the
+test process, on the fresh workspace of a vvm_batch handle; this program is what showed the defect on a library built with
+the old tagging: VVM_TEST_LIB=<that library> python tests/batch_epoch_case.py.)
 
 The launches of a batch share one array of look-back words.  Three calls:
   A  an eight-wide Exec and a four-wide one: two kernel shapes, so two launches;
@@ -16,7 +18,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-os.environ["VVM_DEBUG_SKIP"] = "1024"
+if __name__ == "__main__":
+    os.environ["VVM_DEBUG_SKIP"] = "1024"
 
 import numpy as np  # noqa: E402
 
@@ -32,14 +35,17 @@ CAP = 80_000      # elements per stream: a misplaced tile must still land inside
 
 
 class Emitter:
-    def __init__(self, be, variant, n, kill_half, seed):
+    def __init__(self, be, variant, n, kill_half, seed, cap=None):
+        global CAP
+        if cap is not None:
+            CAP = cap
         self.be, self.n = be, n
         self.w = scripts.fountain(variant=variant)
-        self.host_in = scripts.fountain_streams_np(seed, n, kill_half=kill_half)
+        self.host_in = scripts.fountain_streams_np(seed, CAP if cap is not None else n, kill_half=kill_half)      # (cap given: the size may change later)
         self.ins, self.outs = [], []
         for a in self.host_in:
             buf = np.zeros(CAP, f32)
-            buf[:n] = a[:n]
+            buf[:len(a)] = a
             p = be.lib.vvm_device_alloc(buf.nbytes)
             assert p
             be._check(be.lib.vvm_device_upload(p, buf.ctypes.data, buf.nbytes), "upload")
@@ -52,7 +58,12 @@ class Emitter:
         self.state = VectorVMState(self.w.script.blob, be)
         self.frame = self.state.frame([abi.DataSet(self.ins, self.outs, 0)], n, [self.w.constants])
 
-    def check(self, name):
+    def free(self):
+        self.state.close()
+        for p in self.ins + self.outs:
+            self.be.lib.vvm_device_free(p)
+
+    def check(self, name, tail=True):
         ref, ref_n, _ = run_oracle(self.w.script, [self.w.constants], self.host_in, [f32] * 8, self.n)
         got_n = self.frame.survivors(0)
         if got_n != ref_n:
@@ -65,7 +76,7 @@ class Emitter:
                 bad = int(np.nonzero(h[:ref_n].view(np.uint32) != ref[k][:ref_n].view(np.uint32))[0][0])
                 print("MISMATCH %s: stream %d differs from element %d on" % (name, k, bad))
                 return False
-            if not np.all(h[ref_n:].view(np.uint32) == 0xCDCDCDCD):
+            if tail and not np.all(h[ref_n:].view(np.uint32) == 0xCDCDCDCD):      # (only meaningful for the first Exec into fresh streams)
                 print("MISMATCH %s: stream %d written past its survivors" % (name, k))
                 return False
         return True

@@ -135,6 +135,21 @@ def main():
         print(json.dumps({"config": "batch 4096 emitters x 16Ki, 64 bytecode variants", "particles": total, "survivors": surv, "steps": args.steps,
                           "ms_per_step": el / args.steps * 1e3, "updates_per_s": total * args.steps / el,
                           "algorithmic_GBps_wallclock": alg * args.steps / el / 1e9}), flush=True)
+        # the same batch kept in a handle: nothing changes between ticks / the constants change every tick
+        handle = be.batch_create(arr, oarr)
+        for changed, label in ((0, "nothing changes"), (abi.VVM_BATCH_CHANGED_CONSTANTS, "constants change every tick"),
+                               (abi.VVM_BATCH_CHANGED_INSTANCES | abi.VVM_BATCH_CHANGED_CONSTANTS, "sizes are re-read and constants change every tick")):
+            for _ in range(2):
+                be.batch_exec(handle, changed)
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                be.batch_exec(handle, changed)
+            el = time.perf_counter() - t0
+            surv2 = sum(f.survivors(0) for f in frames)
+            print(json.dumps({"config": "batch 4096 emitters x 16Ki through vvm_batch_exec, " + label, "particles": total, "survivors": surv2, "steps": args.steps,
+                              "ms_per_step": el / args.steps * 1e3, "updates_per_s": total * args.steps / el,
+                              "algorithmic_GBps_wallclock": (32.0 * total + 32.0 * surv2) * args.steps / el / 1e9}), flush=True)
+        be.batch_destroy(handle)
         for st in states:
             st.close()
 
