@@ -7,9 +7,12 @@ A step is one Exec of the fountain update script (8 float32 streams in, 8 out, k
 batch of synthetic particles that is already resident in HBM.  At N = 1 the batch is 64 Mi particles
 (BASELINE.json configs[1]); at N > 1 every rank runs the same-sized shard of a larger emitter (weak scaling), with
 exec_index / random streams based at the shard's first global instance, and every step ends with the all-gather
-of the per-rank survivor counts (RCCL) from which each rank's global acquireindex offset follows.  The Exec leaves
-its count in the buffer the all-gather reads (vvm_exec_options.DeviceCounts), and the all-gather runs on a stream
+of the per-rank survivor counts (RCCL) from which each rank's global acquireindex offset follows.  A step of rank r is
+one vvm_exec_sharded_async call of the C ABI: the Exec leaves its count in the buffer the all-gather reads, and the
+all-gather (ncclAllGather on the library's own communicator, created from an id that rank 0 broadcasts) runs on a stream
 of its own, so the next step's Exec (which needs only the local count) does not wait for the other ranks.
+(--comm torch keeps the exchange in torch.distributed instead; the library's communicator falls back to it by itself
+when RCCL cannot be set up, and `config.parallelism` says which one ran.)
 
 Rank 0 prints ONE JSON line.  `roofline` prices the interpreter kernel against HBM: algorithmic bytes per launch
 (4 bytes x (input streams x instances + output streams x survivors)) over the kernel's mean duration, which is
@@ -66,7 +69,17 @@ def cpu_baseline(workload_name, seconds=12.0, n=1 << 20):
     # The reference runs one Exec on one core (VectorVMRuntime.cpp:2276-2295); Niagara gets its parallelism from running many
     # emitters at once.  Second figure: P threads, each with its own state, each running Execs over its own n / P instances.
     import threading
-    threads = max(1, min(16, int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)))
+    # P = the host cores this GPU's job may use: the box's per-GPU CPU share (OMP_NUM_THREADS is set to it there), capped by the
+    # machine's physical cores as lscpu reports them
+    physical = None
+    try:
+        import subprocess
+        fields = dict(l.split(":", 1) for l in subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout.splitlines() if ":" in l)
+        physical = int(fields["Core(s) per socket"].strip()) * int(fields["Socket(s)"].strip())
+    except Exception:      # noqa: BLE001  (no lscpu: the logical count stands in)
+        physical = None
+    share = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
+    threads = max(1, min(share, physical or share, 64))
     per = n // threads
     frames, states = [], []
     for t in range(threads):
@@ -98,7 +111,9 @@ def cpu_baseline(workload_name, seconds=12.0, n=1 << 20):
     for st in states:
         be.free_state(st)
     result["threads"] = {"value": per * sum(done) / el2, "cores": threads,
-                         "sample": "%d threads, each its own state and %d particles per Exec, %d Execs in %.1f s" % (threads, per, sum(done), el2)}
+                         "physical_cores_of_the_machine": physical,
+                         "sample": "%d threads (this GPU's share of the host's cores), each its own state and %d particles per Exec, %d Execs in %.1f s"
+                                   % (threads, per, sum(done), el2)}
     return result
 
 
@@ -106,7 +121,7 @@ def recorded_traffic(workload, particles):
     """HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE).  Counters cannot be read from inside this process;
     tools/pmc_traffic.sh collects them with rocprofv3 in separate passes of this same command and profiles/ holds the result.
     Returned only when it was taken on this workload and size."""
-    for name in ("r01_traffic.json", "r01_traffic_kill_half.json"):
+    for name in ("r02_traffic.json", "r02_traffic_kill_half.json", "r01_traffic.json", "r01_traffic_kill_half.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 t = json.load(f)
@@ -129,9 +144,17 @@ def main():
                     help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse the multi-rank path on one GPU: all ranks then share device 0)")
     ap.add_argument("--collective-at-one", action="store_true",
                     help="rehearsal on a one-GPU box: run the multi-rank step (count copy, all-gather on its own stream) with a single rank")
+    ap.add_argument("--comm", default="c-abi", choices=["c-abi", "torch"],
+                    help="who runs the count exchange at N > 1: the library's own RCCL communicator (vvm_exec_sharded_async) or torch.distributed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
+
+    # Rank 0 prints ONE line on stdout.  Libraries write there too (RCCL prints a version banner when its first communicator
+    # comes up), so everything else that lands on descriptor 1 goes to stderr and the result line to the real stdout.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     import torch
     from renderer_amd import abi, scripts
@@ -193,9 +216,35 @@ def main():
     # (the Exec leaves its survivor count in the buffer the all-gather reads: vvm_exec_options.DeviceCounts, no copy in between)
     opts = [abi.ExecOptions(0, base, base, stream, flags, counts_dev[k].data_ptr()) for k in range(2)]
 
+    # the library's own communicator: rank 0 draws the id, torch.distributed (already up for the barriers) carries it to the others
+    comm, last_result, pending = None, [None], [0]
+    if distributed and args.comm == "c-abi" and args.backend == "nccl":
+        try:
+            id_t = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                id_t.copy_(torch.frombuffer(bytearray(be.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(id_t, 0)
+            comm = be.comm_create_rccl(rank, world, bytes(id_t.cpu().numpy().tobytes()))
+        except Exception as e:      # noqa: BLE001  (no RCCL to load, or the communicator could not be set up: the torch path still measures the step)
+            sys.stderr.write("rank %d: library communicator unavailable (%s); the exchange stays in torch.distributed\n" % (rank, e))
+            comm = None
+        ok = torch.tensor([1 if comm else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0 and comm:
+            be.comm_destroy(comm)
+            comm = None
+
     def step():
         k = steps_done[0] & 1
         steps_done[0] += 1
+        if comm:
+            # at most two exchanges in flight: the one of two steps ago is collected before the next is enqueued
+            if pending[0] == 2:
+                last_result[0] = be.exec_sharded_wait(comm)
+                pending[0] -= 1
+            be.exec_sharded_async(frame, opt, comm)
+            pending[0] += 1
+            return
         with torch.cuda.stream(torch_stream):
             if distributed:
                 # the path's one exchange: every rank's survivor count, for the global acquireindex offsets
@@ -216,9 +265,15 @@ def main():
                 dist.all_gather(parts, counts_dev[k].cpu())
                 gathered[k].copy_(torch.cat(parts))
 
+    def drain():
+        while comm and pending[0]:
+            last_result[0] = be.exec_sharded_wait(comm)
+            pending[0] -= 1
+
     for _ in range(args.warmup):
         step()
     survivors = state.finish(frame)
+    drain()
     torch.cuda.synchronize()
 
     state.enable_timing(True)
@@ -229,6 +284,7 @@ def main():
     for _ in range(args.steps):
         step()
     survivors = state.finish(frame)
+    drain()
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -240,10 +296,20 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        last = gathered[(steps_done[0] - 1) & 1].tolist()
-        offs = global_offsets(last)
-        assert last[rank] == survivors, (last, rank, survivors)
-        assert offs[rank] == sum(last[:rank])
+        if comm:
+            res = last_result[0]
+            assert res is not None and res.LocalSurvivors[0] == survivors, (rank, survivors)
+            # every rank's figures are consistent with the others': offsets are the running sum of the local counts in rank order
+            mine = torch.tensor([res.LocalSurvivors[0], res.GlobalOffset[0], res.GlobalSurvivors[0]], dtype=torch.int64, device=dev)
+            everyone = [torch.zeros(3, dtype=torch.int64, device=dev) for _ in range(world)]
+            dist.all_gather(everyone, mine)
+            rows = [e.tolist() for e in everyone]
+            assert all(rows[r][1] == sum(q[0] for q in rows[:r]) and rows[r][2] == sum(q[0] for q in rows) for r in range(world)), rows
+        else:
+            last = gathered[(steps_done[0] - 1) & 1].tolist()
+            offs = global_offsets(last)
+            assert last[rank] == survivors, (last, rank, survivors)
+            assert offs[rank] == sum(last[:rank])
 
     # what a plain device-to-device copy of the same sixteen streams sustains on this box, for scale (not a bound the kernel is
     # priced against: `peak` stays the HBM peak)
@@ -276,7 +342,8 @@ def main():
             "config": {"workload": "%s script (8 f32 streams in, 8 out, kill via acquireindex), %d particles per GPU, "
                                    "%.1f%% survive" % (args.workload, n, 100.0 * survivors / max(n, 1)),
                        "particles_per_gpu": n, "survivors_rank0": survivors, "instances_per_lane": state.last_exec_width(),
-                       "parallelism": "instance ranges sharded over %d GPU(s); all-gather of survivor counts" % world if distributed
+                       "parallelism": "instance ranges sharded over %d GPU(s); all-gather of survivor counts by %s" % (
+                           world, "the library's RCCL communicator (vvm_exec_sharded_async)" if comm else "torch.distributed") if distributed
                        else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": recorded_traffic(args.workload, n), "kernel": "vvm_exec_kernel", "kernel_ms": kernel_ms, "launches": launches,
@@ -286,8 +353,11 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
         elif world == 1:
             line["cpu_baseline"] = None
-        print(json.dumps(line), flush=True)
+        real_stdout.write(json.dumps(line) + "\n")
+        real_stdout.flush()
 
+    if comm:
+        be.comm_destroy(comm)
     state.close()
     if distributed:
         dist.destroy_process_group()

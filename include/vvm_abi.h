@@ -41,7 +41,7 @@ enum {
 	VVM_E_UNSUPPORTED_OP    = 4,
 	VVM_E_BAD_BLOB          = 5,
 	VVM_E_HIP               = 6,
-	VVM_E_RCCL              = 7,
+	VVM_E_RCCL              = 7,  /* the count exchange of a sharded Exec failed (RCCL, or the caller's all-gather callback) */
 	VVM_E_TOO_LARGE         = 8
 };
 
@@ -285,6 +285,42 @@ enum {
 VVM_API vvm_batch* vvm_batch_create(vvm_exec_context* ctxs, int32_t n, const vvm_exec_options* opts);
 VVM_API int        vvm_batch_exec(vvm_batch* batch, uint32_t changed);
 VVM_API void       vvm_batch_destroy(vvm_batch* batch);
+
+/* ---- instance ranges sharded over several GPUs (one process per GPU) ----
+ * Rank r of `world` holds a contiguous range of an Exec's instances in its own device memory and runs the Exec over it, with
+ * vvm_exec_options.ExecIndexBase = RandInstanceBase = the global index of the range's first instance, so that exec_index and the
+ * random draws do not depend on the sharding.  The ranks then exchange their survivor counts, 4 bytes per dataset and rank; the
+ * survivors stay where each rank wrote them, and the logical global array is the concatenation of the ranks' compacted prefixes
+ * in rank order, which is the reference's survivor order (VectorVMRuntime.cpp:786-804).  The context's DataSetAccessIndex holds
+ * the LOCAL count - 1 (what the rank's streams hold); vvm_shard_result holds the global figures.
+ * The communicator is either RCCL (librccl.so is loaded when the first one is created: rank 0 obtains an id with
+ * vvm_comm_unique_id, hands it to the other ranks by any means, and every rank calls vvm_comm_create_rccl with its device
+ * current), or a callback that gathers `count` ints per rank in rank order: with VVM_COMM_BUFFERS_HOST it receives host
+ * pointers and runs synchronously (stream = NULL), with VVM_COMM_BUFFERS_DEVICE device pointers and the stream to enqueue on.
+ * No counterpart in the reference: its Exec is one thread in one address space (VectorVMRuntime.cpp:2276-2295). */
+#define VVM_MAX_SHARD_DATASETS 8
+typedef struct vvm_comm vvm_comm;
+typedef int (*vvm_all_gather_fn)(void* user, const int32_t* send, int32_t* recv, int32_t count, void* stream);      /* 0 = success */
+enum { VVM_COMM_BUFFERS_HOST = 0, VVM_COMM_BUFFERS_DEVICE = 1 };
+typedef struct vvm_shard_result {
+	int32_t NumDataSets;
+	int32_t LocalSurvivors[VVM_MAX_SHARD_DATASETS];
+	int64_t GlobalOffset[VVM_MAX_SHARD_DATASETS];      /* survivors of the ranks before this one: where this rank's first survivor stands globally */
+	int64_t GlobalSurvivors[VVM_MAX_SHARD_DATASETS];   /* over all ranks; the global DataSetAccessIndex is this - 1 */
+} vvm_shard_result;
+VVM_API int       vvm_comm_unique_id(uint8_t* out_128_bytes);
+VVM_API vvm_comm* vvm_comm_create_rccl(int32_t rank, int32_t world, const uint8_t* unique_id_128_bytes);
+VVM_API vvm_comm* vvm_comm_create_callback(int32_t rank, int32_t world, vvm_all_gather_fn fn, void* user, int32_t where);
+VVM_API void      vvm_comm_destroy(vvm_comm* comm);
+/* One rank's part of a sharded Exec: vvm_exec_ex over the local range, then the exchange.  Synchronous. */
+VVM_API int vvm_exec_sharded(vvm_exec_context* ctx, const vvm_exec_options* opt, vvm_comm* comm, vvm_shard_result* out);
+/* The same in two halves, so that the exchange of one step runs (on the communicator's own stream) beside the next step's Exec:
+ * vvm_exec_sharded_async enqueues Exec and exchange (up to four exchanges may be pending), vvm_exec_sharded_wait blocks for the
+ * oldest pending exchange and returns its figures; the local results reach the context through vvm_exec_finish as usual. */
+VVM_API int vvm_exec_sharded_async(vvm_exec_context* ctx, const vvm_exec_options* opt, vvm_comm* comm);
+VVM_API int vvm_exec_sharded_wait(vvm_comm* comm, vvm_shard_result* out);
+/* The arithmetic of the exchange alone, no device involved: all_counts[r * num_datasets + d] = survivors of rank r in dataset d. */
+VVM_API int vvm_shard_offsets(int32_t rank, int32_t world, int32_t num_datasets, const int32_t* all_counts, vvm_shard_result* out);
 
 /* Device pointer (int32[MaxOutputDataSet]) to the survivor counts of the last vvm_exec* call made on this state
  * (the caller's vvm_exec_options.DeviceCounts when that was given); valid after the Exec's kernel has run on its

@@ -113,6 +113,16 @@ class ExecOptions(C.Structure):
                 ("Stream", C.c_void_p), ("Flags", C.c_uint32), ("DeviceCounts", C.c_void_p)]
 
 
+MAX_SHARD_DATASETS = 8
+VVM_COMM_BUFFERS_HOST, VVM_COMM_BUFFERS_DEVICE = 0, 1
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.c_void_p)
+
+
+class ShardResult(C.Structure):
+    _fields_ = [("NumDataSets", C.c_int32), ("LocalSurvivors", C.c_int32 * MAX_SHARD_DATASETS),
+                ("GlobalOffset", C.c_int64 * MAX_SHARD_DATASETS), ("GlobalSurvivors", C.c_int64 * MAX_SHARD_DATASETS)]
+
+
 class ProgramInfo(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in (
         "NumTempRegisters", "NumConstBuffers", "NumInputBuffers", "NumOutputBuffers", "NumInstructions",
@@ -271,6 +281,22 @@ class HipBackend(Backend):
         L.vvm_batch_exec.argtypes = [C.c_void_p, C.c_uint32]
         L.vvm_batch_destroy.restype = None
         L.vvm_batch_destroy.argtypes = [C.c_void_p]
+        L.vvm_comm_unique_id.restype = C.c_int
+        L.vvm_comm_unique_id.argtypes = [C.c_char_p]
+        L.vvm_comm_create_rccl.restype = C.c_void_p
+        L.vvm_comm_create_rccl.argtypes = [C.c_int32, C.c_int32, C.c_char_p]
+        L.vvm_comm_create_callback.restype = C.c_void_p
+        L.vvm_comm_create_callback.argtypes = [C.c_int32, C.c_int32, ALL_GATHER_FN, C.c_void_p, C.c_int32]
+        L.vvm_comm_destroy.restype = None
+        L.vvm_comm_destroy.argtypes = [C.c_void_p]
+        L.vvm_exec_sharded.restype = C.c_int
+        L.vvm_exec_sharded.argtypes = [C.POINTER(ExecContext), C.POINTER(ExecOptions), C.c_void_p, C.POINTER(ShardResult)]
+        L.vvm_exec_sharded_async.restype = C.c_int
+        L.vvm_exec_sharded_async.argtypes = [C.POINTER(ExecContext), C.POINTER(ExecOptions), C.c_void_p]
+        L.vvm_exec_sharded_wait.restype = C.c_int
+        L.vvm_exec_sharded_wait.argtypes = [C.c_void_p, C.POINTER(ShardResult)]
+        L.vvm_shard_offsets.restype = C.c_int
+        L.vvm_shard_offsets.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(ShardResult)]
         L.vvm_state_device_counts.restype = C.c_void_p
         L.vvm_state_device_counts.argtypes = [C.c_void_p]
         L.vvm_state_max_output_dataset.restype = C.c_int32
@@ -357,6 +383,49 @@ class HipBackend(Backend):
 
     def batch_destroy(self, handle: int) -> None:
         self.lib.vvm_batch_destroy(handle)
+
+    # ---- sharded Execs (include/vvm_abi.h: "instance ranges sharded over several GPUs") ----
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        self._check(self.lib.vvm_comm_unique_id(buf), "vvm_comm_unique_id")
+        return buf.raw
+
+    def comm_create_rccl(self, rank: int, world: int, unique_id: bytes) -> int:
+        h = self.lib.vvm_comm_create_rccl(rank, world, unique_id)
+        if not h:
+            raise VVMError(VVM_E_RCCL, "vvm_comm_create_rccl", self.error_text())
+        return h
+
+    def comm_create_callback(self, rank: int, world: int, fn, where: int = VVM_COMM_BUFFERS_HOST):
+        """fn(send, recv, count, stream) -> 0 on success; send / recv are ctypes int32 pointers.  Returns (handle, keepalive)."""
+        cb = ALL_GATHER_FN(lambda user, send, recv, count, stream: fn(send, recv, count, stream))
+        h = self.lib.vvm_comm_create_callback(rank, world, cb, None, where)
+        if not h:
+            raise VVMError(VVM_E_INVALID_ARG, "vvm_comm_create_callback", self.error_text())
+        return h, cb
+
+    def comm_destroy(self, comm: int) -> None:
+        self.lib.vvm_comm_destroy(comm)
+
+    def exec_sharded(self, frame: CallFrame, opt: Optional[ExecOptions], comm: int) -> ShardResult:
+        out = ShardResult()
+        self._check(self.lib.vvm_exec_sharded(C.byref(frame.ctx), C.byref(opt) if opt is not None else None, comm, C.byref(out)), "vvm_exec_sharded")
+        return out
+
+    def exec_sharded_async(self, frame: CallFrame, opt: Optional[ExecOptions], comm: int) -> None:
+        self._check(self.lib.vvm_exec_sharded_async(C.byref(frame.ctx), C.byref(opt) if opt is not None else None, comm), "vvm_exec_sharded_async")
+
+    def exec_sharded_wait(self, comm: int) -> ShardResult:
+        out = ShardResult()
+        self._check(self.lib.vvm_exec_sharded_wait(comm, C.byref(out)), "vvm_exec_sharded_wait")
+        return out
+
+    def shard_offsets(self, rank: int, world: int, num_datasets: int, all_counts: Sequence[int]) -> ShardResult:
+        """The arithmetic of the count exchange (no device): all_counts[r * num_datasets + d]."""
+        arr = (C.c_int32 * max(1, len(all_counts)))(*all_counts)
+        out = ShardResult()
+        self._check(self.lib.vvm_shard_offsets(rank, world, num_datasets, arr, C.byref(out)), "vvm_shard_offsets")
+        return out
 
     def inspect_blob(self, blob: bytes) -> ProgramInfo:
         """Thaw + link only (no device needed); raises VVMError with the linker's message on a bad script."""

@@ -1407,3 +1407,237 @@ VVM_API int vvm_state_copy_counts(vvm_state* st, void* dst_device, void* stream)
 }
 
 }  // extern "C"
+
+// --- instance ranges sharded over several GPUs -----------------------------------------------------------
+// One process per GPU; every rank runs one Exec over its contiguous range of instances, and the ranks exchange their survivor
+// counts (4 bytes per dataset and rank): the global output position of rank r's survivors is the sum of the counts of the ranks
+// before it, because concatenating stable compactions of contiguous ranges in range order is the stable compaction of the
+// whole (VectorVMRuntime.cpp:786-804 keeps instance order).  The payload never moves.  The reference has no counterpart: its
+// Exec is one thread in one address space.
+#include <dlfcn.h>
+
+namespace {
+struct vvm_nccl_id { char internal[128]; };      // ncclUniqueId
+// RCCL is loaded on demand and by name: a process that has PyTorch loaded binds to the copy PyTorch brought (same soname),
+// any other process to the system's; this library links against neither.
+struct RcclApi {
+	void* handle = nullptr;
+	int (*get_unique_id)(vvm_nccl_id*) = nullptr;
+	int (*comm_init_rank)(void**, int, vvm_nccl_id, int) = nullptr;
+	int (*all_gather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+	int (*comm_destroy)(void*) = nullptr;
+	const char* (*get_error_string)(int) = nullptr;
+};
+RcclApi g_rccl;
+std::mutex g_rccl_mutex;
+
+int load_rccl()
+{
+	std::lock_guard<std::mutex> lock(g_rccl_mutex);
+	if (g_rccl.handle) return VVM_OK;
+	void* h = nullptr;
+	for (const char* name : {"librccl.so.1", "librccl.so"}) {
+		h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+		if (h) break;
+	}
+	if (!h) return fail(VVM_E_RCCL, std::string("librccl.so could not be loaded: ") + (dlerror() ? dlerror() : "?"));
+	RcclApi api;
+	api.handle = h;
+	api.get_unique_id = (int (*)(vvm_nccl_id*))dlsym(h, "ncclGetUniqueId");
+	api.comm_init_rank = (int (*)(void**, int, vvm_nccl_id, int))dlsym(h, "ncclCommInitRank");
+	api.all_gather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(h, "ncclAllGather");
+	api.comm_destroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+	api.get_error_string = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+	if (!api.get_unique_id || !api.comm_init_rank || !api.all_gather || !api.comm_destroy) return fail(VVM_E_RCCL, "librccl.so lacks an entry point this library needs");
+	g_rccl = api;
+	return VVM_OK;
+}
+int rccl_fail(int code, const char* where)
+{
+	return fail(VVM_E_RCCL, std::string(where) + ": " + (g_rccl.get_error_string ? g_rccl.get_error_string(code) : "error") );
+}
+constexpr int kCommSlots = 4;       // exchanges that may be pending at once
+constexpr int kNcclInt32 = 2;       // ncclInt32
+}  // namespace
+
+struct vvm_comm {
+	int32_t rank = 0, world = 1;
+	int device = -1;
+	void* nccl = nullptr;                    // ncclComm_t, or null for the callback forms
+	vvm_all_gather_fn fn = nullptr; void* user = nullptr; int32_t where = VVM_COMM_BUFFERS_HOST;
+	hipStream_t stream = nullptr;            // the exchanges run here, beside the next Exec
+	int32_t* d_send = nullptr;               // [slot][VVM_MAX_SHARD_DATASETS]
+	int32_t* d_recv = nullptr;               // [slot][world][VVM_MAX_SHARD_DATASETS]
+	int32_t* h_send = nullptr; int32_t* h_recv = nullptr;      // pinned twins
+	hipEvent_t counted[kCommSlots] = {}, exchanged[kCommSlots] = {};
+	int32_t slot_datasets[kCommSlots] = {};
+	uint64_t issued = 0, waited = 0;          // exchanges enqueued / handed out so far
+};
+
+namespace {
+vvm_comm* comm_create_common(int32_t rank, int32_t world)
+{
+	if (world < 1 || rank < 0 || rank >= world) { fail(VVM_E_INVALID_ARG, "bad rank / world"); return nullptr; }
+	if (ensure_device_info() != VVM_OK) return nullptr;
+	vvm_comm* c = new vvm_comm();
+	c->rank = rank; c->world = world;
+	auto bail = [&](hipError_t e, const char* where) -> vvm_comm* { hip_fail(e, where); vvm_comm_destroy(c); return nullptr; };
+	hipError_t e;
+	if ((e = hipGetDevice(&c->device)) != hipSuccess) return bail(e, "hipGetDevice");
+	const size_t send_words = (size_t)kCommSlots * VVM_MAX_SHARD_DATASETS, recv_words = send_words * (size_t)world;
+	if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+	if ((e = hipMalloc((void**)&c->d_send, send_words * 4)) != hipSuccess) return bail(e, "hipMalloc");
+	if ((e = hipMalloc((void**)&c->d_recv, recv_words * 4)) != hipSuccess) return bail(e, "hipMalloc");
+	if ((e = hipMemset(c->d_send, 0, send_words * 4)) != hipSuccess) return bail(e, "hipMemset");
+	if ((e = hipMemset(c->d_recv, 0, recv_words * 4)) != hipSuccess) return bail(e, "hipMemset");
+	if ((e = hipHostMalloc((void**)&c->h_send, send_words * 4, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
+	if ((e = hipHostMalloc((void**)&c->h_recv, recv_words * 4, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
+	for (int k = 0; k < kCommSlots; ++k) {
+		if ((e = hipEventCreateWithFlags(&c->counted[k], hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+		if ((e = hipEventCreateWithFlags(&c->exchanged[k], hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+	}
+	return c;
+}
+}  // namespace
+
+extern "C" {
+
+VVM_API int vvm_shard_offsets(int32_t rank, int32_t world, int32_t num_datasets, const int32_t* all_counts, vvm_shard_result* out)
+{
+	if (!all_counts || !out || world < 1 || rank < 0 || rank >= world || num_datasets < 0 || num_datasets > VVM_MAX_SHARD_DATASETS)
+		return fail(VVM_E_INVALID_ARG, "bad arguments to vvm_shard_offsets");
+	memset(out, 0, sizeof(*out));
+	out->NumDataSets = num_datasets;
+	for (int32_t d = 0; d < num_datasets; ++d) {
+		int64_t before = 0, total = 0;
+		for (int32_t r = 0; r < world; ++r) {
+			const int32_t c = all_counts[(size_t)r * (size_t)num_datasets + (size_t)d];
+			if (c < 0) return fail(VVM_E_INVALID_ARG, "negative survivor count");
+			if (r < rank) before += c;
+			total += c;
+		}
+		out->LocalSurvivors[d] = all_counts[(size_t)rank * (size_t)num_datasets + (size_t)d];
+		out->GlobalOffset[d] = before;
+		out->GlobalSurvivors[d] = total;
+	}
+	return VVM_OK;
+}
+
+VVM_API int vvm_comm_unique_id(uint8_t* out_128_bytes)
+{
+	if (!out_128_bytes) return fail(VVM_E_INVALID_ARG, "null argument");
+	int rc = load_rccl();
+	if (rc != VVM_OK) return rc;
+	vvm_nccl_id id;
+	memset(&id, 0, sizeof id);
+	const int n = g_rccl.get_unique_id(&id);
+	if (n != 0) return rccl_fail(n, "ncclGetUniqueId");
+	memcpy(out_128_bytes, &id, sizeof id);
+	return VVM_OK;
+}
+
+VVM_API vvm_comm* vvm_comm_create_rccl(int32_t rank, int32_t world, const uint8_t* unique_id_128_bytes)
+{
+	if (!unique_id_128_bytes) { fail(VVM_E_INVALID_ARG, "null unique id"); return nullptr; }
+	if (load_rccl() != VVM_OK) return nullptr;
+	vvm_comm* c = comm_create_common(rank, world);
+	if (!c) return nullptr;
+	vvm_nccl_id id;
+	memcpy(&id, unique_id_128_bytes, sizeof id);
+	const int n = g_rccl.comm_init_rank(&c->nccl, world, id, rank);
+	if (n != 0) { rccl_fail(n, "ncclCommInitRank"); c->nccl = nullptr; vvm_comm_destroy(c); return nullptr; }
+	return c;
+}
+
+VVM_API vvm_comm* vvm_comm_create_callback(int32_t rank, int32_t world, vvm_all_gather_fn fn, void* user, int32_t where)
+{
+	if (!fn || (where != VVM_COMM_BUFFERS_HOST && where != VVM_COMM_BUFFERS_DEVICE)) { fail(VVM_E_INVALID_ARG, "bad all-gather callback"); return nullptr; }
+	vvm_comm* c = comm_create_common(rank, world);
+	if (!c) return nullptr;
+	c->fn = fn; c->user = user; c->where = where;
+	return c;
+}
+
+VVM_API void vvm_comm_destroy(vvm_comm* c)
+{
+	if (!c) return;
+	if (c->stream) (void)hipStreamSynchronize(c->stream);
+	if (c->nccl && g_rccl.comm_destroy) (void)g_rccl.comm_destroy(c->nccl);
+	if (c->d_send) (void)hipFree(c->d_send);
+	if (c->d_recv) (void)hipFree(c->d_recv);
+	if (c->h_send) (void)hipHostFree(c->h_send);
+	if (c->h_recv) (void)hipHostFree(c->h_recv);
+	for (int k = 0; k < kCommSlots; ++k) {
+		if (c->counted[k]) (void)hipEventDestroy(c->counted[k]);
+		if (c->exchanged[k]) (void)hipEventDestroy(c->exchanged[k]);
+	}
+	if (c->stream) (void)hipStreamDestroy(c->stream);
+	delete c;
+}
+
+VVM_API int vvm_exec_sharded_async(vvm_exec_context* ctx, const vvm_exec_options* opt, vvm_comm* c)
+{
+	if (!ctx || !ctx->VVMState || !c) return fail(VVM_E_INVALID_ARG, "null context, state or communicator");
+	vvm_state* st = ctx->VVMState;
+	if (st->device != c->device) return fail(VVM_E_INVALID_ARG, "the state and the communicator belong to different devices");
+	if (st->any_ids) return fail(VVM_E_UNSUPPORTED_OP, "scripts with update_id / acquire_id are not sharded: their ID tables are not coordinated between ranks");
+	const int32_t nds = (int32_t)std::max<uint32_t>(st->script.max_output_dataset, 1);
+	if (nds > VVM_MAX_SHARD_DATASETS) return fail(VVM_E_TOO_LARGE, "more output datasets than a sharded Exec exchanges counts for");
+	if (c->issued - c->waited >= (uint64_t)kCommSlots) return fail(VVM_E_INVALID_ARG, "too many exchanges pending: call vvm_exec_sharded_wait");
+	const int k = (int)(c->issued % kCommSlots);
+	int32_t* const d_send = c->d_send + (size_t)k * VVM_MAX_SHARD_DATASETS;
+	int32_t* const d_recv = c->d_recv + (size_t)k * VVM_MAX_SHARD_DATASETS * (size_t)c->world;
+	int32_t* const h_send = c->h_send + (size_t)k * VVM_MAX_SHARD_DATASETS;
+	int32_t* const h_recv = c->h_recv + (size_t)k * VVM_MAX_SHARD_DATASETS * (size_t)c->world;
+	// the Exec leaves its counts where the exchange reads them
+	vvm_exec_options o = opt ? *opt : vvm_exec_options{};
+	o.DeviceCounts = d_send;
+	int rc = vvm_exec_async(ctx, &o);
+	if (rc != VVM_OK) return rc;
+	hipStream_t exec_stream = st->last_stream;
+	c->slot_datasets[k] = nds;
+	if (c->fn && c->where == VVM_COMM_BUFFERS_HOST) {
+		// a host-side exchange (another transport, a test): the counts come to the host first; the call returns when the exchange is done
+		HIP_TRY(hipMemcpyAsync(h_send, d_send, (size_t)nds * 4, hipMemcpyDeviceToHost, exec_stream));
+		HIP_TRY(hipStreamSynchronize(exec_stream));
+		rc = c->fn(c->user, h_send, h_recv, nds, nullptr);
+		if (rc != 0) return fail(VVM_E_RCCL, "the all-gather callback reported a failure");
+		HIP_TRY(hipEventRecord(c->exchanged[k], c->stream));
+	} else {
+		HIP_TRY(hipEventRecord(c->counted[k], exec_stream));
+		HIP_TRY(hipStreamWaitEvent(c->stream, c->counted[k], 0));
+		if (c->fn) {
+			rc = c->fn(c->user, d_send, d_recv, nds, (void*)c->stream);
+			if (rc != 0) return fail(VVM_E_RCCL, "the all-gather callback reported a failure");
+		} else {
+			const int n = g_rccl.all_gather(d_send, d_recv, (size_t)nds, kNcclInt32, c->nccl, c->stream);
+			if (n != 0) return rccl_fail(n, "ncclAllGather");
+		}
+		HIP_TRY(hipMemcpyAsync(h_recv, d_recv, (size_t)nds * (size_t)c->world * 4, hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(hipEventRecord(c->exchanged[k], c->stream));
+	}
+	c->issued++;
+	return VVM_OK;
+}
+
+VVM_API int vvm_exec_sharded_wait(vvm_comm* c, vvm_shard_result* out)
+{
+	if (!c || !out) return fail(VVM_E_INVALID_ARG, "null argument");
+	if (c->waited == c->issued) return fail(VVM_E_INVALID_ARG, "no exchange is pending");
+	const int k = (int)(c->waited % kCommSlots);
+	HIP_TRY(hipEventSynchronize(c->exchanged[k]));
+	c->waited++;
+	return vvm_shard_offsets(c->rank, c->world, c->slot_datasets[k], c->h_recv + (size_t)k * VVM_MAX_SHARD_DATASETS * (size_t)c->world, out);
+}
+
+VVM_API int vvm_exec_sharded(vvm_exec_context* ctx, const vvm_exec_options* opt, vvm_comm* c, vvm_shard_result* out)
+{
+	if (c && c->issued != c->waited) return fail(VVM_E_INVALID_ARG, "earlier exchanges are still pending: call vvm_exec_sharded_wait first");
+	int rc = vvm_exec_sharded_async(ctx, opt, c);
+	if (rc != VVM_OK) return rc;
+	rc = vvm_exec_finish(ctx);
+	if (rc != VVM_OK) return rc;
+	return vvm_exec_sharded_wait(c, out);
+}
+
+}  // extern "C"

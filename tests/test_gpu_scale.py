@@ -146,3 +146,124 @@ def test_two_large_execs_of_different_states_in_flight_together():
     finally:
         for st in states:
             st.close()
+
+
+# ---- the C ABI's sharded Exec ----------------------------------------------------------------------------------------------------------
+class _Shard:
+    """One rank's streams of _script_with_index_and_random on the device, and its call frame."""
+
+    def __init__(self, be, built, age, life, lo, hi):
+        from vm_harness import PAD as pad
+        self.be, self.m = be, hi - lo
+        self.ptrs = []
+        ins = []
+        for a in (age, life):
+            buf = np.zeros(max(self.m, 1) + pad, f32)
+            buf[:self.m] = a[lo:hi]
+            p = be.lib.vvm_device_alloc(buf.nbytes)
+            assert p
+            be._check(be.lib.vvm_device_upload(p, buf.ctypes.data, buf.nbytes), "upload")
+            ins.append(p)
+        self.out_bytes = (max(self.m, 1) + pad) * 4
+        outs = []
+        for _ in range(3):
+            p = be.lib.vvm_device_alloc(self.out_bytes)
+            assert p
+            be._check(be.lib.vvm_device_memset(p, 0xCD, self.out_bytes), "memset")
+            outs.append(p)
+        self.ptrs = ins + outs
+        self.outs = outs
+        self.state = VectorVMState(built.blob, be)
+        # (streams ordered float, float | float, float, int32)
+        self.frame = self.state.frame([abi.DataSet(ins, [outs[0], outs[1], outs[2]], 0, [0, 2, 2], [0, 2, 3])], self.m, [bytes(16)])
+        self.opt = abi.ExecOptions(77, lo, lo, None, 0)
+
+    def download(self, k, count, dtype):
+        h = np.empty(self.out_bytes // 4, dtype)
+        self.be._check(self.be.lib.vvm_device_download(h.ctypes.data, self.outs[k], self.out_bytes), "download")
+        return h[:count]
+
+    def free(self):
+        self.state.close()
+        for p in self.ptrs:
+            self.be.lib.vvm_device_free(p)
+
+
+def test_exec_sharded_with_a_host_all_gather_callback():
+    """vvm_exec_sharded with the callback form, two ranks rehearsed one after the other on device 0: the callback checks what the
+    rank sends and supplies both ranks' counts (known from the oracle); the library's figures and the concatenated survivor
+    prefixes must equal one Exec over all instances."""
+    be = abi.load_hip_backend()
+    built = _script_with_index_and_random()
+    n, world = 200_001, 2
+    age = scripts.u01_np(0, n, 3).astype(f32)
+    life = np.full(n, 0.5, f32)
+    ref, ref_n, _ = run_oracle(built, [bytes(16)], [age, life], [f32, f32, np.int32], n, seed=77)
+    ranges = [shard_range(n, r, world) for r in range(world)]
+    want = [int((age[lo:hi] < 0.5).sum()) for lo, hi in ranges]
+    assert sum(want) == ref_n
+    pieces = []
+    for rank, (lo, hi) in enumerate(ranges):
+        sh = _Shard(be, built, age, life, lo, hi)
+        sent = []
+
+        def gather(send, recv, count, stream, rank=rank):
+            assert count == 1 and not stream
+            sent.append(send[0])
+            for r in range(world):
+                recv[r] = want[r]
+            return 0
+
+        comm, keep = be.comm_create_callback(rank, world, gather, abi.VVM_COMM_BUFFERS_HOST)
+        try:
+            res = be.exec_sharded(sh.frame, sh.opt, comm)
+            assert sent == [want[rank]]
+            assert (res.NumDataSets, res.LocalSurvivors[0], res.GlobalOffset[0], res.GlobalSurvivors[0]) == (1, want[rank], sum(want[:rank]), ref_n)
+            assert sh.frame.survivors(0) == want[rank]          # the context holds the local count
+            pieces.append([sh.download(k, want[rank], dt) for k, dt in enumerate((f32, f32, np.int32))])
+        finally:
+            be.comm_destroy(comm)
+            sh.free()
+    for k in range(3):
+        joined = np.concatenate([p[k] for p in pieces])
+        assert np.array_equal(_bits(joined), _bits(ref[k][:ref_n])), "output %d" % k
+
+
+def test_exec_sharded_over_rccl_and_a_device_callback_with_one_rank():
+    """The two device-side forms with world size 1 (all a one-GPU box can hold): RCCL loaded on demand with a communicator of one
+    rank, and a device callback that copies send to recv on the stream it is given.  Three pipelined steps each."""
+    import ctypes
+    be = abi.load_hip_backend()
+    built = _script_with_index_and_random()
+    n = 150_000
+    age = scripts.u01_np(0, n, 3).astype(f32)
+    life = np.full(n, 0.5, f32)
+    want = int((age < 0.5).sum())
+    hip = ctypes.CDLL("libamdhip64.so")          # (the copy the process already has loaded)
+    hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+    hip.hipMemcpyAsync.restype = ctypes.c_int
+
+    def device_gather(send, recv, count, stream):
+        assert stream
+        return hip.hipMemcpyAsync(ctypes.cast(recv, ctypes.c_void_p), ctypes.cast(send, ctypes.c_void_p), 4 * count, 3, stream)      # device to device
+
+    comm_cb, keep = be.comm_create_callback(0, 1, device_gather, abi.VVM_COMM_BUFFERS_DEVICE)
+    comm_rccl = be.comm_create_rccl(0, 1, be.comm_unique_id())
+    sh = _Shard(be, built, age, life, 0, n)
+    try:
+        for comm in (comm_cb, comm_rccl):
+            for _ in range(3):
+                be.exec_sharded_async(sh.frame, sh.opt, comm)
+            for _ in range(3):
+                res = be.exec_sharded_wait(comm)
+                assert (res.LocalSurvivors[0], res.GlobalOffset[0], res.GlobalSurvivors[0]) == (want, 0, want)
+            be.exec_finish(sh.frame)
+            assert sh.frame.survivors(0) == want
+            with pytest.raises(abi.VVMError):
+                be.exec_sharded_wait(comm)          # nothing pending
+            res = be.exec_sharded(sh.frame, sh.opt, comm)
+            assert res.GlobalSurvivors[0] == want
+    finally:
+        be.comm_destroy(comm_cb)
+        be.comm_destroy(comm_rccl)
+        sh.free()

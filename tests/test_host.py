@@ -444,3 +444,22 @@ def test_product_path_has_no_cpu_fallback():
         assert "no CPU fallback" in str(e.value)
     finally:
         abi._HIP_LIB_PATH, abi._hip_backend = real_path, real_backend
+
+
+def test_shard_offsets_arithmetic():
+    """vvm_shard_offsets: exclusive prefix over ranks and totals, per dataset (no device involved)."""
+    be = abi.load_hip_backend()
+    counts = [5, 0, 7,   0, 2, 1,   9, 9, 0]          # three ranks, three datasets
+    for rank in range(3):
+        r = be.shard_offsets(rank, 3, 3, counts)
+        assert r.NumDataSets == 3
+        for d in range(3):
+            assert r.LocalSurvivors[d] == counts[rank * 3 + d]
+            assert r.GlobalOffset[d] == sum(counts[q * 3 + d] for q in range(rank))
+            assert r.GlobalSurvivors[d] == sum(counts[q * 3 + d] for q in range(3))
+    with pytest.raises(abi.VVMError):
+        be.shard_offsets(3, 3, 3, counts)
+    with pytest.raises(abi.VVMError):
+        be.shard_offsets(0, 1, 9, [0] * 9)
+    with pytest.raises(abi.VVMError):
+        be.shard_offsets(0, 2, 1, [1, -1])

@@ -70,6 +70,11 @@ def _worker(rank, world, port, n, q):
             return [int(x.item()) for x in t]
 
         info = ShardedExec(rank, world, local_exec, all_gather).run(n)
+        # the same figures from the C ABI's own arithmetic (vvm_shard_offsets of libvvm_hip.so, the part of vvm_exec_sharded that
+        # needs no device), fed with what this rank gathered
+        from renderer_amd import abi
+        res = abi.load_hip_backend().shard_offsets(rank, world, 1, info["counts"])
+        info["c_abi"] = (int(res.LocalSurvivors[0]), int(res.GlobalOffset[0]), int(res.GlobalSurvivors[0]))
         q.put((rank, info, [o.tobytes() for o in result["outs"]]))
     finally:
         dist.destroy_process_group()
@@ -103,6 +108,8 @@ def test_two_rank_sharded_exec_matches_single_exec(n):
     assert infos[0]["dataset_access_index"] == ref_n - 1
     assert infos[0]["global_offset"] == 0 and infos[1]["global_offset"] == infos[0]["local_survivors"]
     assert infos[0]["range"][1] == infos[1]["range"][0]
+    for info in infos:
+        assert info["c_abi"] == (info["local_survivors"], info["global_offset"], info["global_survivors"])
     for k in range(3):
         joined = b"".join(g[2][k] for g in got)
         assert joined == ref[k][:ref_n].tobytes(), "output %d differs from the single Exec" % k
