@@ -140,6 +140,7 @@ def main():
     ap.add_argument("--workload", default="fountain", choices=["fountain", "fountain_kill_half"])
     ap.add_argument("--particles", type=int, default=64 * 1024 * 1024, help="instances per GPU")
     ap.add_argument("--width", default="auto", choices=["auto", "4", "8"], help="instances per lane of the kernel (auto: the library's choice)")
+    ap.add_argument("--no-light", action="store_true", help="keep the eight-wide Exec on the general kernel (comparison)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse the multi-rank path on one GPU: all ranks then share device 0)")
     ap.add_argument("--collective-at-one", action="store_true",
@@ -200,7 +201,7 @@ def main():
     # the library, which the collective does not wait for.)
     torch_stream = torch.cuda.Stream(device=dev)
     stream = torch_stream.cuda_stream
-    flags = {"auto": 0, "4": abi.VVM_EXEC_NO_EIGHT_WIDE, "8": abi.VVM_EXEC_FORCE_EIGHT_WIDE}[args.width]
+    flags = {"auto": 0, "4": abi.VVM_EXEC_NO_EIGHT_WIDE, "8": abi.VVM_EXEC_FORCE_EIGHT_WIDE}[args.width] | (abi.VVM_EXEC_NO_LIGHT_KERNEL if args.no_light else 0)
     base = first if first < 2 ** 31 else 0
     opt = abi.ExecOptions(0, base, base, stream, flags)
     # The exchange of a step runs beside the next step's Exec: the Exec writes its count into the step's buffer, the all-gather waits

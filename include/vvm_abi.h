@@ -213,7 +213,11 @@ enum {
 	/* The per-Exec parameter block (descriptor, constants, stream addresses) of a single Exec normally reaches the kernel as a
 	 * kernel argument when it fits 1 KB, and otherwise through a host-to-device copy enqueued ahead of the launch.  This flag
 	 * takes the copy whatever the size (tests / comparison; the environment variable VVM_NO_INLINE_PARAMS does the same). */
-	VVM_EXEC_PARAMS_IN_MEMORY = 1u << 3
+	VVM_EXEC_PARAMS_IN_MEMORY = 1u << 3,
+	/* Scripts that need no more than eight per-lane registers run their eight-wide Execs on a kernel with a smaller register
+	 * file, of which three workgroups fit a CU instead of two.  This flag keeps them on the general eight-wide kernel (tests /
+	 * comparison).  The results are the same either way. */
+	VVM_EXEC_NO_LIGHT_KERNEL = 1u << 4
 };
 #define VVM_EIGHT_WIDE_MIN_INSTANCES (256 * 1024)
 

@@ -8,7 +8,9 @@
 #pragma once
 #include <stdint.h>
 
+#ifndef VVM_BLOCK_THREADS
 #define VVM_BLOCK_THREADS 256
+#endif
 
 // ---- operand = class (3 bits) | index (13 bits) ----
 enum : uint32_t {
@@ -31,7 +33,8 @@ enum : uint32_t {
 	VVM_DOP_LOADN16 = 190, // the same for 16-bit streams: the raw bits, zero-extended
 	VVM_DOP_LOADN  = 191,  // load up to 8 32-bit input streams into consecutive virtual registers (program prologue only):
 	                       // aux = count, aux2 = first register, w1 = first slot of VvmExecDesc::load_ptrs
-	VVM_DOP_ACQUIRE = 192, // acquireindex; every opcode from here on produces no register result
+	VVM_DOP_ACQUIRE = 192, // acquireindex: aux = dataset, o0 = predicate (keep = its sign bit, aux2 = VVM_ACQ_SIGN), or, with the compare that
+	                       // made the predicate folded in, keep = o0 <aux2> o1; every opcode from here on produces no register result
 	VVM_DOP_OUTPUT32 = 193, // up to 3 (src,dst) pairs of outputdata_float / outputdata_int32: aux = count, aux2 = dataset,
 	                        // o0..o2 = sources, w3 = the first pair's slot of VvmExecDesc::out_list (the pairs of one
 	                        // instruction lie in one group of VVM_STAGE_SLOTS slots)
@@ -43,8 +46,17 @@ enum : uint32_t {
 	                        // output (one slot, all instances of the tile), applied to the ID tables when the tile's position is known
 };
 
+// acquireindex's aux2: how the keep bit is formed
+enum : uint32_t {
+	VVM_ACQ_SIGN = 0,
+	VVM_ACQ_LT = 1, VVM_ACQ_LE, VVM_ACQ_GT, VVM_ACQ_GE, VVM_ACQ_EQ, VVM_ACQ_NE,          // float compares (VectorVMRuntime.cpp:1942-1947)
+	VVM_ACQ_LTI, VVM_ACQ_LEI, VVM_ACQ_GTI, VVM_ACQ_GEI, VVM_ACQ_EQI, VVM_ACQ_NEI       // signed integer compares (:1960-1965)
+};
+
 // Output values wait in LDS staging slots until the tile's output position is known; one group of slots is written out at a time.
 #define VVM_STAGE_SLOTS 8
+// the light eight-wide kernel has six staging slots: its programs use the first six entries of every group of eight
+#define VVM_LIGHT_GROUP_SLOTS 6
 // entry of VvmExecDesc::out_list: byte address in the low 48 bits (0 = nothing is written), flags above
 #define VVM_OUT_IS16 (1ull << 62)         // the destination stream has 16-bit elements
 #define VVM_OUT_GROUP16 (1ull << 61)      // on a group's first entry: some entry of the group has VVM_OUT_IS16 or VVM_OUT_UPDATE_ID

@@ -134,6 +134,9 @@ struct vvm_state {
 	vvm::ThawedScript script;
 	vvm::LinkedProgram wide, narrow;       // narrow is linked on demand (VVM_EXEC_NO_VGPR_WIDE)
 	bool narrow_ready = false;
+	vvm::LinkedProgram light;              // the script linked for the light eight-wide kernel, when it fits (linked at vvm_alloc_state)
+	bool light_ready = false;
+	VvmIns* d_code_light = nullptr;
 	// a script with acquireindex on several datasets runs one pass per dataset: the programs of passes 1.. (pass 0 = wide / narrow)
 	std::vector<vvm::LinkedProgram> wide_more, narrow_more;
 	std::vector<VvmIns*> d_code_wide_more, d_code_narrow_more;
@@ -237,6 +240,8 @@ struct PreparedExec {
 	size_t off_consts = 0, off_in = 0, off_load = 0, off_out = 0, off_ids = 0;
 	uint32_t chunk_instances = 0, num_chunks = 0;      // the reference's chunking of this Exec
 	uint32_t instances_per_lane = 4;                   // of the kernel this Exec runs on (8, 4 or 1)
+	bool light = false;                                // ... the light eight-wide kernel
+	bool launch_many() const { return light || lp->many_registers; }      // what vvm_launch_exec_kernel takes as many_registers
 };
 
 int g_page_kb = 64;      // vm.PageSizeInKB, VectorVMRuntime.cpp:44-50
@@ -333,7 +338,11 @@ int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, P
 		const bool can = pe.lp->instances_per_lane == 4 && !pe.lp->full_kernel && !pe.lp->many_registers && !(flags & VVM_EXEC_NO_EIGHT_WIDE);
 		// (the size of the Exec itself decides, also inside a batch: many small Execs measured faster four wide, 0.88 ms against
 		// 0.92 ms for 4096 Execs of 16 Ki instances)
-		if (can && (ctx->NumInstances >= VVM_EIGHT_WIDE_MIN_INSTANCES || (flags & VVM_EXEC_FORCE_EIGHT_WIDE))) pe.instances_per_lane = 8;
+		if (can && (ctx->NumInstances >= VVM_EIGHT_WIDE_MIN_INSTANCES || (flags & VVM_EXEC_FORCE_EIGHT_WIDE))) {
+			pe.instances_per_lane = 8;
+			// scripts that get by with eight registers have a program for the light eight-wide kernel (three workgroups per CU)
+			if (st->light_ready && pass == 0 && !narrow && !(flags & VVM_EXEC_NO_LIGHT_KERNEL)) { pe.lp = &st->light; pe.d_code = st->d_code_light; pe.light = true; }
+		}
 	}
 	const uint32_t tile = VVM_BLOCK_THREADS * pe.instances_per_lane;
 	pe.tiles = ((uint32_t)ctx->NumInstances + tile - 1) / tile;
@@ -499,8 +508,11 @@ hipError_t reset_launch_state(VvmLaunchState* d)
 // Persistent workgroups: as many as can be resident (workgroups per CU by the kernel's register budget), never more than tiles.
 uint32_t grid_for(uint32_t tiles, uint32_t instances_per_lane, bool full, bool many_registers)
 {
-	const uint32_t per_cu = (instances_per_lane == 8 || (instances_per_lane == 4 && many_registers)) ? 2u : full ? 3u : instances_per_lane == 4 ? 4u : 8u;
-	return std::max<uint32_t>(1, std::min<uint32_t>(tiles, (uint32_t)g_dev.num_cus * per_cu));
+	// (eight instances per lane with many_registers set: the light kernel, three workgroups per CU)
+	uint32_t per_cu = (instances_per_lane == 8 && many_registers) ? 3u : (instances_per_lane == 8 || (instances_per_lane == 4 && many_registers)) ? 2u : full ? 3u : instances_per_lane == 4 ? 4u : 8u;
+	static const uint32_t forced = getenv("VVM_DEBUG_WG_PER_CU") ? (uint32_t)atoi(getenv("VVM_DEBUG_WG_PER_CU")) : 0u;      // (measurement aid)
+	if (forced) per_cu = std::min(per_cu, forced);
+	return std::max<uint32_t>(1, std::min<uint32_t>(tiles, (uint32_t)g_dev.num_cus * per_cu * (256u / VVM_BLOCK_THREADS)));
 }
 
 int write_back_counts(vvm_state* st, vvm_exec_context* ctx, bool ran_kernel)
@@ -535,6 +547,13 @@ VVM_API vvm_state* vvm_alloc_state(const uint8_t* blob, size_t num_bytes)
 	if (hipGetDevice(&st->device) != hipSuccess) { fail(VVM_E_HIP, "hipGetDevice"); vvm_free_state(st); return nullptr; }
 	if (upload_code(st->wide, &st->d_code_wide) != VVM_OK) { vvm_free_state(st); return nullptr; }
 	if (link_more_passes(st->script, false, st->wide, st->wide_more, st->d_code_wide_more) != VVM_OK) { vvm_free_state(st); return nullptr; }
+	if (st->wide.instances_per_lane == 4 && !st->wide.full_kernel && !st->wide.many_registers && st->wide.num_passes == 1) {
+		std::string why;
+		if (vvm::link_program(st->script, false, st->light, why, 0, true) == VVM_OK) {
+			if (upload_code(st->light, &st->d_code_light) != VVM_OK) { vvm_free_state(st); return nullptr; }
+			st->light_ready = true;
+		}
+	}
 	hipError_t e;
 	st->any_ids = st->wide.uses_ids;
 	st->const_table.reserve(st->script.num_consts);      // (filled by the first Exec; reserved here so that no Exec allocates for them)
@@ -571,6 +590,7 @@ VVM_API void vvm_free_state(vvm_state* st)
 	st->ring.release();
 	if (st->d_code_wide) (void)hipFree(st->d_code_wide);
 	if (st->d_code_narrow) (void)hipFree(st->d_code_narrow);
+	if (st->d_code_light) (void)hipFree(st->d_code_light);
 	for (VvmIns* p : st->d_code_wide_more) if (p) (void)hipFree(p);
 	for (VvmIns* p : st->d_code_narrow_more) if (p) (void)hipFree(p);
 	if (st->d_perlin) (void)hipFree(st->d_perlin);
@@ -705,8 +725,8 @@ static int exec_enqueue(vvm_exec_context* ctx, const vvm_exec_options* opt, bool
 		}
 		if (timed && pass == 0) HIP_TRY(hipEventRecord(st->ev_start[st->ev_used], stream));
 		const int lrc = vvm_launch_exec_kernel((int)pe.instances_per_lane, inline_block ? nullptr : (const VvmExecDesc*)st->ring.dev[slot], 1, pe.tiles, d_launch,
-		                                       pe.lp->many_registers ? 1 : 0, pe.lp->lds_spill_slots, pe.lp->full_kernel ? 1 : 0,
-		                                       grid_for(pe.tiles, pe.instances_per_lane, pe.lp->full_kernel, pe.lp->many_registers), stream,
+		                                       pe.launch_many() ? 1 : 0, pe.lp->lds_spill_slots, pe.lp->full_kernel ? 1 : 0,
+		                                       grid_for(pe.tiles, pe.instances_per_lane, pe.lp->full_kernel, pe.launch_many()), stream,
 		                                       inline_block ? local_block : nullptr, inline_block ? (uint32_t)pe.bytes : 0u, 0u);
 		if (lrc != 0) return hip_fail((hipError_t)lrc, "kernel launch");
 		if (timed && pass + 1 == num_passes) { HIP_TRY(hipEventRecord(st->ev_stop[st->ev_used], stream)); st->ev_used++; }
@@ -865,7 +885,7 @@ struct BatchPlan {
 	uint32_t total_tiles = 0;
 };
 
-int kernel_key(const PreparedExec& pe) { return (int)pe.instances_per_lane * 4 + (pe.lp->many_registers ? 2 : 0) + (pe.lp->full_kernel ? 1 : 0); }
+int kernel_key(const PreparedExec& pe) { return (int)pe.instances_per_lane * 4 + (pe.launch_many() ? 2 : 0) + (pe.lp->full_kernel ? 1 : 0); }
 
 // Tiles, ticket numbers, look-back words and buffer offsets of every Exec, from the groups' member lists and the prepared sizes.
 void batch_layout(BatchPlan& plan, const vvm_exec_context* ctxs)
@@ -1043,8 +1063,8 @@ int batch_launch_slice(BatchWorkspace& ws, const BatchPlan& plan, int sl, size_t
 		}
 		const uint32_t launch_tag = ws.next_tag++;
 		const int lrc = vvm_launch_exec_kernel((int)pe0.instances_per_lane, (const VvmExecDesc*)(ws.dev + grp.desc_off), (uint32_t)grp.members.size(), grp.tiles,
-		                                       ws.d_launch[g], lp.many_registers ? 1 : 0, grp.spill, lp.full_kernel ? 1 : 0,
-		                                       grid_for(grp.tiles, pe0.instances_per_lane, lp.full_kernel, lp.many_registers), ws.stream, nullptr, 0, launch_tag);
+		                                       ws.d_launch[g], pe0.launch_many() ? 1 : 0, grp.spill, lp.full_kernel ? 1 : 0,
+		                                       grid_for(grp.tiles, pe0.instances_per_lane, lp.full_kernel, pe0.launch_many()), ws.stream, nullptr, 0, launch_tag);
 		if (lrc != 0) { (void)hipStreamSynchronize(ws.stream); return hip_fail((hipError_t)lrc, "batched kernel launch"); }
 		HIP_TRY(hipMemcpyAsync(&ws.h_launch[(size_t)sl * 8 + g], ws.d_launch[g], 80, hipMemcpyDeviceToHost, ws.stream));
 	}
@@ -1322,13 +1342,14 @@ static void fill_info(const vvm::ThawedScript& s, const vvm::LinkedProgram& lp, 
 	out->LdsSpillRegisters = lp.lds_spill_slots;
 	out->BytesInPerInstance = lp.bytes_in_per_instance;
 	out->BytesOutPerInstance = lp.bytes_out_per_instance;
-	out->Flags = s.flags | (lp.full_kernel ? 0x10000u : 0u);
+	out->Flags = s.flags | (lp.full_kernel ? 0x10000u : 0u);      // (vvm_state_info adds 0x20000: a program for the light eight-wide kernel exists)
 }
 
 VVM_API int vvm_state_info(const vvm_state* st, vvm_program_info* out)
 {
 	if (!st || !out) return fail(VVM_E_INVALID_ARG, "null argument");
 	fill_info(st->script, st->wide, out);
+	if (st->light_ready) out->Flags |= 0x20000u;
 	return VVM_OK;
 }
 

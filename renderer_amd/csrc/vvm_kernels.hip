@@ -85,6 +85,17 @@ template <int V, bool SPILL> struct RegTraits;
 template <> struct RegTraits<4, false> { typedef vec16f vec; static constexpr uint32_t RV = 16; };
 template <> struct RegTraits<4, true> { typedef vec32f vec; static constexpr uint32_t RV = 32; };
 template <> struct RegTraits<8, false> { typedef vec16f vec; static constexpr uint32_t RV = 16; };
+// <8, true> is the LIGHT eight-wide kernel, for scripts that get by with eight registers: no LDS register slots (the flag means
+// something else at this width), a 64-VGPR register file, six staging slots; 168 VGPRs and 50 KB of LDS per workgroup, so that
+// three workgroups fit a CU instead of two.  The interpreter is bound by the latency of a single wave's instruction stream
+// (a CU with one workgroup interprets half as fast as with two, with four of the four-wide kernel twice as fast as with two),
+// so a third resident workgroup is what hides the tile's memory phases.
+// (ten elements, of which eight are used: the backend turns a run-time index into an eight-element vector into compare-and-select
+// chains instead of the GPR-index mode, half as fast per interpreted instruction as the sixteen-element file; from nine on it indexes)
+typedef float vec8f __attribute__((ext_vector_type(10)));
+template <> struct RegTraits<8, true> { typedef vec8f vec; static constexpr uint32_t RV = 8; };
+#define IS_LIGHT(V, SPILL) ((V) == 8 && (SPILL))
+#define VVM_LIGHT_STAGE_SLOTS 6u
 
 // Instance slots of a lane.  V = 1: the lane's one instance.  V = 4: four consecutive instances, [4 tid, 4 tid + 4) of the
 // tile.  V = 8: two such groups, the second one VVM_HALF_TILE instances after the first: the tile is two halves of 1024
@@ -112,10 +123,12 @@ template <typename VEC> __device__ __forceinline__ VEC vset(VEC v, uint32_t i, f
 #define LDS_PERLIN_SEL_OFF  768
 #define LDS_PERLIN_GRAD_OFF 1280
 #define LDS_STAGE_OFF(FULL)   ((FULL) ? 1664u : 896u)
-#define LDS_STAGE_SINK_OFF(V, FULL) (LDS_STAGE_OFF(FULL) + VVM_STAGE_SLOTS * VVM_BLOCK_THREADS * (V) * 4u)
-#define LDS_STAGE_KEEP_OFF(V, FULL) (LDS_STAGE_SINK_OFF(V, FULL) + VVM_BLOCK_THREADS * 4u)
-#define LDS_STAGE_BYTES(V)  (VVM_STAGE_SLOTS * VVM_BLOCK_THREADS * (V) * 4u + 2u * VVM_BLOCK_THREADS * 4u)
-#define LDS_SPILL_OFF(V, FULL) (LDS_STAGE_OFF(FULL) + LDS_STAGE_BYTES(V))
+// (LIGHT: the eight-wide kernel with six staging slots, see RegTraits<8, true>)
+#define LDS_SLOTS(LIGHT) ((LIGHT) ? VVM_LIGHT_STAGE_SLOTS : (uint32_t)VVM_STAGE_SLOTS)
+#define LDS_STAGE_SINK_OFF(V, FULL, LIGHT) (LDS_STAGE_OFF(FULL) + LDS_SLOTS(LIGHT) * VVM_BLOCK_THREADS * (V) * 4u)
+#define LDS_STAGE_KEEP_OFF(V, FULL, LIGHT) (LDS_STAGE_SINK_OFF(V, FULL, LIGHT) + VVM_BLOCK_THREADS * 4u)
+#define LDS_STAGE_BYTES(V, LIGHT)  (LDS_SLOTS(LIGHT) * VVM_BLOCK_THREADS * (V) * 4u + 2u * VVM_BLOCK_THREADS * 4u)
+#define LDS_SPILL_OFF(V, FULL, LIGHT) (LDS_STAGE_OFF(FULL) + LDS_STAGE_BYTES(V, LIGHT))
 
 DEV uint32_t fbits(float f) { return __float_as_uint(f); }
 DEV float    bitsf(uint32_t u) { return __uint_as_float(u); }
@@ -538,8 +551,7 @@ template <int V, bool SPILL> DEV void reg_read(CREGS, const Ctx& c, uint32_t idx
 	out[0] = vget(R0, i);
 	if constexpr (V >= 4) { out[1] = vget(R1, i); out[2] = vget(R2, i); out[3] = vget(R3, i); }
 	if constexpr (V == 8) { out[4] = vget(R4, i); out[5] = vget(R5, i); out[6] = vget(R6, i); out[7] = vget(R7, i); }
-	static_assert(!(SPILL && V == 8), "the eight-instance kernel has no LDS register slots");
-	if constexpr (SPILL) {
+	if constexpr (SPILL && V != 8) {      // (the eight-instance kernels have no LDS register slots)
 		if (idx >= RV) {
 			const float* p = c.spill + ((idx - RV) * VVM_BLOCK_THREADS + c.tid) * V;
 			if constexpr (V == 4) { const f4a v = *(const f4a*)p; out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w; }
@@ -551,13 +563,13 @@ template <int V, bool SPILL> DEV RVEC reg_put(RVEC Rk, bool enable, uint32_t idx
 {
 	constexpr uint32_t RV = RegTraits<V, SPILL>::RV;
 	const uint32_t i = idx & (RV - 1);
-	if constexpr (SPILL) enable = enable && (idx < RV);
+	if constexpr (SPILL && V != 8) enable = enable && (idx < RV);
 	return vset(Rk, i, enable ? x : vget(Rk, i));
 }
 template <int V, bool SPILL> DEV void reg_spill(const Ctx& c, bool enable, uint32_t idx, const float (&in)[V])
 {
 	constexpr uint32_t RV = RegTraits<V, SPILL>::RV;
-	if constexpr (SPILL) {
+	if constexpr (SPILL && V != 8) {
 		if (enable && idx >= RV) {
 			float* p = c.spill + ((idx - RV) * VVM_BLOCK_THREADS + c.tid) * V;
 			if constexpr (V == 4) { f4a v; v.x = in[0]; v.y = in[1]; v.z = in[2]; v.w = in[3]; *(f4a*)p = v; }
@@ -901,7 +913,7 @@ template <int V, bool ANY16, bool FULL> DEV void store_slots(const uint64_t (&en
 	}
 #undef VVM_SLOT
 }
-template <int V, bool FULL> DEV void store_tile(Pending& p, const Ctx& c, unsigned char* lds, uint32_t dbg)
+template <int V, bool FULL, bool LIGHT> DEV void store_tile(Pending& p, const Ctx& c, unsigned char* lds, uint32_t dbg)
 {
 	static_assert(VVM_STAGE_SLOTS == 8, "store_slots is written for eight slots");
 	const uint32_t n_staged = STAGED_COUNT(p.stage_end);
@@ -911,7 +923,7 @@ template <int V, bool FULL> DEV void store_tile(Pending& p, const Ctx& c, unsign
 		sload64x8(p.out_list, STAGED_FIRST(p.stage_end), entry);
 		StoreArgs a;
 		a.i0 = c.tid * lane_stride<V>(); a.off4 = 4ull * p.base; a.rec4 = 4u * p.total; a.base = p.base; a.tile_first = p.tile_local * (VVM_BLOCK_THREADS * V);
-		a.keep_word = (const uint32_t*)(lds + LDS_STAGE_KEEP_OFF(V, FULL)) + c.tid;
+		a.keep_word = (const uint32_t*)(lds + LDS_STAGE_KEEP_OFF(V, FULL, LIGHT)) + c.tid;
 		const float* src = (const float*)(lds + LDS_STAGE_OFF(FULL)) + a.i0;
 		if (entry[0] & VVM_OUT_GROUP16) store_slots<V, true, FULL>(entry, n_staged, src, a);
 		else store_slots<V, false, FULL>(entry, n_staged, src, a);
@@ -1016,6 +1028,25 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 	} while (0)
 	const void* load_ptrs = (const void*)DESC_TABLE(c, load_ptrs);
 	uint32_t pc0 = 0;
+	if constexpr (IS_LIGHT(V, SPILL)) {
+		// The light kernel's program starts with exactly one load instruction, for up to eight 32-bit streams into registers 0..7
+		// (the linker sees to it): every stream goes straight to its register, a fixed element of the register vectors, with no
+		// staging copy and no index mode.  The slots past the count read through an empty descriptor (zeros, no memory access).
+		const uint32_t w0 = sload32(prog, 0);
+		const uint32_t cnt = (w0 >> 16) & 0xFFu;
+		uint64_t ptr[8];
+		sload64x8(load_ptrs, sload32(prog, 1), ptr);
+#pragma unroll
+		for (int j = 0; j < 8; ++j) {
+			const bool used = (uint32_t)j < cnt && !(dbg & 2u);
+			const rsrc_t rs = make_rsrc(ptr[j] + 4ull * c.tile_first, used ? 4u * c.valid : 0u);
+			const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(c.tid * 16u), 0, AUX_STREAM_LOAD);
+			const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(VVM_HALF_TILE * 4u + c.tid * 16u), 0, AUX_STREAM_LOAD);
+			R0[j] = bitsf(lo.x); R1[j] = bitsf(lo.y); R2[j] = bitsf(lo.z); R3[j] = bitsf(lo.w);
+			R4[j] = bitsf(hi.x); R5[j] = bitsf(hi.y); R6[j] = bitsf(hi.z); R7[j] = bitsf(hi.w);
+		}
+		pc0 = 1;
+	} else
 	for (;; ++pc0) {
 		const uint32_t w0 = sload32(prog, pc0 * 4 + 0);
 		const uint32_t lop = w0 & 0xFFu;
@@ -1303,7 +1334,7 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 				default: { _Pragma("unroll") LANES r[k] = 0.0f; } break;
 				}
 			}
-			else if (nin_is(nin, 5u)) {
+			else if (!IS_LIGHT(V, SPILL) && nin_is(nin, 5u)) {
 				float a[V], b[V], cc[V], dd[V], ee[V];
 				fetch<V, SPILL>(RARGS, uni, c, o0, a);
 				fetch<V, SPILL>(RARGS, uni, c, o1, b);
@@ -1341,8 +1372,30 @@ leave_run:
 
 		if (op == VVM_DOP_ACQUIRE) {
 			// sign bit of the predicate = keep (VectorVMRuntime.cpp:838-841); instances past the end never survive (:846-857)
+			// aux2 != 0: the linker has folded the compare that produced the predicate into this instruction (the mask had no other
+			// reader): keep = o0 <cmp> o1, the same bit the compare's all-ones mask would carry in its sign
 			float p[V];
 			fetch<V, SPILL>(RARGS, uni, c, o0, p);
+			if (aux2 != VVM_ACQ_SIGN) {
+				float q[V];
+				fetch<V, SPILL>(RARGS, uni, c, o1, q);
+#define ACQ_CMP(expr) { _Pragma("unroll") for (int k = 0; k < V; ++k) { const float A = p[k], B = q[k]; const int32_t IA = (int32_t)fbits(A), IB = (int32_t)fbits(B); (void)IA; (void)IB; p[k] = mask(expr); } } break
+				switch (aux2) {
+				case VVM_ACQ_LT: ACQ_CMP(A < B);
+				case VVM_ACQ_LE: ACQ_CMP(A <= B);
+				case VVM_ACQ_GT: ACQ_CMP(A > B);
+				case VVM_ACQ_GE: ACQ_CMP(A >= B);
+				case VVM_ACQ_EQ: ACQ_CMP(A == B);
+				case VVM_ACQ_NE: ACQ_CMP(A != B);
+				case VVM_ACQ_LTI: ACQ_CMP(IA < IB);
+				case VVM_ACQ_LEI: ACQ_CMP(IA <= IB);
+				case VVM_ACQ_GTI: ACQ_CMP(IA > IB);
+				case VVM_ACQ_GEI: ACQ_CMP(IA >= IB);
+				case VVM_ACQ_EQI: ACQ_CMP(IA == IB);
+				default: ACQ_CMP(IA != IB);
+				}
+#undef ACQ_CMP
+			}
 			uint32_t kb = 0;
 #pragma unroll
 			for (int k = 0; k < V; ++k)
@@ -1355,7 +1408,7 @@ leave_run:
 		// tile's look-back has been in flight since this tile was claimed.
 		if (pend.active) {
 			resolve_tile<V>(pend, c, lds_ctrl, resolves, tag, ls, dbg, pre, have_pre);
-			store_tile<V, FULL>(pend, c, lds, dbg);
+			store_tile<V, FULL, IS_LIGHT(V, SPILL)>(pend, c, lds, dbg);
 			__syncthreads();      // every thread has read its staged values: the slots may be written again
 		}
 		if (op == VVM_DOP_ACQUIRE) continue;
@@ -1369,7 +1422,7 @@ leave_run:
 			cur.stage_end = stage_end; cur.last = last_tile;
 			cur.tile_local = tile_local; cur.status = status; cur.out_list = c.out_list;
 			resolve_tile<V>(cur, c, lds_ctrl, resolves, tag, ls, dbg, pre, false);
-			store_tile<V, FULL>(cur, c, lds, dbg);
+			store_tile<V, FULL, IS_LIGHT(V, SPILL)>(cur, c, lds, dbg);
 			__syncthreads();      // the slots are written again right away
 			t_base = cur.base; t_pending = false; stage_end = 0;
 			continue;
@@ -1387,7 +1440,7 @@ leave_run:
 			uint32_t exists = 0;
 #pragma unroll
 			for (int k = 0; k < V; ++k) exists |= ((c.inst0 + slot_offset<V>(k) < c.num_instances) ? 1u : 0u) << k;
-			((uint32_t*)(lds + LDS_STAGE_KEEP_OFF(V, FULL)))[c.tid] = t_rank | (t_keep << 16) | (exists << 24);
+			((uint32_t*)(lds + LDS_STAGE_KEEP_OFF(V, FULL, IS_LIGHT(V, SPILL))))[c.tid] = t_rank | (t_keep << 16) | (exists << 24);
 			stage_end = max(stage_end, slot_index + 1u);      // (the group's last slot: outputs staged after this one lie below it)
 			continue;
 		}
@@ -1401,7 +1454,7 @@ leave_run:
 			const uint32_t kind = op - VVM_DOP_OUTPUT32;          // 0: 32-bit value  1: float -> half  2: low 16 bits as they are  3: half bits -> float
 			const uint32_t first_slot = o4 | (o5 << 16);
 			float* slot = (float*)(lds + LDS_STAGE_OFF(FULL)) + (first_slot & (VVM_STAGE_SLOTS - 1u)) * (VVM_BLOCK_THREADS * V);
-			float* sink = (float*)(lds + LDS_STAGE_SINK_OFF(V, FULL)) + c.tid;
+			float* sink = (float*)(lds + LDS_STAGE_SINK_OFF(V, FULL, IS_LIGHT(V, SPILL))) + c.tid;
 			uint64_t srcs = (uint64_t)o0 | ((uint64_t)o1 << 16) | ((uint64_t)o2 << 32);
 			for (uint32_t j = 0; j < aux; ++j, srcs >>= 16, slot += VVM_BLOCK_THREADS * V) {
 				float v[V];
@@ -1448,13 +1501,13 @@ leave_run:
 
 // DBG: the bring-up switches of KernelEnv::debug_skip are compiled in (one instantiation only); otherwise they cost nothing.
 template <int V, bool SPILL, bool FULL, bool DBG = false>
-__global__ void __launch_bounds__(VVM_BLOCK_THREADS, (V == 8 || (V == 4 && SPILL) ? 2 : FULL ? 3 : (V == 4 ? 4 : 8))) vvm_exec_kernel(KernelEnv env)
+__global__ void __launch_bounds__(VVM_BLOCK_THREADS, (IS_LIGHT(V, SPILL) ? 3 : V == 8 || (V == 4 && SPILL) ? 2 : FULL ? 3 : (V == 4 ? 4 : 8))) vvm_exec_kernel(KernelEnv env)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	const uint32_t dbgw = DBG ? env.debug_skip : 0u;
 	uint32_t* lds_ctrl = (uint32_t*)lds;
 	uint8_t* lds_perlin = lds + LDS_PERLIN_OFF;
-	float* lds_spill = (float*)(lds + LDS_SPILL_OFF(V, FULL));
+	float* lds_spill = (float*)(lds + LDS_SPILL_OFF(V, FULL, IS_LIGHT(V, SPILL)));
 	Pending pend;
 	pend.active = false; pend.unresolved = false; pend.last = false; pend.total = 0; pend.base = 0; pend.stage_end = 0; pend.tile_local = 0;
 	pend.status = nullptr; pend.out_list = nullptr;
@@ -1550,7 +1603,7 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (V == 8 || (V == 4 && SPILL
 		c.tid = tid; c.wave = wave; c.inst0 = 0; c.num_instances = 0; c.tile_first = 0; c.valid = 0; c.phase = 0;
 		const u64 none[VVM_LB_WORDS_PER_LANE] = {};
 		resolve_tile<V>(pend, c, lds_ctrl, resolves, tag, env.ls, dbgw, none, false);
-		store_tile<V, FULL>(pend, c, lds, dbgw);
+		store_tile<V, FULL, IS_LIGHT(V, SPILL)>(pend, c, lds, dbgw);
 	}
 
 	// the last workgroup to leave re-arms the launch words for the next launch
@@ -1605,6 +1658,8 @@ extern "C" int vvm_launch_exec_kernel(int instances_per_lane, const VvmExecDesc*
                                       VvmLaunchState* ls, int many_registers, uint32_t lds_spill_slots, int full, uint32_t grid, hipStream_t stream,
                                       const void* inline_block, uint32_t inline_bytes, uint32_t tag)
 {
+	// instances_per_lane 8 with many_registers set names the light eight-wide kernel (eight resident registers, six staging slots)
+	const bool light = instances_per_lane == 8 && many_registers != 0;
 	if (tag > VVM_MAX_LAUNCH_TAG) return (int)hipErrorInvalidValue;
 	KernelEnv env = {};      // (the unused part of the block travels too: no indeterminate bytes in the kernel arguments)
 	if (inline_block) {
@@ -1615,7 +1670,7 @@ extern "C" int vvm_launch_exec_kernel(int instances_per_lane, const VvmExecDesc*
 	}
 	env.descs = descs; env.num_execs = num_execs; env.total_tiles = total_tiles; env.ls = ls; env.lds_spill_slots = lds_spill_slots; env.tag = tag;
 	{ const char* dbg = getenv("VVM_DEBUG_SKIP"); env.debug_skip = dbg ? (uint32_t)strtoul(dbg, nullptr, 0) : 0u; }
-	const size_t lds_bytes = (instances_per_lane == 8 ? LDS_SPILL_OFF(8, full != 0) : instances_per_lane == 4 ? LDS_SPILL_OFF(4, full != 0) : LDS_SPILL_OFF(1, full != 0)) +
+	const size_t lds_bytes = (instances_per_lane == 8 ? LDS_SPILL_OFF(8, full != 0, light) : instances_per_lane == 4 ? LDS_SPILL_OFF(4, full != 0, false) : LDS_SPILL_OFF(1, full != 0, false)) +
 	                         (size_t)lds_spill_slots * VVM_BLOCK_THREADS * 4u * (size_t)instances_per_lane;
 	const bool spill = many_registers != 0;      // the kernels with 32 resident registers and LDS register slots
 #ifdef VVM_EXPERIMENT_ONE_KERNEL
@@ -1624,8 +1679,9 @@ extern "C" int vvm_launch_exec_kernel(int instances_per_lane, const VvmExecDesc*
 #else
 #define VVM_LAUNCH(V, S, F) hipLaunchKernelGGL((vvm_exec_kernel<V, S, F>), dim3(grid), dim3(VVM_BLOCK_THREADS), lds_bytes, stream, env)
 	if (instances_per_lane == 8) {
-		if (full || spill) return (int)hipErrorInvalidValue;      // (eight instances per lane: plain scripts only)
-		if (env.debug_skip) hipLaunchKernelGGL((vvm_exec_kernel<8, false, false, true>), dim3(grid), dim3(VVM_BLOCK_THREADS), lds_bytes, stream, env);
+		if (full || lds_spill_slots) return (int)hipErrorInvalidValue;      // (eight instances per lane: plain scripts only)
+		if (light) { if (env.debug_skip) hipLaunchKernelGGL((vvm_exec_kernel<8, true, false, true>), dim3(grid), dim3(VVM_BLOCK_THREADS), lds_bytes, stream, env); else VVM_LAUNCH(8, true, false); }
+		else if (env.debug_skip) hipLaunchKernelGGL((vvm_exec_kernel<8, false, false, true>), dim3(grid), dim3(VVM_BLOCK_THREADS), lds_bytes, stream, env);
 		else VVM_LAUNCH(8, false, false);
 	} else if (instances_per_lane == 4) {
 		if (full) { if (spill) VVM_LAUNCH(4, true, true); else VVM_LAUNCH(4, false, true); }
@@ -1651,6 +1707,8 @@ extern "C" int vvm_kernel_max_dynamic_lds(void)
 	(void)hipFuncSetAttribute((const void*)vvm_exec_kernel<1, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
 	(void)hipFuncSetAttribute((const void*)vvm_exec_kernel<8, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
 	(void)hipFuncSetAttribute((const void*)vvm_exec_kernel<8, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+	(void)hipFuncSetAttribute((const void*)vvm_exec_kernel<8, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+	(void)hipFuncSetAttribute((const void*)vvm_exec_kernel<8, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
 #endif
 	return 160 * 1024 - 64;
 }
@@ -1660,4 +1718,4 @@ extern "C" uint32_t vvm_kernel_resident_registers(int instances_per_lane, int ma
 	if (instances_per_lane == 1) return RegTraits<1, true>::RV;
 	return many_registers ? RegTraits<4, true>::RV : RegTraits<4, false>::RV;
 }
-extern "C" uint32_t vvm_kernel_lds_fixed_bytes(int instances_per_lane, int full) { return instances_per_lane == 4 ? LDS_SPILL_OFF(4, full != 0) : LDS_SPILL_OFF(1, full != 0); }
+extern "C" uint32_t vvm_kernel_lds_fixed_bytes(int instances_per_lane, int full) { return instances_per_lane == 4 ? LDS_SPILL_OFF(4, full != 0, false) : LDS_SPILL_OFF(1, full != 0, false); }

@@ -235,7 +235,8 @@ static uint32_t reallocate_registers(std::vector<VvmIns>& code, uint32_t num_loa
 		const uint32_t op = k.w0 & 0xFFu;
 		uint32_t reads = 0;
 		bool writes = false;
-		if (op == VVM_DOP_ACQUIRE || op == VVM_DOP_UPDATE_ID) reads = 1;
+		if (op == VVM_DOP_ACQUIRE) reads = (k.w0 >> 24) != VVM_ACQ_SIGN ? 2 : 1;
+		else if (op == VVM_DOP_UPDATE_ID) reads = 1;
 		else if (op == VVM_DOP_OUTPUT32 || op == VVM_DOP_OUTPUT16 || op == VVM_DOP_OUTPUT16_FROM16 || op == VVM_DOP_OUTPUT32_FROM16) reads = (k.w0 >> 16) & 0xFFu;
 		else if (op == VVM_OP_done || op >= VVM_DOP_LOADN16) reads = 0;
 		else { reads = (k.w0 >> 8) & 7u; writes = true; }
@@ -277,7 +278,52 @@ static uint32_t reallocate_registers(std::vector<VvmIns>& code, uint32_t num_loa
 	return (uint32_t)busy_until.size();
 }
 
-int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, std::string& err, uint32_t pass)
+// acquireindex whose predicate is the mask of a compare that nothing else reads: the compare is folded into the acquireindex
+// (keep = a <cmp> b, which is the sign bit of the compare's all-ones / all-zeros mask, VectorVMRuntime.cpp:838-841), one
+// interpreted instruction and one register less.  `holds_value` says which bytecode registers are per-lane values.
+static uint32_t acquire_compare_code(uint8_t op)
+{
+	switch (op) {
+	case VVM_OP_cmplt: return VVM_ACQ_LT;   case VVM_OP_cmple: return VVM_ACQ_LE;   case VVM_OP_cmpgt: return VVM_ACQ_GT;
+	case VVM_OP_cmpge: return VVM_ACQ_GE;   case VVM_OP_cmpeq: return VVM_ACQ_EQ;   case VVM_OP_cmpneq: return VVM_ACQ_NE;
+	case VVM_OP_cmplti: return VVM_ACQ_LTI; case VVM_OP_cmplei: return VVM_ACQ_LEI; case VVM_OP_cmpgti: return VVM_ACQ_GTI;
+	case VVM_OP_cmpgei: return VVM_ACQ_GEI; case VVM_OP_cmpeqi: return VVM_ACQ_EQI; case VVM_OP_cmpneqi: return VVM_ACQ_NEI;
+	default: return VVM_ACQ_SIGN;
+	}
+}
+template <typename F> static void fold_compares_into_acquires(std::vector<Decoded>& ins, F holds_value)
+{
+	for (size_t k = 0; k < ins.size(); ++k) {
+		if (ins[k].kind != K_ACQUIRE || ins[k].in.size() != 1 || !holds_value(ins[k].in[0])) continue;
+		const uint16_t r = ins[k].in[0];
+		// the instruction that made the predicate: the last one before k that writes r
+		size_t j = k;
+		for (size_t q = k; q-- > 0;)
+			if (std::find(ins[q].out.begin(), ins[q].out.end(), r) != ins[q].out.end()) { j = q; break; }
+		if (j == k) continue;
+		const uint32_t code = acquire_compare_code(ins[j].op);
+		if (code == VVM_ACQ_SIGN || ins[j].kind != K_ORD || ins[j].out.size() != 1 || ins[j].in.size() != 2) continue;
+		// nobody else reads the mask (any instruction, before or after: the register may be reused, but then the fold is skipped)
+		bool other_reader = false;
+		for (size_t q = 0; q < ins.size() && !other_reader; ++q) {
+			if (q == k) continue;
+			other_reader |= std::find(ins[q].in.begin(), ins[q].in.end(), r) != ins[q].in.end();
+			for (auto& pr : ins[q].pairs) other_reader |= pr.first == r;
+		}
+		if (other_reader) continue;
+		// the compare's operands still hold the same values at the acquireindex
+		bool clobbered = false;
+		for (size_t q = j + 1; q < k && !clobbered; ++q)
+			for (uint16_t w : ins[q].out) clobbered |= (w == ins[j].in[0] || w == ins[j].in[1]);
+		if (clobbered) continue;
+		ins[k].in = ins[j].in;
+		ins[k].fn = (uint16_t)code;
+		ins.erase(ins.begin() + (ptrdiff_t)j);
+		--k;
+	}
+}
+
+int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, std::string& err, uint32_t pass, bool light)
 {
 	std::vector<Decoded> ins;
 	int rc = decode(s, ins, err);
@@ -287,6 +333,7 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 	const uint32_t T = s.num_temps, C = s.num_consts, I = s.num_inputs;
 	const uint32_t O = std::max<uint32_t>(s.num_outputs_remapped, s.num_output_instructions);
 	const uint32_t out0 = T + C + 2 * I;
+	fold_compares_into_acquires(ins, [&](uint16_t r) { return r != VVM_INVALID_REG && (r < T || (r >= out0 && r < out0 + O)); });
 	if (C > VVM_MAX_OPND_INDEX || I > 0xFFF || O > VVM_MAX_OPND_INDEX) { err = "script exceeds the device operand index range"; return VVM_E_TOO_LARGE; }
 
 	// classify inputs from InputDataSetOffsets: per dataset float,int,half then no-advance float,int,half (RT.cpp:515-550)
@@ -413,7 +460,7 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 				break;
 			case K_ACQUIRE:
 				keep = !other_pass;
-				if (keep && holds_value(d.in[0])) live[d.in[0]] = 1;
+				if (keep) for (uint16_t r : d.in) if (holds_value(r)) live[r] = 1;
 				break;
 			case K_IDS:
 				if (d.op == VVM_OP_update_id) {
@@ -549,7 +596,7 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 	// The output list is cut into groups of VVM_STAGE_SLOTS entries (one staging slot each).  An output instruction never
 	// straddles two groups, and a flush instruction precedes the first instruction that stages into a new group.  When the
 	// script has an update_id, the last entry of every group is kept for it (-1 where it is not used).
-	const size_t group_capacity = lp.updates_ids ? VVM_STAGE_SLOTS - 1 : VVM_STAGE_SLOTS;
+	const size_t group_capacity = light ? VVM_LIGHT_GROUP_SLOTS : lp.updates_ids ? VVM_STAGE_SLOTS - 1 : VVM_STAGE_SLOTS;
 	size_t out_cursor = 0;           // next free entry
 	size_t open_group = 0;           // group the instructions emitted so far stage into
 	auto open_slot = [&]() -> size_t {
@@ -596,8 +643,8 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 		case K_ACQUIRE:
 			if (multi_pass && d.dataset != pass_dataset) break;       // another pass's dataset
 			acquired_dataset = (int)d.dataset;
-			k.w0 = VVM_INS_W0(VVM_DOP_ACQUIRE, 1, 0, d.dataset, 0);
-			k.w1 = operand(d.in[0]);
+			k.w0 = VVM_INS_W0(VVM_DOP_ACQUIRE, 1, 0, d.dataset, d.in.size() == 2 ? d.fn : VVM_ACQ_SIGN);      // (fn: the folded compare, see fold_compares_into_acquires)
+			k.w1 = operand(d.in[0]) | (d.in.size() == 2 ? operand(d.in[1]) << 16 : 0u);
 			lp.code.push_back(k);
 			break;
 		case K_OUTPUT: {
@@ -693,6 +740,22 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 		snprintf(msg, sizeof(msg), "script needs %u per-lane registers; the executor holds at most %u", packed, RV + kMaxSpillNarrow);
 		err = msg;
 		return VVM_E_TOO_LARGE;
+	}
+	if (light) {
+		// the light eight-wide kernel: eight resident registers, one load instruction of 32-bit streams into registers 0.., ops of at
+		// most four operands, none of the transcendental / noise / ID instructions, one acquired dataset, and at most six outputs: with
+		// three workgroups per CU the LDS has room for six staging slots each, and a second group of slots would have to resolve
+		// the tile's look-back on the spot (measured: 1.04 ms against 0.84 ms of the general kernel on eight outputs of 64 Mi
+		// instances; so was parking two outputs in global memory, which came out even with the general kernel)
+		bool ok = packed <= 8 && V == 4 && !lp.full_kernel && !lp.uses_ids && lp.num_passes == 1 && prefetch16.empty() && !prefetch32.empty() && prefetch32.size() <= 8;
+		for (const VvmIns& k : lp.code) {
+			const uint32_t op = k.w0 & 0xFFu;
+			if (op != VVM_OP_done && op < VVM_DOP_LOADN16 && ((k.w0 >> 8) & 7u) > 4u) ok = false;
+			if (op == VVM_DOP_FLUSH) ok = false;
+		}
+		if (ok) ok = (lp.code[0].w0 & 0xFFu) == VVM_DOP_LOADN && (lp.code[0].w0 >> 24) == 0;      // (the loads address registers 0..)
+		if (!ok) { err = "script does not fit the light eight-wide kernel"; return VVM_E_UNSUPPORTED_OP; }
+		lp.light = true;
 	}
 	lp.num_vregs = packed;
 	lp.instances_per_lane = V;

@@ -41,6 +41,7 @@ struct LinkedProgram {
 	uint32_t resident_regs = 16;
 	uint32_t lds_spill_slots = 0;
 	bool     many_registers = false;   // runs on the kernels with 32 resident registers (and LDS register slots)
+	bool     light = false;            // linked for the light eight-wide kernel (eight resident registers, output groups of six)
 	bool     full_kernel = false;      // needs the transcendental / noise kernel
 	bool     uses_perlin = false;
 	bool     uses_ids = false;         // update_id or acquire_id ...
@@ -62,6 +63,7 @@ struct LinkedProgram {
 // Returns VVM_OK or an error code with `err` filled.
 int thaw_blob(const uint8_t* blob, size_t n, ThawedScript& out, std::string& err);
 // `pass` selects the dataset of a script with several acquireindex datasets (0 .. out.num_passes - 1 of a first link).
-int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& out, std::string& err, uint32_t pass = 0);
+// light: link for the light eight-wide kernel; fails with VVM_E_UNSUPPORTED_OP when the script does not fit it.
+int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& out, std::string& err, uint32_t pass = 0, bool light = false);
 
 }  // namespace vvm

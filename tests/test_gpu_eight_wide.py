@@ -16,8 +16,17 @@ EIGHT = abi.VVM_EXEC_FORCE_EIGHT_WIDE
 
 
 def _check8(script, consts, ins, dtypes, n, **kw):
+    """Scripts that fit the light eight-wide kernel run on it by default: those are checked on the general kernel as well."""
     ref, ref_n, _ = run_oracle(script, consts, ins, dtypes, n, **kw)
-    got, got_n, _ = run_hip(script, consts, ins, dtypes, n, flags=EIGHT, **kw)
+    got, got_n, info = run_hip(script, consts, ins, dtypes, n, flags=EIGHT, **kw)
+    _compare8(got, got_n, ref, ref_n, n, kw)
+    if info.Flags & 0x20000:
+        got, got_n, _ = run_hip(script, consts, ins, dtypes, n, flags=EIGHT | abi.VVM_EXEC_NO_LIGHT_KERNEL, **kw)
+        _compare8(got, got_n, ref, ref_n, n, kw)
+    return got_n
+
+
+def _compare8(got, got_n, ref, ref_n, n, kw):
     assert got_n == ref_n, "survivor count %d != %d (n=%d)" % (got_n, ref_n, n)
     off = kw.get("instance_offset", 0)
     for k, (a, b) in enumerate(zip(got, ref)):

@@ -152,10 +152,13 @@ def test_fountain_links_to_the_expected_program():
     assert ops.count(DOP_ACQUIRE) == 1 and ops.count(DOP_OUT32) == 3       # 8 outputs as 3 + 3 + 2 pairs
     assert ops[-2:] == [0, 0]                                              # done plus the instruction fetched ahead of it
     body = [c for c in code if 0 < c["op"] < 190]
-    assert [opcodes.NAME[c["op"]] for c in body] == ["add", "cmplt"] + ["mad_mul", "mad"] * 3
+    # (the cmplt that makes the keep mask has no other reader: it is folded into the acquireindex, aux2 = the compare)
+    assert [opcodes.NAME[c["op"]] for c in body] == ["add"] + ["mad_mul", "mad"] * 3
+    acq = [c for c in code if c["op"] == DOP_ACQUIRE][0]
+    assert acq["aux2"] == 1 and cls(acq["o"][0]) == OPC_VREG and cls(acq["o"][1]) == OPC_VREG          # VVM_ACQ_LT over two per-lane registers
     info = be().inspect_blob(w.script.blob)
     assert info.InstancesPerLane == 4 and info.LdsSpillRegisters == 0
-    assert info.NumVirtualRegisters == 9           # eight streams; most results take over the register of a stream read for the last time
+    assert info.NumVirtualRegisters == 8           # the eight streams; every result takes over the register of a stream read for the last time
     # constants are uniform-register operands, streams and temps per-lane registers
     for c in body:
         for o in c["o"][:c["nin"]]:

@@ -24,6 +24,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--which", default="transcendental,kill_half,batch")
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--no-light", action="store_true", help="keep eight-wide Execs on the general kernel")
     args = ap.parse_args()
     import torch
     from renderer_amd import abi, scripts
@@ -38,12 +39,13 @@ def main():
         torch.cuda.synchronize()
         st = VectorVMState(w.script.blob, be)
         frame = st.frame([abi.DataSet([t.data_ptr() for t in ins], [t.data_ptr() for t in outs], 0)], n, [w.constants], list(ext))
+        o = abi.ExecOptions(0, 0, 0, None, abi.VVM_EXEC_NO_LIGHT_KERNEL if args.no_light else 0)
         for _ in range(3):
-            surv = st.exec(frame)
+            surv = st.exec(frame, o)
         st.enable_timing(True)
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            st.exec_async(frame)
+            st.exec_async(frame, o)
         surv = st.finish(frame)
         el = time.perf_counter() - t0
         ms, launches = st.collect_kernel_ms()
@@ -92,6 +94,32 @@ def main():
             run_single("arithmetic %d ops, 4 streams in / 4 out, 64Mi" % n_ops, w, ins[:4], 4, n)
             print(json.dumps({"config": "arithmetic %d ops: interpreted instructions x instances per second = value of 'updates_per_s' x %d" % (n_ops, n_ops)}), flush=True)
 
+    if "six_out" in which:
+        # the fountain script with two of its eight outputs left out (eight streams in, six out): what the light eight-wide kernel,
+        # whose staging holds six outputs, does on fountain-like traffic, against the general kernel (--no-light)
+        from renderer_amd.assembler import FLOAT, Script
+        import struct
+        s = Script()
+        dt, drag = s.const(0), s.const(4)
+        pos = [s.input(0, FLOAT, k) for k in range(3)]
+        vel = [s.input(0, FLOAT, 3 + k) for k in range(3)]
+        age, life = s.input(0, FLOAT, 6), s.input(0, FLOAT, 7)
+        age1 = s.temp(); s.op("add", age, dt, age1)
+        alive = s.temp(); s.op("cmplt", age1, life, alive)
+        s.acquireindex(alive, 0)
+        v1, p1 = s.temps(3), s.temps(3)
+        for c in range(3):
+            s.op("mad_mul", s.const(1 + c), dt, vel[c], drag, v1[c])
+            s.op("mad", v1[c], dt, pos[c], p1[c])
+        s.output_data(FLOAT, 0, [(p1[0], s.output(0, FLOAT, 0)), (p1[1], s.output(0, FLOAT, 1)), (p1[2], s.output(0, FLOAT, 2)),
+                                 (v1[0], s.output(0, FLOAT, 3)), (v1[1], s.output(0, FLOAT, 4)), (age1, s.output(0, FLOAT, 5))])
+        class W6:
+            pass
+        w = W6()
+        w.script = s.build(alias_outputs=True)
+        w.constants = struct.pack("<6f", 1.0 / 60.0, 0.0, 0.0, -980.0, 0.98, 1.0) + bytes(8)
+        n = 64 * 1024 * 1024
+        run_single("fountain with six outputs, 64Mi", w, scripts.fountain_streams_torch(0, n, dev, pad=PAD), 6, n)
     if "transcendental" in which:
         n = 16 * 1024 * 1024
         w = scripts.transcendental(True)
