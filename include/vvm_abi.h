@@ -357,7 +357,8 @@ VVM_API int32_t vvm_state_last_exec_width(const vvm_state* state);
 VVM_API void vvm_set_page_size_kb(int kb);
 /* Thaw and link a blob without touching a device and copy out the linked device program: 4 dwords per instruction
  * (renderer_amd/csrc/vvm_device.h gives the encoding), at most `capacity_instructions` of them.  Returns the number of
- * instructions of the program (negative status code on failure).  narrow != 0 links for the 1-instance-per-lane kernel. */
+ * instructions of the program (negative status code on failure).  narrow = 1 links for the 1-instance-per-lane kernel,
+ * narrow = 2 for the light eight-wide kernel (VVM_E_UNSUPPORTED_OP when the script does not fit it). */
 VVM_API int vvm_inspect_code(const uint8_t* blob, size_t num_bytes, int narrow, uint32_t* out_words, int32_t capacity_instructions);
 
 /* ---- script compile side (host only, no device) ----

@@ -440,11 +440,11 @@ class HipBackend(Backend):
 
     def inspect_code(self, blob: bytes, narrow: bool = False):
         """Linked device program of a blob as a list of (w0, w1, w2, w3) tuples (no device needed)."""
-        n = self.lib.vvm_inspect_code(blob, len(blob), 1 if narrow else 0, None, 0)
+        n = self.lib.vvm_inspect_code(blob, len(blob), int(narrow), None, 0)
         if n < 0:
             self._check(-n, "vvm_inspect_code")
         buf = (C.c_uint32 * (4 * n))()
-        self.lib.vvm_inspect_code(blob, len(blob), 1 if narrow else 0, buf, n)
+        self.lib.vvm_inspect_code(blob, len(blob), int(narrow), buf, n)
         return [tuple(buf[4 * i:4 * i + 4]) for i in range(n)]
 
     def info(self, state: int) -> ProgramInfo:

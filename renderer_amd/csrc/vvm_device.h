@@ -30,9 +30,10 @@ enum : uint32_t {
 
 // ---- device-only opcodes (the reference's opcodes keep their numbers 0..178) ----
 enum : uint32_t {
-	VVM_DOP_LOADN16 = 190, // the same for 16-bit streams: the raw bits, zero-extended
+	VVM_DOP_COPY = 189,    // an ordinary instruction (one operand, one destination): dst = o0, bit for bit
 	VVM_DOP_LOADN  = 191,  // load up to 8 32-bit input streams into consecutive virtual registers (program prologue only):
 	                       // aux = count, aux2 = first register, w1 = first slot of VvmExecDesc::load_ptrs
+	VVM_DOP_LOADN16 = 190, // the same for 16-bit streams: the raw bits, zero-extended
 	VVM_DOP_ACQUIRE = 192, // acquireindex: aux = dataset, o0 = predicate (keep = its sign bit, aux2 = VVM_ACQ_SIGN), or, with the compare that
 	                       // made the predicate folded in, keep = o0 <aux2> o1; every opcode from here on produces no register result
 	VVM_DOP_OUTPUT32 = 193, // up to 3 (src,dst) pairs of outputdata_float / outputdata_int32: aux = count, aux2 = dataset,
@@ -55,8 +56,12 @@ enum : uint32_t {
 
 // Output values wait in LDS staging slots until the tile's output position is known; one group of slots is written out at a time.
 #define VVM_STAGE_SLOTS 8
-// the light eight-wide kernel has six staging slots: its programs use the first six entries of every group of eight
+// The light eight-wide kernel has six staging slots: its programs stage into the first six entries of the output list.  Entries
+// six and seven serve 32-bit outputs whose values stay where they are, in per-lane registers VVM_LIGHT_RIDE_REG and the one after
+// it, until the next tile has resolved the position (no instruction: the kernel looks at the two entries).  A light program
+// writes those two registers only after its acquireindex, and the kernel finishes the previous tile right after that instruction.
 #define VVM_LIGHT_GROUP_SLOTS 6
+#define VVM_LIGHT_RIDE_REG 8
 // entry of VvmExecDesc::out_list: byte address in the low 48 bits (0 = nothing is written), flags above
 #define VVM_OUT_IS16 (1ull << 62)         // the destination stream has 16-bit elements
 #define VVM_OUT_GROUP16 (1ull << 61)      // on a group's first entry: some entry of the group has VVM_OUT_IS16 or VVM_OUT_UPDATE_ID

@@ -1372,7 +1372,7 @@ VVM_API int vvm_inspect_code(const uint8_t* blob, size_t num_bytes, int narrow, 
 	vvm::LinkedProgram lp;
 	std::string err;
 	int rc = vvm::thaw_blob(blob, num_bytes, s, err);
-	if (rc == VVM_OK) rc = vvm::link_program(s, narrow != 0, lp, err);
+	if (rc == VVM_OK) rc = (narrow == 2) ? vvm::link_program(s, false, lp, err, 0, true) : vvm::link_program(s, narrow != 0, lp, err);
 	if (rc != VVM_OK) { fail(rc, err); return -rc; }
 	const int32_t n = (int32_t)lp.code.size();
 	if (out_words && capacity_instructions > 0)

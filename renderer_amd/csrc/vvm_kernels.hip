@@ -90,7 +90,7 @@ template <> struct RegTraits<8, false> { typedef vec16f vec; static constexpr ui
 // three workgroups fit a CU instead of two.  The interpreter is bound by the latency of a single wave's instruction stream
 // (a CU with one workgroup interprets half as fast as with two, with four of the four-wide kernel twice as fast as with two),
 // so a third resident workgroup is what hides the tile's memory phases.
-// (ten elements, of which eight are used: the backend turns a run-time index into an eight-element vector into compare-and-select
+// (ten elements: registers 0..7 and the two that hold riding outputs, VVM_LIGHT_RIDE_REG; the backend turns a run-time index into an eight-element vector into compare-and-select
 // chains instead of the GPR-index mode, half as fast per interpreted instruction as the sixteen-element file; from nine on it indexes)
 typedef float vec8f __attribute__((ext_vector_type(10)));
 template <> struct RegTraits<8, true> { typedef vec8f vec; static constexpr uint32_t RV = 8; };
@@ -547,7 +547,7 @@ struct Ctx {
 template <int V, bool SPILL> DEV void reg_read(CREGS, const Ctx& c, uint32_t idx, float (&out)[V])
 {
 	constexpr uint32_t RV = RegTraits<V, SPILL>::RV;
-	const uint32_t i = idx & (RV - 1);
+	const uint32_t i = idx & (IS_LIGHT(V, SPILL) ? 15u : RV - 1);      // (light: eight registers and the two riding ones)
 	out[0] = vget(R0, i);
 	if constexpr (V >= 4) { out[1] = vget(R1, i); out[2] = vget(R2, i); out[3] = vget(R3, i); }
 	if constexpr (V == 8) { out[4] = vget(R4, i); out[5] = vget(R5, i); out[6] = vget(R6, i); out[7] = vget(R7, i); }
@@ -562,7 +562,7 @@ template <int V, bool SPILL> DEV void reg_read(CREGS, const Ctx& c, uint32_t idx
 template <int V, bool SPILL> DEV RVEC reg_put(RVEC Rk, bool enable, uint32_t idx, float x)
 {
 	constexpr uint32_t RV = RegTraits<V, SPILL>::RV;
-	const uint32_t i = idx & (RV - 1);
+	const uint32_t i = idx & (IS_LIGHT(V, SPILL) ? 15u : RV - 1);
 	if constexpr (SPILL && V != 8) enable = enable && (idx < RV);
 	return vset(Rk, i, enable ? x : vget(Rk, i));
 }
@@ -773,6 +773,8 @@ struct Pending {
 	uint32_t tile_local;
 	gu64*    status;
 	const uint64_t* out_list;      // the Exec's output list; the entry before it is the address of the survivor count
+	uint32_t ride;                 // per lane, light kernel: the lane's acquireindex result for the outputs that wait in registers:
+	                               // keep bits [0:8), rank of the lane's first survivor [8:20), of its first one in the second half [20:32)
 };
 #define STAGED_COUNT(end) ((end) ? (((end) - 1u) & (VVM_STAGE_SLOTS - 1u)) + 1u : 0u)
 #define STAGED_FIRST(end) ((end) ? ((end) - 1u) & ~(VVM_STAGE_SLOTS - 1u) : 0u)
@@ -913,7 +915,8 @@ template <int V, bool ANY16, bool FULL> DEV void store_slots(const uint64_t (&en
 	}
 #undef VVM_SLOT
 }
-template <int V, bool FULL, bool LIGHT> DEV void store_tile(Pending& p, const Ctx& c, unsigned char* lds, uint32_t dbg)
+template <int V, bool FULL, bool LIGHT, typename VEC> DEV void store_tile(Pending& p, const Ctx& c, unsigned char* lds, uint32_t dbg,
+                                                                       VEC R0, VEC R1, VEC R2, VEC R3, VEC R4, VEC R5, VEC R6, VEC R7)
 {
 	static_assert(VVM_STAGE_SLOTS == 8, "store_slots is written for eight slots");
 	const uint32_t n_staged = STAGED_COUNT(p.stage_end);
@@ -927,6 +930,36 @@ template <int V, bool FULL, bool LIGHT> DEV void store_tile(Pending& p, const Ct
 		const float* src = (const float*)(lds + LDS_STAGE_OFF(FULL)) + a.i0;
 		if (entry[0] & VVM_OUT_GROUP16) store_slots<V, true, FULL>(entry, n_staged, src, a);
 		else store_slots<V, false, FULL>(entry, n_staged, src, a);
+		if constexpr (LIGHT) {
+			// Entries six and seven of a light program's list: their values never went to a staging slot, they are still in the registers
+			// the tile left them in (the program that runs now writes those only after this point).  A full tile's values go out as
+			// they lie, 128 bits per half; otherwise every survivor's value goes to its rank, dead ones past the end of the descriptor.
+#pragma unroll
+			for (uint32_t h = 0; h < 2; ++h) {
+				const uint64_t ptr = entry[VVM_LIGHT_GROUP_SLOTS + h] & VVM_OUT_ADDR_MASK;
+				if (ptr) {
+					const rsrc_t rs = make_rsrc(ptr + a.off4, a.rec4);
+					const uint32_t v[8] = {fbits(R0[VVM_LIGHT_RIDE_REG + h]), fbits(R1[VVM_LIGHT_RIDE_REG + h]), fbits(R2[VVM_LIGHT_RIDE_REG + h]), fbits(R3[VVM_LIGHT_RIDE_REG + h]),
+					                       fbits(R4[VVM_LIGHT_RIDE_REG + h]), fbits(R5[VVM_LIGHT_RIDE_REG + h]), fbits(R6[VVM_LIGHT_RIDE_REG + h]), fbits(R7[VVM_LIGHT_RIDE_REG + h])};
+					if (p.total == VVM_BLOCK_THREADS * V) {
+						u32x4 lo, hi;
+						lo.x = v[0]; lo.y = v[1]; lo.z = v[2]; lo.w = v[3];
+						hi.x = v[4]; hi.y = v[5]; hi.z = v[6]; hi.w = v[7];
+						__builtin_amdgcn_raw_buffer_store_b128(lo, rs, (int)(a.i0 * 4u), 0, AUX_STREAM_STORE);
+						__builtin_amdgcn_raw_buffer_store_b128(hi, rs, (int)((VVM_HALF_TILE + a.i0) * 4u), 0, AUX_STREAM_STORE);
+					} else {
+						uint32_t r = (p.ride >> 8) & 0xFFFu;
+#pragma unroll
+						for (int k = 0; k < 8; ++k) {
+							if (k == 4) r = p.ride >> 20;
+							const bool keep = (p.ride >> k) & 1u;
+							__builtin_amdgcn_raw_buffer_store_b32(v[k], rs, (int)(keep ? r * 4u : VVM_RSRC_NOWHERE), 0, AUX_STREAM_STORE);
+							r += keep ? 1u : 0u;
+						}
+					}
+				}
+			}
+		}
 	}
 	p.stage_end = 0;
 	p.active = false;
@@ -987,9 +1020,13 @@ struct KernelEnv {
 // ------------------------------------------------------------------------------------------------------
 template <int V, bool SPILL, bool FULL>
 DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c, unsigned char* lds, uint32_t tile_local, uint32_t tag, VvmLaunchState* ls, uint32_t dbg, Pending& pend,
-                  uint32_t& resolves, const u64 (&pre)[VVM_LB_WORDS_PER_LANE], bool have_pre)
+                  uint32_t& resolves, const u64 (&pre)[VVM_LB_WORDS_PER_LANE], bool have_pre,
+                  RVEC& K0, RVEC& K1, RVEC& K2, RVEC& K3, RVEC& K4, RVEC& K5, RVEC& K6, RVEC& K7)
 {
+	// The register file starts every tile as zeros, except in the light kernel: there it is carried from tile to tile (K0..K7),
+	// because the previous tile's riding outputs are still in registers VVM_LIGHT_RIDE_REG, +1 (the loads below replace registers 0..7).
 	RVEC R0 = 0.0f, R1 = 0.0f, R2 = 0.0f, R3 = 0.0f, R4 = 0.0f, R5 = 0.0f, R6 = 0.0f, R7 = 0.0f;
+	if constexpr (IS_LIGHT(V, SPILL)) { R0 = K0; R1 = K1; R2 = K2; R3 = K3; R4 = K4; R5 = K5; R6 = K6; R7 = K7; }
 	uint32_t* lds_ctrl = (uint32_t*)lds;
 	// acquireindex state of the tile: all wave-uniform except keep and rank
 	uint32_t t_keep = 0, t_rank = 0, t_rank_b = 0;      // (t_rank_b: the second half of an eight-instance tile)
@@ -1232,6 +1269,7 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 				float a[V];
 				fetch<V, SPILL>(RARGS, uni, c, o0, a);
 				switch (op) {
+				case VVM_DOP_COPY: SETF(A);
 				case VVM_OP_rcp: SETF(f_rcp(A));
 				case VVM_OP_rsq: SETF(f_rsq(A));
 				case VVM_OP_sqrt: SETF(f_sqrtg(A));
@@ -1408,7 +1446,7 @@ leave_run:
 		// tile's look-back has been in flight since this tile was claimed.
 		if (pend.active) {
 			resolve_tile<V>(pend, c, lds_ctrl, resolves, tag, ls, dbg, pre, have_pre);
-			store_tile<V, FULL, IS_LIGHT(V, SPILL)>(pend, c, lds, dbg);
+			store_tile<V, FULL, IS_LIGHT(V, SPILL)>(pend, c, lds, dbg, RARGS);
 			__syncthreads();      // every thread has read its staged values: the slots may be written again
 		}
 		if (op == VVM_DOP_ACQUIRE) continue;
@@ -1420,9 +1458,9 @@ leave_run:
 			Pending cur;
 			cur.active = true; cur.unresolved = t_pending; cur.total = t_total; cur.base = t_base;
 			cur.stage_end = stage_end; cur.last = last_tile;
-			cur.tile_local = tile_local; cur.status = status; cur.out_list = c.out_list;
+			cur.tile_local = tile_local; cur.status = status; cur.out_list = c.out_list; cur.ride = 0;
 			resolve_tile<V>(cur, c, lds_ctrl, resolves, tag, ls, dbg, pre, false);
-			store_tile<V, FULL, IS_LIGHT(V, SPILL)>(cur, c, lds, dbg);
+			store_tile<V, FULL, IS_LIGHT(V, SPILL)>(cur, c, lds, dbg, RARGS);
 			__syncthreads();      // the slots are written again right away
 			t_base = cur.base; t_pending = false; stage_end = 0;
 			continue;
@@ -1497,6 +1535,8 @@ leave_run:
 	pend.active = (stage_end != 0) || t_pending;
 	pend.unresolved = t_pending; pend.total = t_total; pend.base = t_base; pend.stage_end = stage_end; pend.last = last_tile;
 	pend.tile_local = tile_local; pend.status = status; pend.out_list = c.out_list;
+	pend.ride = t_keep | (t_rank << 8) | (t_rank_b << 20);
+	if constexpr (IS_LIGHT(V, SPILL)) { K0 = R0; K1 = R1; K2 = R2; K3 = R3; K4 = R4; K5 = R5; K6 = R6; K7 = R7; }
 }
 
 // DBG: the bring-up switches of KernelEnv::debug_skip are compiled in (one instantiation only); otherwise they cost nothing.
@@ -1508,9 +1548,10 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (IS_LIGHT(V, SPILL) ? 3 : V
 	uint32_t* lds_ctrl = (uint32_t*)lds;
 	uint8_t* lds_perlin = lds + LDS_PERLIN_OFF;
 	float* lds_spill = (float*)(lds + LDS_SPILL_OFF(V, FULL, IS_LIGHT(V, SPILL)));
+	RVEC K0 = 0.0f, K1 = 0.0f, K2 = 0.0f, K3 = 0.0f, K4 = 0.0f, K5 = 0.0f, K6 = 0.0f, K7 = 0.0f;      // (light kernel: the register file between tiles)
 	Pending pend;
 	pend.active = false; pend.unresolved = false; pend.last = false; pend.total = 0; pend.base = 0; pend.stage_end = 0; pend.tile_local = 0;
-	pend.status = nullptr; pend.out_list = nullptr;
+	pend.status = nullptr; pend.out_list = nullptr; pend.ride = 0;
 	const uint32_t tid = threadIdx.x;
 	const uint32_t wave = SCALAR(tid >> 6), lane = tid & 63u;
 	// ticket counter of this workgroup's class (see VvmLaunchState); with fewer workgroups than classes only the first
@@ -1595,7 +1636,8 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (IS_LIGHT(V, SPILL) ? 3 : V
 		c.valid = min(num_instances - tile_first, (uint32_t)(VVM_BLOCK_THREADS * V));
 		c.phase = phase;
 		if (!(dbgw & 1u))
-			run_tile<V, SPILL, FULL>((const VvmIns*)DESC_PTR(dp, prog), (gu64*)DESC_PTR(dp, status), last_tile, c, lds, tile_local, tag, env.ls, dbgw, pend, resolves, pre, have_pre);
+			run_tile<V, SPILL, FULL>((const VvmIns*)DESC_PTR(dp, prog), (gu64*)DESC_PTR(dp, status), last_tile, c, lds, tile_local, tag, env.ls, dbgw, pend, resolves, pre, have_pre,
+			                         K0, K1, K2, K3, K4, K5, K6, K7);
 	}
 	if (pend.active) {
 		Ctx c;
@@ -1603,7 +1645,7 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (IS_LIGHT(V, SPILL) ? 3 : V
 		c.tid = tid; c.wave = wave; c.inst0 = 0; c.num_instances = 0; c.tile_first = 0; c.valid = 0; c.phase = 0;
 		const u64 none[VVM_LB_WORDS_PER_LANE] = {};
 		resolve_tile<V>(pend, c, lds_ctrl, resolves, tag, env.ls, dbgw, none, false);
-		store_tile<V, FULL, IS_LIGHT(V, SPILL)>(pend, c, lds, dbgw);
+		store_tile<V, FULL, IS_LIGHT(V, SPILL)>(pend, c, lds, dbgw, K0, K1, K2, K3, K4, K5, K6, K7);
 	}
 
 	// the last workgroup to leave re-arms the launch words for the next launch

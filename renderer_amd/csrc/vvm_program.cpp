@@ -217,9 +217,11 @@ static const uint32_t kMaxSpillNarrow = 128;   // 1 KB each
 // 0..num_loaded-1 (the load instructions address consecutive numbers) and give them up after their last use; a register that
 // is read before anything wrote it keeps a register of its own from the top of the program (its content is whatever the last
 // tile left, as the reference's is whatever its batch memory held).  Returns the number of registers in use after packing.
-static uint32_t reallocate_registers(std::vector<VvmIns>& code, uint32_t num_loaded, uint32_t provisional)
+// Values written to the provisional registers from `first_ride` on keep fixed registers outside the packed ones:
+// VVM_LIGHT_RIDE_REG + (provisional number - first_ride).
+static uint32_t reallocate_registers(std::vector<VvmIns>& code, uint32_t num_loaded, uint32_t provisional, uint32_t first_ride = 0xFFFFFFFFu)
 {
-	struct Value { int32_t def, last; uint32_t reg; };
+	struct Value { int32_t def, last; uint32_t reg; bool fixed; };
 	struct Ref { uint32_t ins, field, value; };
 	std::vector<Value> values;
 	std::vector<Ref> refs;
@@ -229,7 +231,7 @@ static uint32_t reallocate_registers(std::vector<VvmIns>& code, uint32_t num_loa
 		uint32_t& w = (&k.w1)[f >> 1];
 		w = (f & 1) ? (w & 0xFFFFu) | (v << 16) : (w & 0xFFFF0000u) | v;
 	};
-	for (uint32_t i = 0; i < num_loaded; ++i) { values.push_back(Value{-1, -1, i}); holds[i] = (int32_t)i; }
+	for (uint32_t i = 0; i < num_loaded; ++i) { values.push_back(Value{-1, -1, i, false}); holds[i] = (int32_t)i; }
 	for (uint32_t p = 0; p < code.size(); ++p) {
 		VvmIns& k = code[p];
 		const uint32_t op = k.w0 & 0xFFu;
@@ -244,7 +246,7 @@ static uint32_t reallocate_registers(std::vector<VvmIns>& code, uint32_t num_loa
 			const uint32_t o = field_of(k, f);
 			if (VVM_OPND_CLS(o) != VVM_OPC_VREG) continue;
 			const uint32_t r = VVM_OPND_IDX(o);
-			if (holds[r] < 0) { holds[r] = (int32_t)values.size(); values.push_back(Value{-1, -1, 0}); }
+			if (holds[r] < 0) { holds[r] = (int32_t)values.size(); values.push_back(Value{-1, -1, 0, false}); }
 			values[(size_t)holds[r]].last = (int32_t)p;
 			refs.push_back(Ref{p, f, (uint32_t)holds[r]});
 		}
@@ -253,14 +255,14 @@ static uint32_t reallocate_registers(std::vector<VvmIns>& code, uint32_t num_loa
 			if (VVM_OPND_CLS(o) == VVM_OPC_VREG) {
 				const uint32_t r = VVM_OPND_IDX(o);
 				holds[r] = (int32_t)values.size();
-				values.push_back(Value{(int32_t)p, (int32_t)p, 0});
+				values.push_back(Value{(int32_t)p, (int32_t)p, r >= first_ride ? VVM_LIGHT_RIDE_REG + (r - first_ride) : 0u, r >= first_ride});
 				refs.push_back(Ref{p, 5, (uint32_t)holds[r]});
 			}
 		}
 	}
 	// linear scan in order of definition; the lowest free register first
 	std::vector<uint32_t> order;
-	for (uint32_t v = num_loaded; v < values.size(); ++v) order.push_back(v);
+	for (uint32_t v = num_loaded; v < values.size(); ++v) if (!values[v].fixed) order.push_back(v);
 	std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return values[a].def < values[b].def; });
 	std::vector<int32_t> busy_until(num_loaded, 0);      // per register: last instruction that reads the value it holds
 	for (uint32_t i = 0; i < num_loaded; ++i) busy_until[i] = values[i].last;
@@ -598,6 +600,32 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 	// script has an update_id, the last entry of every group is kept for it (-1 where it is not used).
 	const size_t group_capacity = light ? VVM_LIGHT_GROUP_SLOTS : lp.updates_ids ? VVM_STAGE_SLOTS - 1 : VVM_STAGE_SLOTS;
 	size_t out_cursor = 0;           // next free entry
+	// light programs: the 32-bit outputs that fall on entries six and seven of the list wait in registers instead of staging slots
+	// (VVM_LIGHT_RIDE_REG); what each of them outputs, as an operand
+	// Which outputs: as many as the script has beyond six, by preference those whose value an instruction after the acquireindex
+	// makes (that instruction then writes the ride register directly); any other value gets there by a copy.
+	const uint32_t first_ride = num_loaded + nv;      // provisional registers of the two
+	struct Ride { uint32_t src; size_t at; bool direct; };      // source operand, the program position of the output, value made after the acquireindex
+	std::vector<Ride> rides_;
+	size_t rides_wanted = 0, acquire_at = (size_t)-1;
+	if (light) {
+		size_t total_pairs = 0;
+		for (size_t q = 0; q < ins.size(); ++q) if (needed[q] && ins[q].kind == K_OUTPUT) total_pairs += ins[q].pairs.size();
+		rides_wanted = total_pairs > VVM_LIGHT_GROUP_SLOTS ? std::min<size_t>(2, total_pairs - VVM_LIGHT_GROUP_SLOTS) : 0;
+	}
+	auto ins_field = [](VvmIns& k, uint32_t f) -> uint32_t { const uint32_t w = (&k.w1)[f >> 1]; return (f & 1) ? w >> 16 : w & 0xFFFFu; };
+	auto ins_set_field = [](VvmIns& k, uint32_t f, uint32_t v) {
+		uint32_t& w = (&k.w1)[f >> 1];
+		w = (f & 1) ? (w & 0xFFFFu) | (v << 16) : (w & 0xFFFF0000u) | v;
+	};
+	auto ordinary = [](const VvmIns& k) { const uint32_t op = k.w0 & 0xFFu; return op != VVM_OP_done && op < VVM_DOP_LOADN16; };
+	// the instruction before position `before` that last wrote per-lane register operand `reg` (lp.code.size(): none)
+	auto last_def = [&](uint32_t reg, size_t before) -> size_t {
+		for (size_t q = before; q-- > 0;)
+			if (ordinary(lp.code[q]) && ins_field(lp.code[q], 5) == reg) return q;
+		return lp.code.size();
+	};
+	if (light && first_ride + 2 > VVM_MAX_OPND_INDEX) { err = "script does not fit the light eight-wide kernel"; return VVM_E_UNSUPPORTED_OP; }
 	size_t open_group = 0;           // group the instructions emitted so far stage into
 	auto open_slot = [&]() -> size_t {
 		if (out_cursor % VVM_STAGE_SLOTS == group_capacity) out_cursor = (out_cursor / VVM_STAGE_SLOTS + 1) * VVM_STAGE_SLOTS;
@@ -643,6 +671,7 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 		case K_ACQUIRE:
 			if (multi_pass && d.dataset != pass_dataset) break;       // another pass's dataset
 			acquired_dataset = (int)d.dataset;
+			if (acquire_at == (size_t)-1) acquire_at = lp.code.size();
 			k.w0 = VVM_INS_W0(VVM_DOP_ACQUIRE, 1, 0, d.dataset, d.in.size() == 2 ? d.fn : VVM_ACQ_SIGN);      // (fn: the folded compare, see fold_compares_into_acquires)
 			k.w1 = operand(d.in[0]) | (d.in.size() == 2 ? operand(d.in[1]) << 16 : 0u);
 			lp.code.push_back(k);
@@ -657,6 +686,22 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 			// (VectorVMRuntime.cpp:565, 769): its list entry stays empty.
 			const bool live = acquired_dataset >= 0 && (uint32_t)acquired_dataset == d.dataset;
 			for (size_t i = 0; i < d.pairs.size();) {
+				if (light && dop == VVM_DOP_OUTPUT32 && live && rides_.size() < 2) {
+					const uint32_t src = operand(d.pairs[i].first);
+					bool direct = false;
+					if (VVM_OPND_CLS(src) == VVM_OPC_VREG && rides_.size() < rides_wanted) {
+						const size_t def = last_def(src, lp.code.size());
+						direct = def < lp.code.size() && def > acquire_at;
+						for (const Ride& r : rides_) if (r.src == src && last_def(src, r.at) == def) direct = false;      // (the same value twice: the second one is copied)
+					}
+					if (direct || out_cursor % VVM_STAGE_SLOTS >= VVM_LIGHT_GROUP_SLOTS) {
+						if (lp.out_list.size() < VVM_STAGE_SLOTS) { lp.out_list.resize(VVM_STAGE_SLOTS, -1); lp.out_is16.resize(VVM_STAGE_SLOTS, 0); }
+						lp.out_list[VVM_LIGHT_GROUP_SLOTS + rides_.size()] = (int32_t)(d.pairs[i].second - out0);
+						rides_.push_back(Ride{src, lp.code.size(), direct});
+						++i;
+						continue;
+					}
+				}
 				// sources in o0..o2; the destinations are consecutive entries of the output list, first one in w3
 				const size_t at = open_slot();
 				const size_t n = std::min<size_t>(std::min<size_t>(3, d.pairs.size() - i), group_capacity - at % VVM_STAGE_SLOTS);
@@ -727,12 +772,32 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 		default: break;
 		}
 	}
+	// the riding outputs, last one first (a copy that is inserted moves what follows it)
+	for (size_t n = rides_.size(); n-- > 0;) {
+		const Ride& r = rides_[n];
+		const uint32_t ride_reg = VVM_OPND(VVM_OPC_VREG, first_ride + (uint32_t)n);
+		if (!r.direct) {
+			lp.code.insert(lp.code.begin() + (ptrdiff_t)r.at, VvmIns{VVM_INS_W0(VVM_DOP_COPY, 1, 1, 0, 0), r.src, 0, ride_reg << 16});
+			continue;
+		}
+		// the instruction that makes the value writes the ride register, and so reads everyone who reads the value: up to the
+		// instruction that puts the next value into the register it had
+		const size_t def = last_def(r.src, r.at);
+		ins_set_field(lp.code[def], 5, ride_reg);
+		for (size_t q = def + 1; q < lp.code.size(); ++q) {
+			VvmIns& k = lp.code[q];
+			const uint32_t op = k.w0 & 0xFFu;
+			const uint32_t reads = ordinary(k) ? (k.w0 >> 8) & 7u : (op >= VVM_DOP_OUTPUT32 && op <= VVM_DOP_OUTPUT32_FROM16) ? (k.w0 >> 16) & 0xFFu : 0u;
+			for (uint32_t f = 0; f < reads; ++f) if (ins_field(k, f) == r.src) ins_set_field(k, f, ride_reg);
+			if (ordinary(k) && ins_field(k, 5) == r.src) break;
+		}
+	}
 	lp.code.push_back(VvmIns{VVM_INS_W0(VVM_OP_done, 0, 0, 0, 0), 0, 0, 0});
 	lp.code.push_back(VvmIns{VVM_INS_W0(VVM_OP_done, 0, 0, 0, 0), 0, 0, 0});   // the kernel fetches one instruction ahead
 	// pack the per-lane registers, then choose the kernel shape: up to 16 registers: everything in VGPRs at full occupancy
 	// (four or eight instances per lane); up to 32 + LDS slots: the four-wide kernel with 32 resident registers; beyond: one
 	// instance per lane.  Registers past the resident ones live in LDS slots.
-	const uint32_t packed = reallocate_registers(lp.code, num_loaded, num_loaded + nv);
+	const uint32_t packed = reallocate_registers(lp.code, num_loaded, num_loaded + nv + 2, light ? first_ride : 0xFFFFFFFFu);
 	uint32_t V = 4, RV = 16;
 	if (packed > 16) RV = 32;
 	if (force_narrow || packed > RV + kMaxSpillWide) { V = 1; RV = 32; }
@@ -743,10 +808,10 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 	}
 	if (light) {
 		// the light eight-wide kernel: eight resident registers, one load instruction of 32-bit streams into registers 0.., ops of at
-		// most four operands, none of the transcendental / noise / ID instructions, one acquired dataset, and at most six outputs: with
-		// three workgroups per CU the LDS has room for six staging slots each, and a second group of slots would have to resolve
-		// the tile's look-back on the spot (measured: 1.04 ms against 0.84 ms of the general kernel on eight outputs of 64 Mi
-		// instances; so was parking two outputs in global memory, which came out even with the general kernel)
+		// most four operands, none of the transcendental / noise / ID instructions, one acquired dataset, and at most eight outputs: with
+		// three workgroups per CU the LDS has room for six staging slots each, two more 32-bit outputs wait in registers, and a second
+		// group of slots would have to resolve the tile's look-back on the spot (measured: 1.04 ms against 0.84 ms of the general
+		// kernel on eight outputs of 64 Mi instances; so was parking two outputs in global memory: 0.85 ms)
 		bool ok = packed <= 8 && V == 4 && !lp.full_kernel && !lp.uses_ids && lp.num_passes == 1 && prefetch16.empty() && !prefetch32.empty() && prefetch32.size() <= 8;
 		for (const VvmIns& k : lp.code) {
 			const uint32_t op = k.w0 & 0xFFu;

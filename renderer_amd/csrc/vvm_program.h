@@ -41,7 +41,8 @@ struct LinkedProgram {
 	uint32_t resident_regs = 16;
 	uint32_t lds_spill_slots = 0;
 	bool     many_registers = false;   // runs on the kernels with 32 resident registers (and LDS register slots)
-	bool     light = false;            // linked for the light eight-wide kernel (eight resident registers, output groups of six)
+	bool     light = false;            // linked for the light eight-wide kernel (eight resident registers, six staged outputs and up to
+	                                   // two that wait in registers VVM_LIGHT_RIDE_REG, +1)
 	bool     full_kernel = false;      // needs the transcendental / noise kernel
 	bool     uses_perlin = false;
 	bool     uses_ids = false;         // update_id or acquire_id ...

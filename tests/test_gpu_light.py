@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from renderer_amd import abi
-from renderer_amd.assembler import FLOAT, INT32, Script
+from renderer_amd.assembler import FLOAT, HALF, INT32, Script
 from vm_harness import run_hip, run_oracle
 
 pytestmark = pytest.mark.gpu
@@ -23,8 +23,9 @@ def _both(script, consts, ins, dtypes, n, want_light=True, **kw):
         assert got_n == ref_n
         off = kw.get("instance_offset", 0)
         for k, (a, b) in enumerate(zip(got, ref)):
-            assert np.array_equal(a[off:off + got_n].view(np.uint32), b[off:off + ref_n].view(np.uint32)), "stream %d, flags %d" % (k, flags)
-            assert np.all(a[:off].view(np.uint32) == 0xCDCDCDCD) and np.all(a[off + got_n:].view(np.uint32) == 0xCDCDCDCD), "stream %d written outside its survivors" % k
+            bits, fill = (np.uint16, 0xCDCD) if a.dtype == np.float16 else (np.uint32, 0xCDCDCDCD)
+            assert np.array_equal(a[off:off + got_n].view(bits), b[off:off + ref_n].view(bits)), "stream %d, flags %d" % (k, flags)
+            assert np.all(a[:off].view(bits) == fill) and np.all(a[off + got_n:].view(bits) == fill), "stream %d written outside its survivors" % k
     return ref_n
 
 
@@ -117,18 +118,86 @@ def test_predicate_from_a_constant_and_from_an_input():
         assert survivors == (int((mask < 0).sum()) if from_input else n)
 
 
-def test_seven_outputs_stay_on_the_general_kernel():
+def _chain_script(n_out, half_at=None):
+    """x + c, that + c, ...: one output per link."""
     s = Script()
     x = s.input(0, FLOAT, 0)
-    s.acquireindex(s.const(0), 0)
+    keep = s.temp(); s.op("cmplt", x, s.const(2), keep)
+    s.acquireindex(keep, 0)
     outs = []
-    for i in range(7):
+    for i in range(n_out):
         t = s.temp(); s.op("add", x, s.const(1), t)
         outs.append(t)
         x = t
-    s.output_data(FLOAT, 0, [(t, s.output(0, FLOAT, i)) for i, t in enumerate(outs)])
-    n = 4100
-    _both(s.build(), [struct.pack("<If", 0xFFFFFFFF, 0.5) + bytes(8)], [np.linspace(0, 1, n).astype(f32)], [f32] * 7, n, want_light=False)
+    for i, t in enumerate(outs):
+        if i == half_at:
+            s.output_data(HALF, 0, [(t, s.output(0, HALF, 0))])
+        else:
+            s.output_data(FLOAT, 0, [(t, s.output(0, FLOAT, i - (half_at is not None and i > half_at)))])
+    return s.build()
+
+
+CHAIN_CONSTS = struct.pack("<Iff", 0xFFFFFFFF, 0.5, 0.7) + bytes(4)
+
+
+@pytest.mark.parametrize("n_out,light", [(6, True), (7, True), (8, True), (9, False)])
+@pytest.mark.parametrize("n", [2048, 9001])
+def test_seventh_and_eighth_output_wait_in_registers(n_out, light, n):
+    """Six outputs are staged in LDS; two more stay in registers until the next tile knows the position; nine need a second group
+    of slots, which the light kernel does not have."""
+    x = np.linspace(0, 1, n).astype(f32)
+    survivors = _both(_chain_script(n_out), [CHAIN_CONSTS], [x], [f32] * n_out, n, want_light=light, instance_offset=2)
+    assert 0 < survivors < n
+
+
+def test_half_outputs_are_staged_and_a_32_bit_output_rides_instead():
+    n = 5000
+    x = np.linspace(0, 1, n).astype(f32)
+    for half_at in (6, 2):      # (only 32-bit outputs can wait in registers: the linker picks one of those, wherever the half output comes)
+        _both(_chain_script(7, half_at), [CHAIN_CONSTS], [x], [f32] * 6 + [np.float16], n)
+
+
+def test_riding_outputs_that_need_a_copy():
+    """Outputs seven and eight are an input stream and a constant (nothing after the acquireindex makes them), the same value goes to
+    two outputs, and a temp is written again after it was output."""
+    s = Script()
+    a, b = s.input(0, FLOAT, 0), s.input(0, FLOAT, 1)
+    early = s.temp(); s.op("mul", a, b, early)                      # made before the acquireindex
+    keep = s.temp(); s.op("cmpge", a, s.const(1), keep)
+    s.acquireindex(keep, 0)
+    t = s.temp(); s.op("add", a, b, t)
+    s.output_data(FLOAT, 0, [(t, s.output(0, FLOAT, 0)), (t, s.output(0, FLOAT, 1))])
+    s.op("sub", a, b, t)                                            # the temp again, after its first value was output
+    u = s.temp(); s.op("mul", t, t, u)
+    s.output_data(FLOAT, 0, [(t, s.output(0, FLOAT, 2)), (u, s.output(0, FLOAT, 3)), (early, s.output(0, FLOAT, 4)), (a, s.output(0, FLOAT, 5))])
+    s.output_data(FLOAT, 0, [(b, s.output(0, FLOAT, 6)), (s.const(2), s.output(0, FLOAT, 7))])
+    n = 7001
+    rng = np.random.default_rng(8)
+    ins = [rng.standard_normal(n).astype(f32), rng.standard_normal(n).astype(f32)]
+    survivors = _both(s.build(), [struct.pack("<Iff", 0, 0.25, 3.5) + bytes(4)], ins, [f32] * 8, n)
+    assert 0 < survivors < n
+
+
+def test_eight_pass_through_streams():
+    """Eight streams in, the same eight out: every register is taken by a stream, the two riding outputs are copies."""
+    s = Script()
+    xs = [s.input(0, FLOAT, i) for i in range(8)]
+    keep = s.temp(); s.op("cmplt", xs[0], xs[1], keep)
+    s.acquireindex(keep, 0)
+    s.output_data(FLOAT, 0, [(x, s.output(0, FLOAT, i)) for i, x in enumerate(xs)])
+    n = 12345
+    rng = np.random.default_rng(4)
+    ins = [rng.standard_normal(n).astype(f32) for _ in range(8)]
+    survivors = _both(s.build(), [bytes(16)], ins, [f32] * 8, n)
+    assert 0 < survivors < n
+
+
+@pytest.mark.parametrize("kill_half", [False, True])
+def test_fountain_on_the_light_kernel_across_many_tiles(kill_half):
+    from renderer_amd import scripts
+    w = scripts.fountain()
+    n = 1_000_003
+    _both(w.script, [w.constants], scripts.fountain_streams_np(0, n, kill_half=kill_half), [f32] * 8, n)
 
 
 def test_large_exec_takes_the_light_kernel_by_itself():

@@ -144,6 +144,39 @@ def test_register_index_out_of_range_is_rejected():
 
 
 # ---- linker ---------------------------------------------------------------------------------------------------------------------
+def test_fountain_links_for_the_light_kernel_with_two_outputs_in_registers():
+    """Eight outputs: six are staged, two stay in registers 8 and 9, which the instructions that make their values write directly
+    (both come after the acquireindex), so the program has no copy and two output instructions."""
+    w = scripts.fountain()
+    code = [decode(i) for i in be().inspect_code(w.script.blob, 2)]
+    ops = [c["op"] for c in code]
+    assert ops[0] == DOP_LOADN and code[0]["aux"] == 8 and ops.count(DOP_OUT32) == 2 and 189 not in ops and 197 not in ops
+    at = ops.index(DOP_ACQUIRE)
+    writers = {idx(c["o"][5]): k for k, c in enumerate(code) if 0 < c["op"] < 190}
+    assert writers[8] > at and writers[9] > at and max(writers) == 9
+    assert sorted(r for r in writers if r < 8) == sorted(set(r for r in writers if r < 8))
+    staged = [o for c in code if c["op"] == DOP_OUT32 for o in c["o"][:c["aux"]]]
+    assert len(staged) == 6 and all(idx(o) < 8 for o in staged)
+
+
+def test_light_link_copies_values_that_nothing_after_the_acquireindex_makes():
+    s = Script()
+    xs = [s.input(0, FLOAT, i) for i in range(8)]
+    keep = s.temp(); s.op("cmplt", xs[0], xs[1], keep)
+    s.acquireindex(keep, 0)
+    s.output_data(FLOAT, 0, [(x, s.output(0, FLOAT, i)) for i, x in enumerate(xs)])
+    code = [decode(i) for i in be().inspect_code(s.build().blob, 2)]
+    copies = [c for c in code if c["op"] == 189]
+    assert [idx(c["o"][5]) for c in copies] == [8, 9] and [idx(c["o"][0]) for c in copies] == [6, 7]
+    # nine outputs need a second group of staging slots: no light program
+    s = Script()
+    x = s.input(0, FLOAT, 0)
+    s.acquireindex(s.const(0), 0)
+    s.output_data(FLOAT, 0, [(x, s.output(0, FLOAT, i)) for i in range(9)])
+    with pytest.raises(abi.VVMError):
+        be().inspect_code(s.build().blob, 2)
+
+
 def test_fountain_links_to_the_expected_program():
     w = scripts.fountain()
     code = [decode(i) for i in be().inspect_code(w.script.blob)]
