@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--which", default="transcendental,kill_half,batch")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--no-light", action="store_true", help="keep eight-wide Execs on the general kernel")
+    ap.add_argument("--batch-flags", type=int, default=0, help="vvm_exec_options.Flags of every member of the batch (4: force eight instances per lane)")
     args = ap.parse_args()
     import torch
     from renderer_amd import abi, scripts
@@ -150,7 +151,7 @@ def main():
             states.append(st)
             off = e * per * 4
             frames.append(st.frame([abi.DataSet([t.data_ptr() + off for t in ins], [t.data_ptr() + off for t in outs], 0)], per, [w.constants]))
-            opts.append(abi.ExecOptions(0, 0, 0, None, 0))
+            opts.append(abi.ExecOptions(0, 0, 0, None, args.batch_flags))
         arr, oarr = be.pack_batch(frames, opts)
         for _ in range(2):
             be.exec_batch_packed(arr, oarr)
