@@ -169,26 +169,30 @@ DEV int32_t cvtt(float a) { const int32_t q = (int32_t)a; return (a >= -21474836
 DEV int32_t cvtr(float a) { const int32_t q = __float2int_rn(a); return (a >= -2147483648.0f && a < 2147483648.0f) ? q : (int32_t)0x80000000; }
 DEV float   i2f(int32_t a) { return (float)a; }                                               // SSE.h:3407
 
-DEV float ue_atan2(float Y, float X)                                                          // GenericPlatformMath.cpp:33-76
+// atan2 as the reference computes it (GenericPlatformMath.cpp:33-76): reduce to the first octant, where the ratio of the smaller to
+// the larger magnitude lies in [0, 1]; the angle there is ratio * P(ratio^2) with the reference's six minimax coefficients, evaluated
+// by Horner's rule in single precision in this order (bit parity depends on it); then undo the reduction by three reflections.
+DEV float first_octant_angle(float ratio)
 {
-	const float PI = 3.1415926535897932f;
-	const float ax = f_abs(X), ay = f_abs(Y);
-	const bool ybig = ay > ax;
-	float t0 = ybig ? ay : ax, t1 = ybig ? ax : ay;
-	const bool zero = (t0 == 0.f);
-	float t3 = t1 / t0, t4 = t3 * t3;
-	t0 = +7.2128853633444123e-03f;
-	t0 = t0 * t4 + -3.5059680836411644e-02f;
-	t0 = t0 * t4 + +8.1675882859940430e-02f;
-	t0 = t0 * t4 + -1.3374657325451267e-01f;
-	t0 = t0 * t4 + +1.9856563505717162e-01f;
-	t0 = t0 * t4 + -3.3324998579202170e-01f;
-	t0 = t0 * t4 + 1.0f;
-	t3 = t0 * t3;
-	t3 = ybig ? (0.5f * PI) - t3 : t3;
-	t3 = (X < 0.0f) ? PI - t3 : t3;
-	t3 = (Y < 0.0f) ? -t3 : t3;
-	return zero ? 0.f : t3;
+	const float coeff[7] = {+7.2128853633444123e-03f, -3.5059680836411644e-02f, +8.1675882859940430e-02f, -1.3374657325451267e-01f,
+	                        +1.9856563505717162e-01f, -3.3324998579202170e-01f, 1.0f};
+	const float square = ratio * ratio;
+	float poly = coeff[0];
+#pragma unroll
+	for (int i = 1; i < 7; ++i) poly = poly * square + coeff[i];
+	return poly * ratio;
+}
+DEV float ue_atan2(float y, float x)
+{
+	const float pi = 3.1415926535897932f;
+	const float mag_x = f_abs(x), mag_y = f_abs(y);
+	const bool steep = mag_y > mag_x;                                   // above the diagonal: the roles of x and y swap
+	const float larger = steep ? mag_y : mag_x, smaller = steep ? mag_x : mag_y;
+	float angle = first_octant_angle(smaller / larger);
+	angle = steep ? (0.5f * pi) - angle : angle;                        // reflect about the diagonal
+	angle = (x < 0.0f) ? pi - angle : angle;                            // ... about the vertical axis
+	angle = (y < 0.0f) ? -angle : angle;                                // ... about the horizontal axis
+	return (larger == 0.f) ? 0.f : angle;                               // atan2(0, 0) = 0 (:47-50)
 }
 DEV float f_acos(float a) { return ue_atan2(f_sqrtg((1.0f - a) * (1.0f + a)), a); }           // RT.cpp:1924
 DEV float f_asin(float a) { return (3.14159265359f * 0.25f) - f_acos(a); }                    // RT.cpp:1925 with :111
