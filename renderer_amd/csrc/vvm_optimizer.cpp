@@ -220,6 +220,7 @@ struct Optimizer {
 	void reorder(int one_past_last_input);
 	void sort_output_runs();
 	void merge_ops();
+	bool apply_merge_rule(uint32_t first, uint32_t second, int found);
 	void build_io_tables();
 	void minimise_temps();
 	void alias_outputs();
@@ -553,6 +554,181 @@ void Optimizer::sort_output_runs()
 	}
 }
 
+// ---- the merged opcodes as data -------------------------------------------------------------------------------------------------
+// One row per way two instructions fold into a merged opcode of VectorVM.h:153-231 (the decisions of VectorVMOptimizer.cpp:
+// 1815-2518).  `first` makes a value that `second` reads; the row says which pairs it covers, what vetoes it, and how the merged
+// instruction's operands are taken from the two.  Rows for one (first, second) are tried in table order and the first whose
+// conditions hold decides; a veto on that row means the pair stays as it is.
+namespace merge {
+enum Reads : uint8_t {       // how `second` reads `first` (what the pair search found)
+	R_ANY,                   // no condition
+	R_OPERAND,               // through exactly one of its operands
+	R_OPERAND0, R_OPERAND1,  // ... through that operand
+	R_EXEC_INDEX,            // `first` is exec_index and `second` its only reader
+	R_TWIN                   // the two have the same inputs (the *_2x forms and sin_cos): the reference's search for these never
+	                         // yields a pair (see merge_ops), so the rows are inert; they are listed because the reference has them
+};
+enum At : uint8_t {          // where first's result sits among second's operands, compared by name and register class
+	AT_ANY, AT_0, AT_1, AT_2, AT_0_OR_1
+};
+enum : uint8_t {
+	F_END_PASS = 1,          // no merge, and the whole pass ends here (the reference returns from the pass: :2095-2098)
+	F_EXEC_ADDI = 2          // the veto of exec_index + addi (below)
+};
+constexpr uint8_t NO_VETO = 0xFF;
+// `take`: the merged instruction's registers, inputs then outputs, two characters each:
+//   a<i> / b<i>   register i of first / second (inputs first, then outputs)
+//   bs            of a two-input `second`, the input that is not first's result: input 1 if input 0 equals the result, else input 0
+//   bk            the same choice made from the pair search's finding instead of a comparison
+struct Rule {
+	uint8_t first, second;
+	uint8_t reads, at;
+	uint8_t merged, nin, nout;
+	const char* take;
+	uint8_t dup_lo, dup_hi;  // veto when first's result appears twice among second's operands [dup_lo, dup_hi] (NO_VETO: no such check)
+	uint8_t flags;
+};
+#define CHAIN1 "a0bsb2"              /* a one-input first, a two-input second */
+#define CHAIN2 "a0a1bsb2"            /* two-input first */
+#define CHAIN3 "a0a1a2bsb2"          /* three-input first */
+static const Rule kRules[] = {
+	{VVM_OP_exec_index, VVM_OP_i2f,  R_EXEC_INDEX, AT_ANY, VVM_OP_exec_indexf,     0, 1, "b1",   NO_VETO, 0, 0},
+	{VVM_OP_exec_index, VVM_OP_addi, R_EXEC_INDEX, AT_ANY, VVM_OP_exec_index_addi, 1, 1, "bsb2", NO_VETO, 0, F_EXEC_ADDI},
+	// compare + select: the "greater" and "not equal" forms use the opposite compare with the two selected values swapped
+	{VVM_OP_cmplt,   VVM_OP_select, R_OPERAND0, AT_ANY, VVM_OP_cmplt_select,  4, 1, "a0a1b1b2b3", NO_VETO, 0, 0},
+	{VVM_OP_cmple,   VVM_OP_select, R_OPERAND0, AT_ANY, VVM_OP_cmple_select,  4, 1, "a0a1b1b2b3", NO_VETO, 0, 0},
+	{VVM_OP_cmpgt,   VVM_OP_select, R_OPERAND0, AT_ANY, VVM_OP_cmple_select,  4, 1, "a0a1b2b1b3", NO_VETO, 0, 0},
+	{VVM_OP_cmpge,   VVM_OP_select, R_OPERAND0, AT_ANY, VVM_OP_cmplt_select,  4, 1, "a0a1b2b1b3", NO_VETO, 0, 0},
+	{VVM_OP_cmpeq,   VVM_OP_select, R_OPERAND0, AT_ANY, VVM_OP_cmpeq_select,  4, 1, "a0a1b1b2b3", NO_VETO, 0, 0},
+	{VVM_OP_cmpneq,  VVM_OP_select, R_OPERAND0, AT_ANY, VVM_OP_cmpeq_select,  4, 1, "a0a1b2b1b3", NO_VETO, 0, 0},
+	{VVM_OP_cmplti,  VVM_OP_select, R_OPERAND0, AT_ANY, VVM_OP_cmplti_select, 4, 1, "a0a1b1b2b3", NO_VETO, 0, 0},
+	{VVM_OP_cmplei,  VVM_OP_select, R_OPERAND0, AT_ANY, VVM_OP_cmplei_select, 4, 1, "a0a1b1b2b3", NO_VETO, 0, 0},
+	{VVM_OP_cmpgti,  VVM_OP_select, R_OPERAND0, AT_ANY, VVM_OP_cmplei_select, 4, 1, "a0a1b2b1b3", NO_VETO, 0, 0},
+	{VVM_OP_cmpgei,  VVM_OP_select, R_OPERAND0, AT_ANY, VVM_OP_cmplti_select, 4, 1, "a0a1b2b1b3", NO_VETO, 0, 0},
+	{VVM_OP_cmpeqi,  VVM_OP_select, R_OPERAND0, AT_ANY, VVM_OP_cmpeqi_select, 4, 1, "a0a1b1b2b3", NO_VETO, 0, 0},
+	{VVM_OP_cmpneqi, VVM_OP_select, R_OPERAND0, AT_ANY, VVM_OP_cmpeqi_select, 4, 1, "a0a1b2b1b3", NO_VETO, 0, 0},
+	// (compare + logic_and / logic_or: twenty-four rows, generated: see rules())
+	{VVM_OP_mad, VVM_OP_mad,  R_OPERAND, AT_2,   VVM_OP_mad_mad0, 5, 1, "a0a1a2b0b1b3", 0, 3, 0},      // first is second's addend
+	{VVM_OP_mad, VVM_OP_mad,  R_OPERAND, AT_ANY, VVM_OP_mad_mad1, 5, 1, "a0a1a2bsb2b3", 0, 3, 0},      // first is a factor of second
+	{VVM_OP_mad, VVM_OP_add,  R_OPERAND, AT_ANY, VVM_OP_mad_add,  4, 1, CHAIN3, NO_VETO, 0, 0},
+	{VVM_OP_mad, VVM_OP_mul,  R_OPERAND, AT_ANY, VVM_OP_mad_mul,  4, 1, CHAIN3, NO_VETO, 0, 0},
+	{VVM_OP_mad, VVM_OP_sub,  R_OPERAND, AT_0,   VVM_OP_mad_sub0, 4, 1, CHAIN3, NO_VETO, 0, 0},
+	{VVM_OP_mad, VVM_OP_sub,  R_OPERAND, AT_ANY, VVM_OP_mad_sub1, 4, 1, CHAIN3, NO_VETO, 0, 0},
+	{VVM_OP_mad, VVM_OP_sqrt, R_OPERAND, AT_ANY, VVM_OP_mad_sqrt, 3, 1, "a0a1a2b1", NO_VETO, 0, 0},
+	{VVM_OP_mul, VVM_OP_mad,  R_OPERAND, AT_0,   VVM_OP_mul_mad0, 4, 1, "a0a1b1b2b3", NO_VETO, 0, 0},
+	{VVM_OP_mul, VVM_OP_mad,  R_OPERAND, AT_1,   VVM_OP_mul_mad0, 4, 1, "a0a1b0b2b3", NO_VETO, 0, 0},
+	{VVM_OP_mul, VVM_OP_mad,  R_OPERAND, AT_2,   VVM_OP_mul_mad1, 4, 1, "a0a1b0b1b3", NO_VETO, 0, 0},
+	{VVM_OP_mul, VVM_OP_add,  R_OPERAND, AT_ANY, VVM_OP_mul_add,  3, 1, CHAIN2, 0, 1, 0},
+	{VVM_OP_mul, VVM_OP_sub,  R_OPERAND, AT_0,   VVM_OP_mul_sub0, 3, 1, CHAIN2, 0, 1, 0},
+	{VVM_OP_mul, VVM_OP_sub,  R_OPERAND, AT_ANY, VVM_OP_mul_sub1, 3, 1, CHAIN2, 0, 1, 0},
+	{VVM_OP_mul, VVM_OP_mul,  R_OPERAND, AT_ANY, VVM_OP_mul_mul,  3, 1, CHAIN2, 0, 1, 0},
+	{VVM_OP_mul, VVM_OP_max,  R_OPERAND, AT_ANY, VVM_OP_mul_max,  3, 1, CHAIN2, 0, 1, 0},
+	{VVM_OP_mul, VVM_OP_mul,  R_TWIN,    AT_ANY, VVM_OP_mul_2x,   2, 2, "a0a1a2b2", NO_VETO, 0, 0},
+	// add + mad merges only when the sum is the mad's addend; any other add + mad ends the pass
+	{VVM_OP_add, VVM_OP_mad,  R_OPERAND, AT_2,   VVM_OP_add_mad1, 4, 1, "a0a1b0b1b3", 0, 2, 0},
+	{VVM_OP_add, VVM_OP_mad,  R_OPERAND, AT_ANY, 0,               0, 0, "", NO_VETO, 0, F_END_PASS},
+	{VVM_OP_add, VVM_OP_add,  R_OPERAND, AT_ANY, VVM_OP_add_add,  3, 1, CHAIN2, NO_VETO, 0, 0},
+	{VVM_OP_sub, VVM_OP_cmplt, R_OPERAND1, AT_ANY, VVM_OP_sub_cmplt1, 3, 1, "a0a1b0b2", NO_VETO, 0, 0},
+	{VVM_OP_sub, VVM_OP_neg,  R_OPERAND, AT_ANY, VVM_OP_sub_neg,  2, 1, "a0a1b1", NO_VETO, 0, 0},
+	{VVM_OP_sub, VVM_OP_mul,  R_OPERAND, AT_ANY, VVM_OP_sub_mul,  3, 1, CHAIN2, NO_VETO, 0, 0},
+	{VVM_OP_div, VVM_OP_mad,  R_OPERAND, AT_0_OR_1, VVM_OP_div_mad0, 4, 1, "a0a1bsb2b3", NO_VETO, 0, 0},      // the quotient must be a factor of the mad
+	{VVM_OP_div, VVM_OP_f2i,  R_OPERAND, AT_ANY, VVM_OP_div_f2i,  2, 1, "a0a1b1", NO_VETO, 0, 0},
+	{VVM_OP_div, VVM_OP_mul,  R_OPERAND, AT_ANY, VVM_OP_div_mul,  3, 1, CHAIN2, NO_VETO, 0, 0},
+	{VVM_OP_muli, VVM_OP_addi, R_ANY, AT_ANY, VVM_OP_muli_addi, 3, 1, CHAIN2, NO_VETO, 0, 0},
+	{VVM_OP_addi, VVM_OP_bit_rshift, R_ANY, AT_ANY, VVM_OP_addi_bit_rshift, 3, 1, CHAIN2, NO_VETO, 0, 0},
+	{VVM_OP_addi, VVM_OP_muli, R_ANY, AT_ANY, VVM_OP_addi_muli, 3, 1, CHAIN2, NO_VETO, 0, 0},
+	{VVM_OP_b2i, VVM_OP_b2i,  R_TWIN, AT_ANY, VVM_OP_b2i_2x, 1, 2, "a0a1b1", NO_VETO, 0, 0},
+	{VVM_OP_i2f, VVM_OP_div,  R_OPERAND, AT_0,   VVM_OP_i2f_div0, 2, 1, "a0b1b2", NO_VETO, 0, 0},          // the converted value is the numerator
+	{VVM_OP_i2f, VVM_OP_div,  R_OPERAND, AT_ANY, VVM_OP_i2f_div1, 2, 1, "a0b0b2", NO_VETO, 0, 0},
+	{VVM_OP_i2f, VVM_OP_mul,  R_OPERAND, AT_ANY, VVM_OP_i2f_mul,  2, 1, CHAIN1, NO_VETO, 0, 0},
+	{VVM_OP_i2f, VVM_OP_mad,  R_OPERAND, AT_0,   VVM_OP_i2f_mad0, 3, 1, "a0b1b2b3", NO_VETO, 0, 0},
+	{VVM_OP_i2f, VVM_OP_mad,  R_OPERAND, AT_1,   VVM_OP_i2f_mad0, 3, 1, "a0b0b2b3", NO_VETO, 0, 0},
+	{VVM_OP_i2f, VVM_OP_mad,  R_OPERAND, AT_ANY, VVM_OP_i2f_mad1, 3, 1, "b0b1a0b3", NO_VETO, 0, 0},
+	{VVM_OP_f2i, VVM_OP_select, R_OPERAND1, AT_ANY, VVM_OP_f2i_select1, 3, 1, "b0a0b2b3", NO_VETO, 0, 0},
+	{VVM_OP_f2i, VVM_OP_maxi, R_OPERAND, AT_ANY, VVM_OP_f2i_maxi, 2, 1, CHAIN1, NO_VETO, 0, 0},
+	{VVM_OP_f2i, VVM_OP_addi, R_OPERAND, AT_ANY, VVM_OP_f2i_addi, 2, 1, CHAIN1, NO_VETO, 0, 0},
+	{VVM_OP_bit_and, VVM_OP_i2f, R_ANY, AT_ANY, VVM_OP_bit_and_i2f, 2, 1, "a0a1b1", NO_VETO, 0, 0},
+	{VVM_OP_random, VVM_OP_random, R_TWIN, AT_ANY, VVM_OP_random_2x, 1, 2, "a0a1b1", NO_VETO, 0, 0},
+	{VVM_OP_select, VVM_OP_mul, R_ANY, AT_ANY, VVM_OP_select_mul, 4, 1, CHAIN3, NO_VETO, 0, 0},
+	{VVM_OP_select, VVM_OP_add, R_ANY, AT_ANY, VVM_OP_select_add, 4, 1, CHAIN3, NO_VETO, 0, 0},
+	{VVM_OP_sin, VVM_OP_cos, R_TWIN, AT_ANY, VVM_OP_sin_cos, 1, 2, "a0a1b1", NO_VETO, 0, 0},                 // (sine first in the merged form)
+	{VVM_OP_cos, VVM_OP_sin, R_TWIN, AT_ANY, VVM_OP_sin_cos, 1, 2, "a0b1a1", NO_VETO, 0, 0},
+	{VVM_OP_neg, VVM_OP_cmplt, R_OPERAND, AT_ANY, VVM_OP_neg_cmplt, 2, 1, "a0bkb2", NO_VETO, 0, 0},
+	{VVM_OP_random, VVM_OP_add, R_OPERAND, AT_ANY, VVM_OP_random_add, 2, 1, "a0bkb2", NO_VETO, 0, 0},
+	{VVM_OP_max, VVM_OP_f2i, R_OPERAND0, AT_ANY, VVM_OP_max_f2i, 2, 1, "a0a1b1", NO_VETO, 0, 0},
+	{VVM_OP_bit_rshift, VVM_OP_bit_and, R_ANY, AT_ANY, VVM_OP_bit_rshift_bit_and, 3, 1, CHAIN2, NO_VETO, 0, 0},
+	{VVM_OP_fmod, VVM_OP_add, R_ANY, AT_ANY, VVM_OP_fmod_add, 3, 1, CHAIN2, NO_VETO, 0, 0},
+	{VVM_OP_bit_or, VVM_OP_muli, R_ANY, AT_ANY, VVM_OP_bit_or_muli, 3, 1, CHAIN2, NO_VETO, 0, 0},
+	{VVM_OP_bit_lshift, VVM_OP_bit_or, R_ANY, AT_ANY, VVM_OP_bit_lshift_bit_or, 3, 1, CHAIN2, NO_VETO, 0, 0},
+};
+#undef CHAIN1
+#undef CHAIN2
+#undef CHAIN3
+// the table above plus compare + logic_and / logic_or (the merged opcodes follow the compares' order, VectorVM.h:165-188)
+static const std::vector<Rule>& rules()
+{
+	static const std::vector<Rule> all = [] {
+		std::vector<Rule> v(std::begin(kRules), std::end(kRules));
+		static const uint8_t compares[12] = {VVM_OP_cmplt, VVM_OP_cmple, VVM_OP_cmpgt, VVM_OP_cmpge, VVM_OP_cmpeq, VVM_OP_cmpneq,
+		                                     VVM_OP_cmplti, VVM_OP_cmplei, VVM_OP_cmpgti, VVM_OP_cmpgei, VVM_OP_cmpeqi, VVM_OP_cmpneqi};
+		for (int x = 0; x < 12; ++x) {
+			v.push_back(Rule{compares[x], VVM_OP_logic_and, R_OPERAND, AT_ANY, (uint8_t)(VVM_OP_cmplt_logic_and + x), 3, 1, "a0a1bsb2", NO_VETO, 0, 0});
+			v.push_back(Rule{compares[x], VVM_OP_logic_or, R_OPERAND, AT_ANY, (uint8_t)(VVM_OP_cmplt_logic_or + x), 3, 1, "a0a1bsb2", NO_VETO, 0, 0});
+		}
+		return v;
+	}();
+	return all;
+}
+}  // namespace merge
+
+// Folds instruction `second` and the instruction `first` it reads into one, if a rule covers the pair.  `found`: what the pair
+// search recorded (0: exec_index and its reader; 1 << x: operand x of second reads first; -1: twins).  Returns false when the
+// pass has to end.
+bool Optimizer::apply_merge_rule(uint32_t first, uint32_t second, int found)
+{
+	using namespace merge;
+	Ins& a = ins[first];
+	Ins& b = ins[second];
+	const uint32_t ar = a.regs, br = b.regs;
+	const uint32_t result = a.nin;                      // first's (first) result among its registers
+	auto equal = [&](uint32_t ai, uint32_t bi) { return ssa[ar + ai] == ssa[br + bi] && cls[ar + ai] == cls[br + bi]; };
+	for (const Rule& r : rules()) {
+		if (r.first != a.op || r.second != b.op) continue;
+		const bool reads_ok = r.reads == R_ANY || (r.reads == R_OPERAND && found >= 1) || (r.reads == R_OPERAND0 && found == 1) ||
+		                      (r.reads == R_OPERAND1 && found == 2) || (r.reads == R_EXEC_INDEX && found == 0) || (r.reads == R_TWIN && found == -1);
+		if (!reads_ok) continue;
+		const bool at_ok = r.at == AT_ANY || (r.at == AT_0 && equal(result, 0)) || (r.at == AT_1 && equal(result, 1)) || (r.at == AT_2 && equal(result, 2)) ||
+		                   (r.at == AT_0_OR_1 && (equal(result, 0) || equal(result, 1)));
+		if (!at_ok) continue;
+		if (r.flags & F_END_PASS) return false;
+		if (r.dup_lo != NO_VETO) {
+			// first's result twice among second's operands (e.g. mul(t, t)): no merged form (RegDupeCheck, :432-452)
+			for (uint32_t x = r.dup_lo; x < r.dup_hi; ++x)
+				if (ssa[br + x] == ssa[ar + result] && cls[br + x] == RT_TEMP)
+					for (uint32_t y = x + 1; y <= r.dup_hi; ++y)
+						if (ssa[br + x] == ssa[br + y] && cls[br + x] == cls[br + y]) return true;
+		}
+		const uint32_t count = (uint32_t)strlen(r.take) / 2;
+		const uint32_t nr = new_regs((int)count);
+		// exec_index + addi: not when both addends match the register that follows exec_index's result in the register list (the
+		// reference compares register 1 of an instruction that has one, :1840-1846; kept, registers allocated first as there)
+		if ((r.flags & F_EXEC_ADDI) && equal(1, 0) && equal(1, 1)) return true;
+		for (uint32_t t = 0; t < count; ++t) {
+			const char who = r.take[2 * t], which = r.take[2 * t + 1];
+			uint32_t from;
+			if (who == 'a') from = ar + (uint32_t)(which - '0');
+			else if (which == 's') from = br + (equal(result, 0) ? 1u : 0u);
+			else if (which == 'k') from = br + (found == 1 ? 1u : 0u);
+			else from = br + (uint32_t)(which - '0');
+			reg[nr + t] = reg[from]; ssa[nr + t] = ssa[from]; cls[nr + t] = cls[from];
+		}
+		a.merged_into = (int)second;
+		b.op = r.merged; b.nin = r.nin; b.nout = r.nout; b.regs = nr;
+		return true;
+	}
+	return true;
+}
+
 // Steps 13-14 (:1582-2518): pairs of ops where the second reads the first one's result (and nothing else does) are folded into
 // the merged opcodes of VectorVM.h:153-231.
 void Optimizer::merge_ops()
@@ -616,225 +792,8 @@ void Optimizer::merge_ops()
 	}
 
 	for (const Pair& pr : pairs) {
-		Ins& a = ins[pr.first];
-		Ins& b = ins[pr.second];
-		if (a.merged_into != -1 || b.merged_into != -1) continue;
-		const uint32_t ar = a.regs, br = b.regs;
-		uint32_t nr = 0;
-		auto fresh = [&](int n) { nr = new_regs(n); };
-		auto from_a = [&](int to, int from) { reg[nr + to] = reg[ar + from]; ssa[nr + to] = ssa[ar + from]; cls[nr + to] = cls[ar + from]; };
-		auto from_b = [&](int to, int from) { reg[nr + to] = reg[br + from]; ssa[nr + to] = ssa[br + from]; cls[nr + to] = cls[br + from]; };
-		auto same = [&](int ai, int bi) { return ssa[ar + ai] == ssa[br + bi] && cls[ar + ai] == cls[br + bi]; };
-		auto merged = [&](int op, int nin, int nout) { a.merged_into = (int)pr.second; b.op = (uint8_t)op; b.nin = nin; b.nout = nout; b.regs = nr; };
-		// does `second` read the result of `first` (its operand `a_out`) twice among its operands [lo, hi]?  (RegDupeCheck, :432-452)
-		auto reads_twice = [&](int a_out, int lo, int hi) {
-			for (int x = lo; x < hi; ++x)
-				if (ssa[br + x] == ssa[ar + a_out] && cls[br + x] == RT_TEMP)
-					for (int y = x + 1; y <= hi; ++y)
-						if (ssa[br + x] == ssa[br + y] && cls[br + x] == cls[br + y]) return true;
-			return false;
-		};
-		// first's inputs, then the operand of a two-input `second` that is not first's result, then second's result
-		auto chain2 = [&](int a_inputs, int op) {
-			fresh(a_inputs + 2);
-			for (int x = 0; x < a_inputs; ++x) from_a(x, x);
-			from_b(a_inputs, same(a_inputs, 0) ? 1 : 0);
-			from_b(a_inputs + 1, 2);
-			merged(op, a_inputs + 1, 1);
-		};
-		const int kind = pr.kind;
-		const uint8_t ao = a.op, bo = b.op;
-		bool stop = false;
-		if (kind == 0) {
-			if (ao == VVM_OP_exec_index && bo == VVM_OP_i2f) { fresh(1); from_b(0, 1); merged(VVM_OP_exec_indexf, 0, 1); }
-			else if (ao == VVM_OP_exec_index && bo == VVM_OP_addi) {
-				fresh(2);
-				if (!(same(1, 0) && same(1, 1))) { from_b(0, same(0, 0) ? 1 : 0); from_b(1, 2); merged(VVM_OP_exec_index_addi, 1, 1); }
-			}
-		} else if (kind == 1 && bo == VVM_OP_select) {
-			int op = 0;
-			bool reverse = false;          // the "greater" and "not equal" forms swap the two selected values
-			switch (ao) {
-			case VVM_OP_cmplt: op = VVM_OP_cmplt_select; break;
-			case VVM_OP_cmple: op = VVM_OP_cmple_select; break;
-			case VVM_OP_cmpgt: op = VVM_OP_cmple_select; reverse = true; break;
-			case VVM_OP_cmpge: op = VVM_OP_cmplt_select; reverse = true; break;
-			case VVM_OP_cmpeq: op = VVM_OP_cmpeq_select; break;
-			case VVM_OP_cmpneq: op = VVM_OP_cmpeq_select; reverse = true; break;
-			case VVM_OP_cmplti: op = VVM_OP_cmplti_select; break;
-			case VVM_OP_cmplei: op = VVM_OP_cmplei_select; break;
-			case VVM_OP_cmpgti: op = VVM_OP_cmplei_select; reverse = true; break;
-			case VVM_OP_cmpgei: op = VVM_OP_cmplti_select; reverse = true; break;
-			case VVM_OP_cmpeqi: op = VVM_OP_cmpeqi_select; break;
-			case VVM_OP_cmpneqi: op = VVM_OP_cmpeqi_select; reverse = true; break;
-			default: break;
-			}
-			if (op) {
-				fresh(5);
-				from_a(0, 0); from_a(1, 1);
-				from_b(2, reverse ? 2 : 1); from_b(3, reverse ? 1 : 2);
-				from_b(4, 3);
-				merged(op, 4, 1);
-			}
-		} else if (kind >= 1 && (bo == VVM_OP_logic_and || bo == VVM_OP_logic_or)) {
-			static const uint8_t cmps[12] = {VVM_OP_cmplt, VVM_OP_cmple, VVM_OP_cmpgt, VVM_OP_cmpge, VVM_OP_cmpeq, VVM_OP_cmpneq,
-			                                 VVM_OP_cmplti, VVM_OP_cmplei, VVM_OP_cmpgti, VVM_OP_cmpgei, VVM_OP_cmpeqi, VVM_OP_cmpneqi};
-			for (int x = 0; x < 12; ++x)
-				if (ao == cmps[x]) { chain2(2, (bo == VVM_OP_logic_and ? VVM_OP_cmplt_logic_and : VVM_OP_cmplt_logic_or) + x); break; }
-		} else if (kind >= 1 && ao == VVM_OP_mad) {
-			switch (bo) {
-			case VVM_OP_mad:
-				if (!reads_twice(3, 0, 3)) {
-					fresh(6);
-					from_a(0, 0); from_a(1, 1); from_a(2, 2);
-					int op;
-					if (same(3, 2)) { op = VVM_OP_mad_mad0; from_b(3, 0); from_b(4, 1); }              // first is the addend of second
-					else { op = VVM_OP_mad_mad1; from_b(3, same(3, 0) ? 1 : 0); from_b(4, 2); }         // first is a factor of second
-					from_b(5, 3);
-					merged(op, 5, 1);
-				}
-				break;
-			case VVM_OP_add: case VVM_OP_mul: case VVM_OP_sub: {
-				int op = bo == VVM_OP_add ? VVM_OP_mad_add : bo == VVM_OP_mul ? VVM_OP_mad_mul : VVM_OP_mad_sub0;
-				if (op == VVM_OP_mad_sub0 && !same(3, 0)) op = VVM_OP_mad_sub1;
-				chain2(3, op);
-				break;
-			}
-			case VVM_OP_sqrt:
-				fresh(4);
-				from_a(0, 0); from_a(1, 1); from_a(2, 2); from_b(3, 1);
-				merged(VVM_OP_mad_sqrt, 3, 1);
-				break;
-			default: break;
-			}
-		} else if (ao == VVM_OP_mul) {
-			if (kind >= 1) {
-				switch (bo) {
-				case VVM_OP_mad: {
-					fresh(5);
-					from_a(0, 0); from_a(1, 1);
-					int op = 0;
-					if (same(2, 0)) { op = VVM_OP_mul_mad0; from_b(2, 1); from_b(3, 2); }
-					else if (same(2, 1)) { op = VVM_OP_mul_mad0; from_b(2, 0); from_b(3, 2); }
-					else if (same(2, 2)) { op = VVM_OP_mul_mad1; from_b(2, 0); from_b(3, 1); }
-					from_b(4, 3);
-					if (op) merged(op, 4, 1);
-					break;
-				}
-				case VVM_OP_add: case VVM_OP_sub: case VVM_OP_mul: case VVM_OP_max:
-					if (!reads_twice(2, 0, 1)) {
-						int op = bo == VVM_OP_add ? VVM_OP_mul_add : bo == VVM_OP_sub ? VVM_OP_mul_sub0 : bo == VVM_OP_mul ? VVM_OP_mul_mul : VVM_OP_mul_max;
-						if (op == VVM_OP_mul_sub0 && !same(2, 0)) op = VVM_OP_mul_sub1;
-						chain2(2, op);
-					}
-					break;
-				default: break;
-				}
-			} else if (kind == -1 && bo == VVM_OP_mul) {
-				fresh(4);
-				from_a(0, 0); from_a(1, 1); from_a(2, 2); from_b(3, 2);
-				merged(VVM_OP_mul_2x, 2, 2);
-			}
-		} else if (kind >= 1 && ao == VVM_OP_add) {
-			if (bo == VVM_OP_mad) {
-				// only when the sum is the mad's addend; anything else ends the whole merge pass in the reference (:2095-2098)
-				if (!same(2, 2)) stop = true;
-				else if (!reads_twice(2, 0, 2)) {
-					fresh(5);
-					from_a(0, 0); from_a(1, 1); from_b(2, 0); from_b(3, 1); from_b(4, 3);
-					merged(VVM_OP_add_mad1, 4, 1);
-				}
-			} else if (bo == VVM_OP_add) chain2(2, VVM_OP_add_add);
-		} else if (kind >= 1 && ao == VVM_OP_sub) {
-			if (bo == VVM_OP_cmplt && kind == 2) {
-				fresh(4);
-				from_a(0, 0); from_a(1, 1); from_b(2, 0); from_b(3, 2);
-				merged(VVM_OP_sub_cmplt1, 3, 1);
-			} else if (bo == VVM_OP_neg) {
-				fresh(3);
-				from_a(0, 0); from_a(1, 1); from_b(2, 1);
-				merged(VVM_OP_sub_neg, 2, 1);
-			} else if (bo == VVM_OP_mul) chain2(2, VVM_OP_sub_mul);
-		} else if (ao == VVM_OP_div && kind >= 1) {
-			if (bo == VVM_OP_mad) {
-				if (same(2, 0) || same(2, 1)) {            // the quotient must be a factor of the mad
-					fresh(5);
-					from_a(0, 0); from_a(1, 1);
-					from_b(2, same(2, 0) ? 1 : 0); from_b(3, 2); from_b(4, 3);
-					merged(VVM_OP_div_mad0, 4, 1);
-				}
-			} else if (bo == VVM_OP_f2i) {
-				fresh(3);
-				from_a(0, 0); from_a(1, 1); from_b(2, 1);
-				merged(VVM_OP_div_f2i, 2, 1);
-			} else if (bo == VVM_OP_mul) chain2(2, VVM_OP_div_mul);
-		} else if (ao == VVM_OP_muli && bo == VVM_OP_addi) chain2(2, VVM_OP_muli_addi);
-		else if (ao == VVM_OP_addi && (bo == VVM_OP_bit_rshift || bo == VVM_OP_muli)) chain2(2, bo == VVM_OP_bit_rshift ? VVM_OP_addi_bit_rshift : VVM_OP_addi_muli);
-		else if (ao == VVM_OP_b2i && bo == VVM_OP_b2i && kind == -1) {
-			fresh(3);
-			from_a(0, 0); from_a(1, 1); from_b(2, 1);
-			merged(VVM_OP_b2i_2x, 1, 2);
-		} else if (ao == VVM_OP_i2f && kind >= 1) {
-			if (bo == VVM_OP_div) {
-				fresh(3);
-				from_a(0, 0);
-				const bool numerator = same(1, 0);
-				from_b(1, numerator ? 1 : 0); from_b(2, 2);
-				merged(numerator ? VVM_OP_i2f_div0 : VVM_OP_i2f_div1, 2, 1);
-			} else if (bo == VVM_OP_mul) chain2(1, VVM_OP_i2f_mul);
-			else if (bo == VVM_OP_mad) {
-				fresh(4);
-				int op = VVM_OP_i2f_mad0;
-				if (same(1, 0)) { from_a(0, 0); from_b(1, 1); from_b(2, 2); }
-				else if (same(1, 1)) { from_a(0, 0); from_b(1, 0); from_b(2, 2); }
-				else { op = VVM_OP_i2f_mad1; from_b(0, 0); from_b(1, 1); from_a(2, 0); }
-				from_b(3, 3);
-				merged(op, 3, 1);
-			}
-		} else if (ao == VVM_OP_f2i && kind >= 1) {
-			if (bo == VVM_OP_select && kind == 2) {
-				fresh(4);
-				from_b(0, 0); from_a(1, 0); from_b(2, 2); from_b(3, 3);
-				merged(VVM_OP_f2i_select1, 3, 1);
-			} else if (bo == VVM_OP_maxi) chain2(1, VVM_OP_f2i_maxi);
-			else if (bo == VVM_OP_addi) chain2(1, VVM_OP_f2i_addi);
-		} else if (ao == VVM_OP_bit_and && bo == VVM_OP_i2f) {
-			fresh(3);
-			from_a(0, 0); from_a(1, 1); from_b(2, 1);
-			merged(VVM_OP_bit_and_i2f, 2, 1);
-		} else if (ao == VVM_OP_random && bo == VVM_OP_random && kind == -1) {
-			fresh(3);
-			from_a(0, 0); from_a(1, 1); from_b(2, 1);
-			merged(VVM_OP_random_2x, 1, 2);
-		} else if (ao == VVM_OP_select && bo == VVM_OP_mul) chain2(3, VVM_OP_select_mul);
-		else if (ao == VVM_OP_select && bo == VVM_OP_add) chain2(3, VVM_OP_select_add);
-		else if (((ao == VVM_OP_cos && bo == VVM_OP_sin) || (ao == VVM_OP_sin && bo == VVM_OP_cos)) && kind == -1) {
-			fresh(3);
-			from_a(0, 0);
-			if (ao == VVM_OP_sin) { from_a(1, 1); from_b(2, 1); }
-			else { from_b(1, 1); from_a(2, 1); }
-			merged(VVM_OP_sin_cos, 1, 2);
-		} else if (ao == VVM_OP_neg && bo == VVM_OP_cmplt && kind >= 1) {
-			fresh(3);
-			from_a(0, 0); from_b(1, kind == 1 ? 1 : 0); from_b(2, 2);
-			merged(VVM_OP_neg_cmplt, 2, 1);
-		} else if (ao == VVM_OP_random && bo == VVM_OP_add && kind >= 1) {
-			fresh(3);
-			from_a(0, 0); from_b(1, kind == 1 ? 1 : 0); from_b(2, 2);
-			merged(VVM_OP_random_add, 2, 1);
-		} else if (ao == VVM_OP_max && bo == VVM_OP_f2i && kind == 1) {
-			fresh(3);
-			from_a(0, 0); from_a(1, 1); from_b(2, 1);
-			merged(VVM_OP_max_f2i, 2, 1);
-		} else {
-			int op = 0;
-			if (ao == VVM_OP_bit_rshift && bo == VVM_OP_bit_and) op = VVM_OP_bit_rshift_bit_and;
-			else if (ao == VVM_OP_fmod && bo == VVM_OP_add) op = VVM_OP_fmod_add;
-			else if (ao == VVM_OP_bit_or && bo == VVM_OP_muli) op = VVM_OP_bit_or_muli;
-			else if (ao == VVM_OP_bit_lshift && bo == VVM_OP_bit_or) op = VVM_OP_bit_lshift_bit_or;
-			if (op) chain2(2, op);
-		}
-		if (stop) break;
+		if (ins[pr.first].merged_into != -1 || ins[pr.second].merged_into != -1) continue;
+		if (!apply_merge_rule(pr.first, pr.second, pr.kind)) break;
 	}
 }
 
