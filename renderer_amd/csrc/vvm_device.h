@@ -56,6 +56,7 @@ enum : uint32_t {
 
 // Output values wait in LDS staging slots until the tile's output position is known; one group of slots is written out at a time.
 #define VVM_STAGE_SLOTS 8
+#define VVM_MAX_ID_USES 8      // datasets with update_id / acquire_id per script
 // The light eight-wide kernel has six staging slots: its programs stage into the first six entries of the output list.  Entries
 // six and seven serve 32-bit outputs whose values stay where they are, in per-lane registers VVM_LIGHT_RIDE_REG and the one after
 // it, until the next tile has resolved the position (no instruction: the kernel looks at the two entries).  A light program
@@ -124,7 +125,7 @@ struct VvmExecDesc {
 	uint32_t flags;
 	uint32_t num_unif;             // constants copied into the uniform register, a multiple of 4, at most VVM_MAX_UNIFORMS
 	uint32_t pad;
-	const VvmIdDesc* ids;          // persistent-ID tables, when the script has update_id / acquire_id
+	const VvmIdDesc* ids;          // persistent-ID tables, one VvmIdDesc per dataset the script's update_id / acquire_id work on (acquire_id's aux2 = which)
 };
 
 enum : uint32_t {

@@ -157,7 +157,9 @@ struct vvm_state {
 	bool cur_counts_in_launch = false;
 	bool any_ids = false;                  // some pass of the script has update_id / acquire_id
 	bool counts_in_launch = false;         // d_counts lies in the spare words of *d_launch: counts and launch words come back in one copy
-	int32_t* h_counts = nullptr;           // pinned: counts, then the launch error word
+	int32_t* h_counts = nullptr;           // pinned, nc = number of datasets: [0, nc) survivor counts and [nc, 2 nc) MaxUsedID per dataset as read
+	                                       // back from d_counts (same layout there), [2 nc, 3 nc) MaxUsedID per dataset on its way to the
+	                                       // device, from word mirror_word() on the launch words as read back
 	ParamRing ring;
 	hipStream_t stream = nullptr;
 	bool own_stream = false;
@@ -180,7 +182,10 @@ struct vvm_state {
 	// persistent IDs (update_id / acquire_id): scratch of the MaxUsedID pass, and what the write-back after the Exec needs
 	uint32_t* d_chunk_prefix = nullptr; uint32_t chunk_capacity = 0;
 	int32_t*  d_id_scratch = nullptr;   uint32_t id_scratch_capacity = 0;
-	int32_t   id_num_free_start = 0, id_num_spawned_start = 0;
+	std::vector<int32_t> id_num_free_start, id_num_spawned_start;      // per dataset: the counters when the Exec was enqueued
+	uint32_t id_datasets = 0;              // one more than the highest dataset an update_id / acquire_id names
+	size_t num_datasets() const { return std::max<uint32_t>(std::max<uint32_t>(script.max_output_dataset, 1), id_datasets); }
+	size_t mirror_word() const { return 3 * num_datasets() + 4; }
 	uint32_t  last_width = 0;          // instances per lane of the kernel the last Exec ran on
 	int       device = -1;             // ordinal of the device that holds the state's memory (the one current at vvm_alloc_state)
 };
@@ -352,16 +357,16 @@ int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, P
 	pe.off_load = align_up(pe.off_in + 8u * (size_t)s.num_inputs, 64);
 	pe.off_out = align_up(pe.off_load + 8u * pe.lp->load_list.size(), 64) + 64;      // (the entry before the list is in use too)
 	pe.off_ids = align_up(pe.off_out + 8u * align_up(pe.lp->out_list.size(), VVM_STAGE_SLOTS), 16);
-	pe.bytes = align_up(pe.off_ids + (pe.lp->uses_ids ? sizeof(VvmIdDesc) : 0), 256);      // (the block itself is 256-byte aligned)
+	pe.bytes = align_up(pe.off_ids + pe.lp->id_uses.size() * sizeof(VvmIdDesc), 256);      // (the block itself is 256-byte aligned)
 	(void)O;
 	reference_chunking(s, ctx, pe.chunk_instances, pe.num_chunks);
-	if (pe.lp->uses_ids) {
+	for (const vvm::LinkedProgram::IdUse& use : pe.lp->id_uses) {
 		// update_id / acquire_id: the tables must be there, in device memory, and small enough for 32-bit byte offsets
-		if ((int)pe.lp->id_dataset >= ctx->DataSets.num) return fail(VVM_E_INVALID_ARG, "the script's ID instructions name a dataset the context does not provide");
-		const vvm_dataset_meta& ds = ctx->DataSets.data[pe.lp->id_dataset];
+		if ((int)use.dataset >= ctx->DataSets.num) return fail(VVM_E_INVALID_ARG, "the script's ID instructions name a dataset the context does not provide");
+		const vvm_dataset_meta& ds = ctx->DataSets.data[use.dataset];
 		if (!ds.FreeIDTable || !ds.FreeIDTable->data || !ds.NumFreeIDs) return fail(VVM_E_INVALID_ARG, "the script has ID instructions but the dataset has no FreeIDTable / NumFreeIDs");
 		if (ds.FreeIDTable->max < 0 || ds.FreeIDTable->max > (1 << 29)) return fail(VVM_E_INVALID_ARG, "FreeIDTable->Max() out of range");
-		if (pe.lp->updates_ids) {
+		if (use.updates) {
 			if (!ds.IDTable || !ds.IDTable->data || !ds.MaxUsedID) return fail(VVM_E_INVALID_ARG, "update_id needs the dataset's IDTable and MaxUsedID");
 			if (ds.IDTable->num < 0 || ds.IDTable->num > (1 << 29)) return fail(VVM_E_INVALID_ARG, "IDTable->Num() out of range");
 			if ((int64_t)*ds.NumFreeIDs + ctx->NumInstances > ds.FreeIDTable->max) return fail(VVM_E_INVALID_ARG, "FreeIDTable cannot take the IDs of every instance");
@@ -374,6 +379,10 @@ int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, P
 			if ((int64_t)*ds.NumFreeIDs > (int64_t)ds.FreeIDTable->max - *ds.NumSpawnedIDs - ctx->NumInstances)
 				return fail(VVM_E_INVALID_ARG, "the free IDs and the spawned-ID log overlap in FreeIDTable");
 		}
+		// two datasets of one Exec must not share ID tables (each is worked on as if alone)
+		for (const vvm::LinkedProgram::IdUse& other : pe.lp->id_uses)
+			if (other.dataset < use.dataset && (int)other.dataset < ctx->DataSets.num && ctx->DataSets.data[other.dataset].FreeIDTable == ds.FreeIDTable)
+				return fail(VVM_E_INVALID_ARG, "two datasets with ID instructions share one FreeIDTable");
 	}
 	return VVM_OK;
 }
@@ -466,9 +475,11 @@ int fill_params(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* op
 	for (size_t k = 0; k < lp.out_list.size(); ++k) {
 		if (lp.out_is16[k]) out_list[k & ~(size_t)(VVM_STAGE_SLOTS - 1)] |= VVM_OUT_GROUP16;
 	}
-	if (lp.uses_ids) {
-		const vvm_dataset_meta& ds = ctx->DataSets.data[lp.id_dataset];
-		VvmIdDesc* ids = (VvmIdDesc*)(host + pe.off_ids);
+	if (lp.uses_ids) d->ids = (const VvmIdDesc*)(dev + pe.off_ids);      // (dev is an address here: checked above)
+	for (size_t u = 0; u < lp.id_uses.size(); ++u) {
+		const vvm::LinkedProgram::IdUse& use = lp.id_uses[u];
+		const vvm_dataset_meta& ds = ctx->DataSets.data[use.dataset];
+		VvmIdDesc* ids = (VvmIdDesc*)(host + pe.off_ids) + u;
 		memset(ids, 0, sizeof(*ids));
 		ids->id_table = ds.IDTable ? ds.IDTable->data : nullptr;
 		ids->id_table_num = ds.IDTable ? (uint32_t)ds.IDTable->num : 0;
@@ -476,9 +487,8 @@ int fill_params(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* op
 		ids->free_table_max = (uint32_t)ds.FreeIDTable->max;
 		ids->chunk_prefix = st->d_chunk_prefix;
 		ids->id_scratch = st->d_id_scratch;
-		const size_t ncounts = std::max<uint32_t>(s.max_output_dataset, 1);
-		ids->max_id = d->counts + ncounts;                      // the word after the survivor counts
-		ids->survivors = d->counts + lp.id_dataset;
+		ids->max_id = d->counts + st->num_datasets() + use.dataset;      // the dataset's word behind the survivor counts
+		ids->survivors = d->counts + use.dataset;
 		ids->instance_offset = ds.InstanceOffset;
 		ids->num_free_start = *ds.NumFreeIDs;
 		ids->num_spawned_start = ds.NumSpawnedIDs ? *ds.NumSpawnedIDs : 0;
@@ -486,13 +496,12 @@ int fill_params(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* op
 		ids->chunk_instances = pe.chunk_instances;
 		ids->num_instances = (uint32_t)ctx->NumInstances;
 		ids->num_chunks = pe.num_chunks;
-		d->ids = (const VvmIdDesc*)(dev + pe.off_ids);      // (dev is an address here: checked above)
-		for (size_t k = 0; k < lp.out_list.size(); ++k)
-			if (lp.out_list[k] == -2) {
-				out_list[k] = (uint64_t)(uintptr_t)d->ids | VVM_OUT_UPDATE_ID;
-				out_list[k & ~(size_t)(VVM_STAGE_SLOTS - 1)] |= VVM_OUT_GROUP16;
-			}
 	}
+	for (size_t k = 0; k < lp.out_list.size(); ++k)
+		if (lp.out_list[k] <= -2) {      // an update_id: the entry is the address of its dataset's descriptor
+			out_list[k] = (uint64_t)(uintptr_t)(d->ids + (size_t)(-2 - lp.out_list[k])) | VVM_OUT_UPDATE_ID;
+			out_list[k & ~(size_t)(VVM_STAGE_SLOTS - 1)] |= VVM_OUT_GROUP16;
+		}
 	return VVM_OK;
 }
 
@@ -567,7 +576,12 @@ VVM_API vvm_state* vvm_alloc_state(const uint8_t* blob, size_t num_bytes)
 	}
 	if ((e = hipMalloc((void**)&st->d_launch, sizeof(VvmLaunchState))) != hipSuccess) return bail(e, "hipMalloc(launch state)");
 	if ((e = reset_launch_state(st->d_launch)) != hipSuccess) return bail(e, "reset(launch state)");
-	const size_t ncounts = std::max<uint32_t>(st->script.max_output_dataset, 1) + 4;
+	for (const vvm::LinkedProgram::IdUse& u : st->wide.id_uses) st->id_datasets = std::max(st->id_datasets, u.dataset + 1);
+	for (const vvm::LinkedProgram& more : st->wide_more)
+		for (const vvm::LinkedProgram::IdUse& u : more.id_uses) st->id_datasets = std::max(st->id_datasets, u.dataset + 1);
+	const size_t ncounts = 2 * st->num_datasets() + 4;      // (survivor counts, then one MaxUsedID word per dataset)
+	st->id_num_free_start.assign(st->num_datasets(), 0);
+	st->id_num_spawned_start.assign(st->num_datasets(), 0);
 	if (ncounts * 4 <= sizeof(((VvmLaunchState*)nullptr)->reserved)) {
 		// (a synchronous Exec of a small emitter is bound by the round trips of the call: one copy back instead of two is 4 of 25 us)
 		st->d_counts = (int32_t*)((uint8_t*)st->d_launch + offsetof(VvmLaunchState, reserved));      // zeroed with the launch words
@@ -576,8 +590,9 @@ VVM_API vvm_state* vvm_alloc_state(const uint8_t* blob, size_t num_bytes)
 		if ((e = hipMalloc((void**)&st->d_counts, ncounts * 4)) != hipSuccess) return bail(e, "hipMalloc(counts)");
 		if ((e = hipMemset(st->d_counts, 0, ncounts * 4)) != hipSuccess) return bail(e, "hipMemset(counts)");
 	}
-	if ((e = hipHostMalloc((void**)&st->h_counts, ncounts * 4 + sizeof(VvmLaunchState), hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc(counts)");
-	memset(st->h_counts, 0, ncounts * 4 + sizeof(VvmLaunchState));
+	const size_t host_bytes = st->mirror_word() * 4 + sizeof(VvmLaunchState);
+	if ((e = hipHostMalloc((void**)&st->h_counts, host_bytes, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc(counts)");
+	memset(st->h_counts, 0, host_bytes);
 	if ((e = hipStreamCreateWithFlags(&st->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
 	st->own_stream = true;
 	return st;
@@ -667,7 +682,6 @@ static int exec_enqueue(vvm_exec_context* ctx, const vvm_exec_options* opt, bool
 	unsigned long long* const d_status = no_alloc ? (unsigned long long*)(scratch_ptr + VVM_NOALLOC_STATUS_OFF) : st->d_status;
 	st->cur_status = d_status;
 	st->cur_status_words = no_alloc ? (size_t)VVM_NOALLOC_MAX_TILES : (size_t)st->status_capacity;
-	const size_t ncounts = std::max<uint32_t>(st->script.max_output_dataset, 1);
 	const bool timed = st->timing && st->ev_used < 4096 && (!no_alloc || st->ev_used < st->ev_start.size());      // (no new events without allocating)
 	if (timed) {
 		if (st->ev_used == st->ev_start.size()) {
@@ -685,11 +699,12 @@ static int exec_enqueue(vvm_exec_context* ctx, const vvm_exec_options* opt, bool
 			rc = prepare(st, ctx, opt, pe, pass);
 			if (rc != VVM_OK) return rc;
 		}
-		if (pe.lp->uses_ids) {
-			const vvm_dataset_meta& ds = ctx->DataSets.data[pe.lp->id_dataset];
-			st->id_num_free_start = *ds.NumFreeIDs;
-			st->id_num_spawned_start = ds.NumSpawnedIDs ? *ds.NumSpawnedIDs : 0;
-			if (pe.lp->updates_ids) {
+		for (const vvm::LinkedProgram::IdUse& use : pe.lp->id_uses) {
+			const vvm_dataset_meta& ds = ctx->DataSets.data[use.dataset];
+			st->id_num_free_start[use.dataset] = *ds.NumFreeIDs;
+			st->id_num_spawned_start[use.dataset] = ds.NumSpawnedIDs ? *ds.NumSpawnedIDs : 0;
+			if (use.updates) {
+				// (one update_id per pass, and the passes follow each other on the stream: they share the two buffers)
 				if (pe.num_chunks > st->chunk_capacity || (uint32_t)ctx->NumInstances > st->id_scratch_capacity) {
 					HIP_TRY(hipStreamSynchronize(stream));
 					if (st->d_chunk_prefix) HIP_TRY(hipFree(st->d_chunk_prefix));
@@ -700,8 +715,9 @@ static int exec_enqueue(vvm_exec_context* ctx, const vvm_exec_options* opt, bool
 					HIP_TRY(hipMalloc((void**)&st->d_id_scratch, (size_t)st->id_scratch_capacity * 4));
 				}
 				// MaxUsedID starts from the caller's value (the kernel only ever raises it, VectorVMRuntime.cpp:1383-1399)
-				st->h_counts[ncounts + 1] = *ds.MaxUsedID;
-				HIP_TRY(hipMemcpyAsync(st->d_counts + ncounts, st->h_counts + ncounts + 1, 4, hipMemcpyHostToDevice, stream));
+				const size_t nd = st->num_datasets();
+				st->h_counts[2 * nd + use.dataset] = *ds.MaxUsedID;
+				HIP_TRY(hipMemcpyAsync(st->d_counts + nd + use.dataset, st->h_counts + 2 * nd + use.dataset, 4, hipMemcpyHostToDevice, stream));
 			}
 		}
 		// A small block travels as a kernel argument; a larger one, or one whose ID descriptor other kernels read, through a slot
@@ -730,8 +746,9 @@ static int exec_enqueue(vvm_exec_context* ctx, const vvm_exec_options* opt, bool
 		                                       inline_block ? local_block : nullptr, inline_block ? (uint32_t)pe.bytes : 0u, 0u);
 		if (lrc != 0) return hip_fail((hipError_t)lrc, "kernel launch");
 		if (timed && pass + 1 == num_passes) { HIP_TRY(hipEventRecord(st->ev_stop[st->ev_used], stream)); st->ev_used++; }
-		if (pe.lp->uses_ids && pe.lp->updates_ids) {
-			const int mrc = vvm_launch_max_id_kernel((const VvmIdDesc*)(st->ring.dev[slot] + pe.off_ids), pe.num_chunks, stream);
+		for (size_t u = 0; u < pe.lp->id_uses.size(); ++u) {
+			if (!pe.lp->id_uses[u].updates) continue;
+			const int mrc = vvm_launch_max_id_kernel((const VvmIdDesc*)(st->ring.dev[slot] + pe.off_ids) + u, pe.num_chunks, stream);
 			if (mrc != 0) return hip_fail((hipError_t)mrc, "MaxUsedID kernel launch");
 		}
 		if (slot >= 0) {
@@ -751,28 +768,28 @@ VVM_API int vvm_exec_finish(vvm_exec_context* ctx)
 	vvm_state* st = ctx->VVMState;
 	const bool ran = ctx->NumInstances > 0;
 	if (st->last_stream) {
-		const size_t nc = std::max<uint32_t>(st->script.max_output_dataset, 1);
+		const size_t nc = st->num_datasets(), mirror = st->mirror_word();
+		const size_t with_ids = st->any_ids ? 2 * nc : nc;      // words to read back: the survivor counts, and the MaxUsedID words behind them
 		const bool pending = st->results_pending;
 		const bool with_caller = st->counts_src && st->counts_src != st->cur_counts;      // counts left with the caller
 		if (pending) {
 			if (with_caller) {
 				HIP_TRY(hipMemcpyAsync(st->h_counts, st->counts_src, nc * 4, hipMemcpyDeviceToHost, st->last_stream));
-				HIP_TRY(hipMemcpyAsync(st->h_counts + nc + 4, st->cur_launch, 80, hipMemcpyDeviceToHost, st->last_stream));
-			} else if (st->cur_counts_in_launch) {      // the launch words up to and including stats[], then the counts and the MaxUsedID word behind them
-				HIP_TRY(hipMemcpyAsync(st->h_counts + nc + 4, st->cur_launch, offsetof(VvmLaunchState, reserved) + (nc + 1) * 4, hipMemcpyDeviceToHost, st->last_stream));
+				HIP_TRY(hipMemcpyAsync(st->h_counts + mirror, st->cur_launch, 80, hipMemcpyDeviceToHost, st->last_stream));
+			} else if (st->cur_counts_in_launch) {      // the launch words up to and including stats[], then the counts and the MaxUsedID words behind them
+				HIP_TRY(hipMemcpyAsync(st->h_counts + mirror, st->cur_launch, offsetof(VvmLaunchState, reserved) + with_ids * 4, hipMemcpyDeviceToHost, st->last_stream));
 			} else {
-				HIP_TRY(hipMemcpyAsync(st->h_counts, st->cur_counts, (nc + 1) * 4, hipMemcpyDeviceToHost, st->last_stream));     // (and the MaxUsedID word)
-				HIP_TRY(hipMemcpyAsync(st->h_counts + nc + 4, st->cur_launch, 80, hipMemcpyDeviceToHost, st->last_stream));     // the words up to and including stats[]
+				HIP_TRY(hipMemcpyAsync(st->h_counts, st->cur_counts, with_ids * 4, hipMemcpyDeviceToHost, st->last_stream));     // (and the MaxUsedID words)
+				HIP_TRY(hipMemcpyAsync(st->h_counts + mirror, st->cur_launch, 80, hipMemcpyDeviceToHost, st->last_stream));     // the words up to and including stats[]
 			}
 		}
 		HIP_TRY(hipStreamSynchronize(st->last_stream));
-		if (pending && st->cur_counts_in_launch && !with_caller) memcpy(st->h_counts, (const uint8_t*)(st->h_counts + nc + 4) + offsetof(VvmLaunchState, reserved), (nc + 1) * 4);
+		if (pending && st->cur_counts_in_launch && !with_caller) memcpy(st->h_counts, (const uint8_t*)(st->h_counts + mirror) + offsetof(VvmLaunchState, reserved), with_ids * 4);
 	}
 	st->results_pending = false;
 	st->in_flight = false;
 	if (ran) {
-		const size_t ncounts = std::max<uint32_t>(st->script.max_output_dataset, 1);
-		const VvmLaunchState* ls = (const VvmLaunchState*)(st->h_counts + ncounts + 4);
+		const VvmLaunchState* ls = (const VvmLaunchState*)(st->h_counts + st->mirror_word());
 		if (getenv("VVM_DEBUG_STATS"))
 			fprintf(stderr, "vvm stats (cumulative): lookbacks %llu rounds %llu polls %llu clocks/16 %llu | ticket %llu load %llu interp %llu tiles %llu\n", ls->stats[0], ls->stats[1], ls->stats[2], ls->stats[3], ls->stats[4], ls->stats[5], ls->stats[6], ls->stats[7]);
 		if (ls->pad != 0) {
@@ -783,20 +800,26 @@ VVM_API int vvm_exec_finish(vvm_exec_context* ctx)
 			return fail(VVM_E_HIP, "look-back timed out inside the kernel (a tile never published its count)");
 		}
 	}
-	const vvm::LinkedProgram* id_lp = st->wide.uses_ids ? &st->wide : nullptr;      // (update_id sits in its dataset's pass)
-	for (const vvm::LinkedProgram& more : st->wide_more) if (!id_lp && more.uses_ids) id_lp = &more;
-	if (ran && id_lp) {
-		// the dataset's ID counters, as the reference leaves them (VectorVMRuntime.cpp:1175, 1383-1399, 1411-1429)
-		const vvm::LinkedProgram& lp = *id_lp;
-		vvm_dataset_meta& ds = ctx->DataSets.data[lp.id_dataset];
-		const size_t ncounts = std::max<uint32_t>(st->script.max_output_dataset, 1);
-		if (lp.updates_ids) {
-			*ds.NumFreeIDs = st->id_num_free_start + (ctx->NumInstances - st->h_counts[lp.id_dataset]);
-			*ds.MaxUsedID = st->h_counts[ncounts];
-		} else {
-			*ds.NumFreeIDs = st->id_num_free_start - ctx->NumInstances;
-			*ds.NumSpawnedIDs = st->id_num_spawned_start + ctx->NumInstances;
-		}
+	if (ran && st->any_ids) {
+		// the datasets' ID counters, as the reference leaves them (VectorVMRuntime.cpp:1175, 1383-1399, 1411-1429); a dataset's
+		// update_id sits in the program of its own pass, acquire_id in every pass's
+		std::vector<uint8_t> done(st->num_datasets(), 0);
+		auto settle = [&](const vvm::LinkedProgram& lp) {
+			for (const vvm::LinkedProgram::IdUse& use : lp.id_uses) {
+				if (done[use.dataset]) continue;
+				done[use.dataset] = 1;
+				vvm_dataset_meta& ds = ctx->DataSets.data[use.dataset];
+				if (use.updates) {
+					*ds.NumFreeIDs = st->id_num_free_start[use.dataset] + (ctx->NumInstances - st->h_counts[use.dataset]);
+					*ds.MaxUsedID = st->h_counts[st->num_datasets() + use.dataset];
+				} else {
+					*ds.NumFreeIDs = st->id_num_free_start[use.dataset] - ctx->NumInstances;
+					*ds.NumSpawnedIDs = st->id_num_spawned_start[use.dataset] + ctx->NumInstances;
+				}
+			}
+		};
+		settle(st->wide);
+		for (const vvm::LinkedProgram& more : st->wide_more) settle(more);
 	}
 	return write_back_counts(st, ctx, ran);
 }

@@ -1351,7 +1351,7 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 					// IDs from the end of the free list, reversed (:1417-1421), and the chunks pop in order.  The IDs are also logged as
 					// spawned: chunk c's, in instance order, at FreeIDTable[Max - (NumSpawnedIDs + instances up to the end of chunk c)]
 					// (:1429-1432).  aux 1 is the instruction's second destination, the tag (:1435).
-					const void* idp = (const void*)DESC_PTR(c.dp, ids);
+					const void* idp = (const void*)(DESC_PTR(c.dp, ids) + (uint64_t)aux2 * sizeof(VvmIdDesc));      // (aux2: the dataset's descriptor)
 					if (aux == 1) {
 						const uint32_t tag_value = sload32(idp, offsetof(VvmIdDesc, acquire_tag) / 4);
 						_Pragma("unroll") LANES r[k] = bitsf(tag_value);

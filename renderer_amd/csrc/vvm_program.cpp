@@ -379,16 +379,19 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 		if (g_ops[d.op].heavy) heavy = true;
 		if (d.kind == K_EXTFN) uses_perlin = true;
 		if (d.kind == K_IDS) {
-			// One dataset's ID tables per script, and one direction: update_id returns IDs to the free list that acquire_id takes them
-			// from, chunk by chunk in the reference (VectorVMRuntime.cpp:1175, 1411-1423), so a script that does both to one dataset
+			// Any number of datasets, one direction per dataset: update_id returns IDs to the free list that acquire_id takes them
+			// from, chunk by chunk in the reference (VectorVMRuntime.cpp:1175, 1411-1423), so a script that does both to ONE dataset
 			// depends on the reference's chunk order.
 			const bool upd = d.op == VVM_OP_update_id;
-			if (lp.uses_ids && (lp.id_dataset != d.dataset || lp.updates_ids != upd)) {
-				err = "update_id and acquire_id in one script, or on more than one dataset, are not supported by the GPU executor";
-				return VVM_E_UNSUPPORTED_OP;
+			bool known = false;
+			for (const LinkedProgram::IdUse& u : lp.id_uses) {
+				if (u.dataset != d.dataset) continue;
+				if (u.updates != upd) { err = "update_id and acquire_id on one dataset in one script are not supported by the GPU executor"; return VVM_E_UNSUPPORTED_OP; }
+				if (upd) { err = "more than one update_id for a dataset is not supported by the GPU executor"; return VVM_E_UNSUPPORTED_OP; }
+				known = true;
 			}
-			if (lp.uses_ids && upd) { err = "more than one update_id in a script is not supported by the GPU executor"; return VVM_E_UNSUPPORTED_OP; }
-			lp.uses_ids = true; lp.updates_ids = upd; lp.id_dataset = d.dataset;
+			if (!known) lp.id_uses.push_back(LinkedProgram::IdUse{d.dataset, upd});
+			if (lp.id_uses.size() > VVM_MAX_ID_USES) { err = "update_id / acquire_id on too many datasets"; return VVM_E_TOO_LARGE; }
 		}
 		if (d.kind == K_OUTPUT) {
 			for (auto& p : d.pairs) {
@@ -428,10 +431,11 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 	}
 	const uint32_t scratch0 = nv;
 	nv += max_scratch;
-	if (lp.uses_ids && lp.updates_ids && !(lp.id_dataset < lp.acquires_dataset.size() && lp.acquires_dataset[lp.id_dataset])) {
-		err = "update_id on a dataset the script has no acquireindex for";       // it walks that dataset's keep mask (VectorVMRuntime.cpp:1178)
-		return VVM_E_UNSUPPORTED_OP;
-	}
+	for (const LinkedProgram::IdUse& u : lp.id_uses)
+		if (u.updates && !(u.dataset < lp.acquires_dataset.size() && lp.acquires_dataset[u.dataset])) {
+			err = "update_id on a dataset the script has no acquireindex for";       // it walks that dataset's keep mask (VectorVMRuntime.cpp:1178)
+			return VVM_E_UNSUPPORTED_OP;
+		}
 	// A script that runs acquireindex for several datasets is executed in one pass per dataset: every pass runs the whole
 	// script, but only the pass's dataset is compacted and written (the others' acquireindex and outputs are left out of the
 	// pass's program).  The instructions are pure functions of the inputs, so every pass computes the same values.
@@ -440,7 +444,17 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 	const bool multi_pass = lp.num_passes > 1;
 	const uint32_t pass_dataset = lp.acquire_order.empty() ? 0 : lp.acquire_order[pass];
 	lp.pass_dataset = pass_dataset;
-	if (multi_pass && lp.updates_ids && lp.id_dataset != pass_dataset) { lp.uses_ids = false; lp.updates_ids = false; }     // update_id runs in its dataset's pass
+	// update_id runs in its dataset's pass; acquire_id in every pass (its register results may feed any dataset's outputs; what it
+	// writes to the ID tables depends on the instance index alone, so every pass writes the same)
+	if (multi_pass)
+		lp.id_uses.erase(std::remove_if(lp.id_uses.begin(), lp.id_uses.end(), [&](const LinkedProgram::IdUse& u) { return u.updates && u.dataset != pass_dataset; }), lp.id_uses.end());
+	lp.uses_ids = !lp.id_uses.empty();
+	lp.updates_ids = false;
+	for (const LinkedProgram::IdUse& u : lp.id_uses) lp.updates_ids = lp.updates_ids || u.updates;
+	auto id_slot = [&](uint32_t dataset) -> uint32_t {
+		for (size_t i = 0; i < lp.id_uses.size(); ++i) if (lp.id_uses[i].dataset == dataset) return (uint32_t)i;
+		return 0;
+	};
 
 	// Instructions whose results reach neither an output, an acquireindex nor an ID table of this pass are left out (one
 	// backward sweep over the straight-line script).  A pass of a script with several acquired datasets then only computes what
@@ -752,7 +766,7 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 				const size_t at = open_group * VVM_STAGE_SLOTS + (VVM_STAGE_SLOTS - 1);
 				if (at + 1 > 0xFFFFu) { err = "too many outputs"; return VVM_E_TOO_LARGE; }
 				if (lp.out_list.size() < at + 1) { lp.out_list.resize(at + 1, -1); lp.out_is16.resize(at + 1, 0); }
-				lp.out_list[at] = -2;
+				lp.out_list[at] = -2 - (int32_t)id_slot(d.dataset);      // (-2 - slot of the dataset's VvmIdDesc)
 				k.w0 = VVM_INS_W0(VVM_DOP_UPDATE_ID, 0, 0, 1, d.dataset);
 				k.w1 = operand(d.in[0]); k.w2 = 0; k.w3 = (uint32_t)at;
 				lp.code.push_back(k);
@@ -763,7 +777,7 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 				for (size_t i = 0; i < 2; ++i) {
 					if (d.out[i] == VVM_INVALID_REG) continue;
 					if (VVM_OPND_CLS(operand(d.out[i])) != VVM_OPC_VREG) { err = "an acquire_id destination is not a temp or output register"; return VVM_E_BAD_BLOB; }
-					outs.push_back(SplitOut{d.out[i], VVM_INS_W0(VVM_OP_acquire_id, 0, 1, i, d.dataset)});
+					outs.push_back(SplitOut{d.out[i], VVM_INS_W0(VVM_OP_acquire_id, 0, 1, i, id_slot(d.dataset))});
 				}
 				emit_split(d, outs, o);
 			}

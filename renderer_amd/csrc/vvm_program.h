@@ -45,9 +45,13 @@ struct LinkedProgram {
 	                                   // two that wait in registers VVM_LIGHT_RIDE_REG, +1)
 	bool     full_kernel = false;      // needs the transcendental / noise kernel
 	bool     uses_perlin = false;
-	bool     uses_ids = false;         // update_id or acquire_id ...
-	bool     updates_ids = false;      // ... which of the two
-	uint32_t id_dataset = 0;           // ... and the dataset whose ID tables it works on
+	// update_id / acquire_id: one entry per dataset whose ID tables this pass works on (its index is the slot of the dataset's
+	// VvmIdDesc behind the Exec descriptor); a dataset is either updated (at most one update_id, in the dataset's own pass) or
+	// acquired from
+	struct IdUse { uint32_t dataset; bool updates; };
+	std::vector<IdUse> id_uses;
+	bool     uses_ids = false;         // id_uses is not empty
+	bool     updates_ids = false;      // ... and has an update_id
 	std::vector<uint8_t> acquires_dataset;   // per output dataset: the script runs acquireindex for it
 	std::vector<uint32_t> acquire_order;     // those datasets in program order
 	uint32_t num_passes = 1;                 // one pass per acquired dataset (see link_program)

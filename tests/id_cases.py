@@ -82,3 +82,51 @@ def np_acquire_id(st: IdState, n: int, chunk: int):
     st.num_free -= n
     st.num_spawned += n
     return st, out, np.full(n, st.tag, np.int32)
+
+
+# ---- ID instructions on more than one dataset of one script ----------------------------------------------------------------------
+def update_and_spawn_script():
+    """Dataset 0: keep = x < limit, acquireindex, update_id(id).  Dataset 1 (no outputs of its own): acquire_id -> (id, tag), which go
+    out with dataset 0's survivors."""
+    s = Script()
+    x = s.input(0, FLOAT, 0)
+    pid = s.input(0, INT32, 0)
+    keep = s.temp()
+    s.op("cmplt", x, s.const(0), keep)
+    s.acquireindex(keep, 0)
+    s.update_id(pid, pid, 0)
+    new_id, tag = s.temps(2)
+    s.acquire_id(new_id, tag, 1)
+    s.output_data(FLOAT, 0, [(x, s.output(0, FLOAT, 0))])
+    s.output_data(INT32, 0, [(pid, s.output(0, INT32, 0)), (new_id, s.output(0, INT32, 1)), (tag, s.output(0, INT32, 2))])
+    return s.build()
+
+
+def two_spawns_script():
+    """acquire_id on datasets 0 and 1; everything survives; outputs both IDs and both tags."""
+    s = Script()
+    id0, tag0, id1, tag1 = s.temps(4)
+    s.acquire_id(id0, tag0, 0)
+    s.acquire_id(id1, tag1, 1)
+    s.acquireindex(s.const(0), 0)
+    s.output_data(INT32, 0, [(id0, s.output(0, INT32, 0)), (tag0, s.output(0, INT32, 1)), (id1, s.output(0, INT32, 2)), (tag1, s.output(0, INT32, 3))])
+    return s.build()
+
+
+def two_updates_script():
+    """Two acquired datasets with their own keep masks (x < limit0, x < limit1) and their own update_id, on two ID streams."""
+    s = Script()
+    x = s.input(0, FLOAT, 0)
+    pid0, pid1 = s.input(0, INT32, 0), s.input(0, INT32, 1)
+    keep0, keep1 = s.temps(2)
+    s.op("cmplt", x, s.const(0), keep0)
+    s.op("cmplt", x, s.const(1), keep1)
+    s.acquireindex(keep0, 0)
+    s.acquireindex(keep1, 1)
+    s.update_id(pid0, pid0, 0)
+    s.update_id(pid1, pid1, 1)
+    s.output_data(FLOAT, 0, [(x, s.output(0, FLOAT, 0))])
+    s.output_data(INT32, 0, [(pid0, s.output(0, INT32, 0))])
+    s.output_data(FLOAT, 1, [(x, s.output(1, FLOAT, 0))])
+    s.output_data(INT32, 1, [(pid1, s.output(1, INT32, 0))])
+    return s.build()

@@ -80,3 +80,94 @@ def test_id_instructions_need_their_tables():
     with pytest.raises(abi.VVMError) as e:
         run_hip(id_cases.spawn_script(), [bytes([255] * 4) + bytes(12)], [], [np.int32, np.int32], 8, ids=st)
     assert e.value.code == abi.VVM_E_INVALID_ARG and "fewer free IDs" in str(e.value)
+
+
+# ---- ID instructions on several datasets of one script ---------------------------------------------------------------------------
+def _spawn_state(n, seed, tag):
+    rng = np.random.default_rng(seed)
+    st = IdState(np.zeros(0, np.int32), np.full(3 * n + 40, -3, np.int32), num_free=n + 9, max_used=0, num_spawned=4, tag=tag)
+    st.free_table[:n + 9] = rng.permutation(10 * n + 100)[:n + 9]
+    return st
+
+
+def _update_state(n, seed):
+    rng = np.random.default_rng(seed)
+    ids = rng.permutation(n + 5)[:n].astype(np.int32)
+    st = IdState(np.full(n + 5, -1, np.int32), np.full(2 * n + 16, -7, np.int32), num_free=3, max_used=2)
+    st.free_table[:3] = [900001, 900002, 900003]
+    return ids, st
+
+
+def _same_tables(got, want):
+    assert np.array_equal(got.id_table, want.id_table) and np.array_equal(got.free_table, want.free_table)
+    assert (got.num_free, got.max_used, got.num_spawned) == (want.num_free, want.max_used, want.num_spawned)
+
+
+@pytest.mark.parametrize("n,page_kb", [(7, 64), (1000, 64), (4099, 2), (150001, 2), (150001, 64)])
+def test_update_id_and_acquire_id_on_two_datasets(n, page_kb):
+    rng = np.random.default_rng(n)
+    x = rng.random(n).astype(f32)
+    ids, upd = _update_state(n, 1)
+    spawn = _spawn_state(n, 2, tag=31)
+    script, consts, dtypes = id_cases.update_and_spawn_script(), [id_cases.update_constants(0.6)], [f32, np.int32, np.int32, np.int32]
+    want_upd, want_spawn, got_upd, got_spawn = upd.copy(), spawn.copy(), upd.copy(), spawn.copy()
+    ref, ref_n, _ = run_oracle(script, consts, [x, ids], dtypes, n, ids=want_upd, more_datasets=[[]], more_ids=[want_spawn], page_kb=page_kb)
+    out, out_n, _ = run_hip(script, consts, [x, ids], dtypes, n, ids=got_upd, more_datasets=[[]], more_ids=[got_spawn], page_kb=page_kb)
+    assert out_n == ref_n
+    for a, b in zip(out, ref):
+        assert np.array_equal(a[:out_n].view(np.uint32), b[:ref_n].view(np.uint32))
+    _same_tables(got_upd, want_upd)
+    _same_tables(got_spawn, want_spawn)
+
+
+@pytest.mark.parametrize("n,page_kb", [(5, 64), (3000, 2), (100003, 64)])
+def test_acquire_id_on_two_datasets(n, page_kb):
+    a, b = _spawn_state(n, 3, tag=5), _spawn_state(n, 4, tag=6)
+    consts = [bytes([255] * 4) + bytes(12)]
+    want_a, want_b, got_a, got_b = a.copy(), b.copy(), a.copy(), b.copy()
+    ref, ref_n, _ = run_oracle(id_cases.two_spawns_script(), consts, [], [np.int32] * 4, n, ids=want_a, more_datasets=[[]], more_ids=[want_b], page_kb=page_kb)
+    out, out_n, _ = run_hip(id_cases.two_spawns_script(), consts, [], [np.int32] * 4, n, ids=got_a, more_datasets=[[]], more_ids=[got_b], page_kb=page_kb)
+    assert out_n == ref_n == n
+    for x, y in zip(out, ref):
+        assert np.array_equal(x[:n], y[:n])
+    _same_tables(got_a, want_a)
+    _same_tables(got_b, want_b)
+
+
+@pytest.mark.parametrize("n,page_kb", [(9, 64), (3001, 2), (120001, 2)])
+def test_update_id_on_two_acquired_datasets(n, page_kb):
+    import struct
+    rng = np.random.default_rng(n + 1)
+    x = rng.random(n).astype(f32)
+    ids0, st0 = _update_state(n, 11)
+    ids1, st1 = _update_state(n, 12)
+    consts = [struct.pack("<ff", 0.7, 0.2) + bytes(8)]
+    script = id_cases.two_updates_script()
+    want0, want1, got0, got1 = st0.copy(), st1.copy(), st0.copy(), st1.copy()
+    ref_more, got_more = [], []
+    ref, ref_n, _ = run_oracle(script, consts, [x, ids0, ids1], [f32, np.int32], n, ids=want0, more_datasets=[[f32, np.int32]], more_results=ref_more,
+                               more_ids=[want1], page_kb=page_kb)
+    out, out_n, _ = run_hip(script, consts, [x, ids0, ids1], [f32, np.int32], n, ids=got0, more_datasets=[[f32, np.int32]], more_results=got_more,
+                            more_ids=[got1], page_kb=page_kb)
+    assert out_n == ref_n and got_more[0][1] == ref_more[0][1]
+    for a, b in zip(out, ref):
+        assert np.array_equal(a[:out_n].view(np.uint32), b[:ref_n].view(np.uint32))
+    m = ref_more[0][1]
+    for a, b in zip(got_more[0][0], ref_more[0][0]):
+        assert np.array_equal(a[:m].view(np.uint32), b[:m].view(np.uint32))
+    _same_tables(got0, want0)
+    _same_tables(got1, want1)
+
+
+def test_update_id_and_acquire_id_on_one_dataset_are_refused():
+    """The reference's result then depends on its chunk order: a chunk's acquire_id pops what the chunk before it has freed."""
+    from renderer_amd.assembler import INT32, Script
+    s = Script()
+    t0, t1 = s.temps(2)
+    s.acquire_id(t0, t1, 0)
+    s.acquireindex(s.const(0), 0)
+    s.update_id(t0, t1, 0)
+    s.output_data(INT32, 0, [(t0, s.output(0, INT32, 0))])
+    with pytest.raises(abi.VVMError) as e:
+        run_hip(s.build(), [bytes(16)], [], [np.int32], 8)
+    assert "one dataset" in str(e.value)

@@ -1,4 +1,6 @@
 """CPU tests of the oracle's update_id / acquire_id against the numpy statement in id_cases.py."""
+import struct
+
 import numpy as np
 import pytest
 
@@ -62,3 +64,58 @@ def test_acquire_id_matches_numpy(n, page_kb):
     assert np.array_equal(outs[0][:n], want_ids) and np.array_equal(outs[1][:n], want_tags)
     assert np.array_equal(got.free_table, want.free_table)
     assert (got.num_free, got.num_spawned) == (want.num_free, want.num_spawned)
+
+
+# ---- several datasets with ID instructions in one script (VectorVMRuntime.cpp:1134-1135, 1406-1408: every instruction names its dataset)
+def _spawn_state(n, seed, tag):
+    rng = np.random.default_rng(seed)
+    st = IdState(np.zeros(0, np.int32), np.full(3 * n + 40, -3, np.int32), num_free=n + 9, max_used=0, num_spawned=4, tag=tag)
+    st.free_table[:n + 9] = rng.permutation(10 * n + 100)[:n + 9]
+    return st
+
+
+def _update_state(n, seed):
+    rng = np.random.default_rng(seed)
+    ids = rng.permutation(n + 5)[:n].astype(np.int32)
+    st = IdState(np.full(n + 5, -1, np.int32), np.full(2 * n + 16, -7, np.int32), num_free=3, max_used=2)
+    st.free_table[:3] = [900001, 900002, 900003]
+    return ids, st
+
+
+@pytest.mark.parametrize("n,page_kb", [(7, 64), (1000, 64), (4099, 2)])
+def test_update_id_and_acquire_id_on_two_datasets_match_numpy(n, page_kb):
+    rng = np.random.default_rng(n)
+    x = rng.random(n).astype(f32)
+    ids, upd = _update_state(n, 1)
+    spawn = _spawn_state(n, 2, tag=31)
+    got_upd, got_spawn = upd.copy(), spawn.copy()
+    outs, surv, frame = run_oracle(id_cases.update_and_spawn_script(), [id_cases.update_constants(0.6)], [x, ids], [f32, np.int32, np.int32, np.int32], n,
+                                   ids=got_upd, more_datasets=[[]], more_ids=[got_spawn], page_kb=page_kb)
+    chunk = frame.ctx.Internal.MaxInstancesPerChunk
+    keep = x < f32(0.6)
+    want_upd = id_cases.np_update_id(upd, ids, keep, chunk)
+    want_spawn, new_ids, tags = id_cases.np_acquire_id(spawn, n, chunk)
+    assert surv == int(keep.sum())
+    assert np.array_equal(outs[1][:surv], ids[keep]) and np.array_equal(outs[2][:surv], new_ids[keep]) and np.array_equal(outs[3][:surv], tags[keep])
+    for got, want in ((got_upd, want_upd), (got_spawn, want_spawn)):
+        assert np.array_equal(got.id_table, want.id_table) and np.array_equal(got.free_table, want.free_table)
+        assert (got.num_free, got.max_used, got.num_spawned) == (want.num_free, want.max_used, want.num_spawned)
+
+
+def test_two_update_ids_on_two_datasets_match_numpy():
+    n = 3001
+    rng = np.random.default_rng(5)
+    x = rng.random(n).astype(f32)
+    ids0, st0 = _update_state(n, 11)
+    ids1, st1 = _update_state(n, 12)
+    got0, got1 = st0.copy(), st1.copy()
+    more = []
+    consts = [struct.pack("<ff", 0.7, 0.2) + bytes(8)]
+    outs, surv, frame = run_oracle(id_cases.two_updates_script(), consts, [x, ids0, ids1], [f32, np.int32], n, ids=got0,
+                                   more_datasets=[[f32, np.int32]], more_results=more, more_ids=[got1], page_kb=2)
+    chunk = frame.ctx.Internal.MaxInstancesPerChunk
+    for got, st, ids, limit in ((got0, st0, ids0, 0.7), (got1, st1, ids1, 0.2)):
+        want = id_cases.np_update_id(st, ids, x < f32(limit), chunk)
+        assert np.array_equal(got.id_table, want.id_table) and np.array_equal(got.free_table, want.free_table)
+        assert (got.num_free, got.max_used) == (want.num_free, want.max_used)
+    assert surv == int((x < f32(0.7)).sum()) and more[0][1] == int((x < f32(0.2)).sum())

@@ -47,8 +47,10 @@ def run_oracle(script: BuiltScript, const_tables: Sequence[bytes], inputs: Seque
                out_dtypes: Sequence, n: int, instance_offset: int = 0, ext_fns: Sequence = (),
                seed: int = 0, exec_index_base: int = 0, rand_instance_base: int = 0, strict: bool = False,
                page_kb: int = 64, out_fill: int = 0xCD, ids: Optional[IdState] = None,
-               more_datasets: Sequence[Sequence] = (), more_results: Optional[list] = None) -> Tuple[List[np.ndarray], int, abi.CallFrame]:
-    """more_datasets: output dtypes of datasets 1, 2, ... (outputs only); their (streams, survivors) are appended to more_results."""
+               more_datasets: Sequence[Sequence] = (), more_results: Optional[list] = None,
+               more_ids: Sequence[Optional[IdState]] = ()) -> Tuple[List[np.ndarray], int, abi.CallFrame]:
+    """more_datasets: output dtypes of datasets 1, 2, ... (outputs only); their (streams, survivors) are appended to more_results.
+    more_ids: the ID tables of datasets 1, 2, ... (None: the dataset has none)."""
     from oracle_binding import load_oracle
     be = load_oracle()
     be.set_strict(strict)
@@ -67,6 +69,9 @@ def run_oracle(script: BuiltScript, const_tables: Sequence[bytes], inputs: Seque
         ids.attach(ds, ids.id_table.ctypes.data, ids.free_table.ctypes.data)
     more_outs = [[np.frombuffer(bytes([out_fill]) * (total * np.dtype(dt).itemsize), dtype=dt).copy() for dt in dts] for dts in more_datasets]
     more_ds = [abi.DataSet([], [a.ctypes.data for a in o], instance_offset, [0, 0, 0], _type_offsets(o)) for o in more_outs]
+    for d, st in zip(more_ds, more_ids):
+        if st is not None:
+            st.attach(d, st.id_table.ctypes.data, st.free_table.ctypes.data)
     state = be.alloc_state(script.blob)
     try:
         frame = abi.CallFrame(state, [ds] + more_ds, n, const_tables, ext_fns)
@@ -78,6 +83,9 @@ def run_oracle(script: BuiltScript, const_tables: Sequence[bytes], inputs: Seque
             more_results.extend((o, frame.survivors(1 + i)) for i, o in enumerate(more_outs))
         if ids is not None:
             ids.read_counters(frame.datasets[0])
+        for i, st in enumerate(more_ids):
+            if st is not None:
+                st.read_counters(frame.datasets[1 + i])
     finally:
         be.free_state(state)
     return outs, surv, frame
@@ -88,7 +96,8 @@ def run_hip(script: BuiltScript, const_tables: Sequence[bytes], inputs: Sequence
             seed: int = 0, exec_index_base: int = 0, rand_instance_base: int = 0, flags: int = 0,
             out_fill: int = 0xCD, repeat: int = 1, ids: Optional[IdState] = None, page_kb: int = 64,
             more_datasets: Sequence[Sequence] = (), more_results: Optional[list] = None,
-            batch_with: Optional[Sequence] = None, device_counts: Optional[list] = None) -> Tuple[List[np.ndarray], int, abi.ProgramInfo]:
+            batch_with: Optional[Sequence] = None, device_counts: Optional[list] = None,
+            more_ids: Sequence[Optional[IdState]] = ()) -> Tuple[List[np.ndarray], int, abi.ProgramInfo]:
     """Same contract as run_oracle, through the C ABI of libvvm_hip.so with streams in device memory.
     batch_with: call frames of other emitters; the Exec then runs as the middle member of one vvm_exec_batch call with them.
     device_counts: a list; the Exec gets a buffer of eight ints (filled with -1) as vvm_exec_options.DeviceCounts, whose contents
@@ -135,6 +144,19 @@ def run_hip(script: BuiltScript, const_tables: Sequence[bytes], inputs: Sequence
                 be._check(L.vvm_device_memset(p, out_fill, nbytes), "memset")
             more_dev.append(ptrs)
         more_ds = [abi.DataSet([], ptrs, instance_offset, [0, 0, 0], _type_offsets([np.empty(0, dt) for dt in dts])) for ptrs, dts in zip(more_dev, more_datasets)]
+        more_id_dev = []
+        for d, st in zip(more_ds, more_ids):
+            ptrs = []
+            if st is not None:
+                for a in (st.id_table, st.free_table):
+                    p = L.vvm_device_alloc(max(a.nbytes, 4))
+                    assert p, be.error_text()
+                    dev_ids.append(p)
+                    ptrs.append(p)
+                    if a.nbytes:
+                        be._check(L.vvm_device_upload(p, a.ctypes.data, a.nbytes), "upload")
+                st.attach(d, ptrs[0], ptrs[1])
+            more_id_dev.append(ptrs)
         state = be.alloc_state(script.blob)
         try:
             frame = abi.CallFrame(state, [ds] + more_ds, n, const_tables, ext_fns)
@@ -172,6 +194,12 @@ def run_hip(script: BuiltScript, const_tables: Sequence[bytes], inputs: Sequence
                 for a, p in zip((ids.id_table, ids.free_table), dev_ids):
                     if a.nbytes:
                         be._check(L.vvm_device_download(a.ctypes.data, p, a.nbytes), "download")
+            for i, st in enumerate(more_ids):
+                if st is not None:
+                    st.read_counters(frame.datasets[1 + i])
+                    for a, p in zip((st.id_table, st.free_table), more_id_dev[i]):
+                        if a.nbytes:
+                            be._check(L.vvm_device_download(a.ctypes.data, p, a.nbytes), "download")
         finally:
             be.free_state(state)
         for p, dt in zip(dev_out, out_dtypes):
