@@ -217,7 +217,11 @@ enum {
 	/* Scripts that need no more than eight per-lane registers run their eight-wide Execs on a kernel with a smaller register
 	 * file, of which three workgroups fit a CU instead of two.  This flag keeps them on the general eight-wide kernel (tests /
 	 * comparison).  The results are the same either way. */
-	VVM_EXEC_NO_LIGHT_KERNEL = 1u << 4
+	VVM_EXEC_NO_LIGHT_KERNEL = 1u << 4,
+	/* A script that runs acquireindex for several datasets is executed as one pass per dataset; the passes normally go out as one
+	 * launch that runs all of them on a tile of instances before it moves on (the streams they share are read from memory
+	 * once).  This flag launches the passes one after the other instead (tests / comparison).  The results are the same. */
+	VVM_EXEC_SEPARATE_PASSES = 1u << 5
 };
 #define VVM_EIGHT_WIDE_MIN_INSTANCES (256 * 1024)
 

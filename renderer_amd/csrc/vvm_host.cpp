@@ -183,6 +183,7 @@ struct vvm_state {
 	uint32_t* d_chunk_prefix = nullptr; uint32_t chunk_capacity = 0;
 	int32_t*  d_id_scratch = nullptr;   uint32_t id_scratch_capacity = 0;
 	std::vector<int32_t> id_num_free_start, id_num_spawned_start;      // per dataset: the counters when the Exec was enqueued
+	uint32_t id_buffer_pieces = 0;         // pieces of d_chunk_prefix / d_id_scratch (chunk_capacity / id_scratch_capacity entries each)
 	uint32_t id_datasets = 0;              // one more than the highest dataset an update_id / acquire_id names
 	size_t num_datasets() const { return std::max<uint32_t>(std::max<uint32_t>(script.max_output_dataset, 1), id_datasets); }
 	size_t mirror_word() const { return 3 * num_datasets() + 4; }
@@ -246,6 +247,7 @@ struct PreparedExec {
 	uint32_t chunk_instances = 0, num_chunks = 0;      // the reference's chunking of this Exec
 	uint32_t instances_per_lane = 4;                   // of the kernel this Exec runs on (8, 4 or 1)
 	bool light = false;                                // ... the light eight-wide kernel
+	uint32_t id_buffers = 0;                           // which piece of the state's update_id buffers this pass works in (fused passes run together)
 	bool launch_many() const { return light || lp->many_registers; }      // what vvm_launch_exec_kernel takes as many_registers
 };
 
@@ -485,8 +487,8 @@ int fill_params(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* op
 		ids->id_table_num = ds.IDTable ? (uint32_t)ds.IDTable->num : 0;
 		ids->free_table = ds.FreeIDTable->data;
 		ids->free_table_max = (uint32_t)ds.FreeIDTable->max;
-		ids->chunk_prefix = st->d_chunk_prefix;
-		ids->id_scratch = st->d_id_scratch;
+		ids->chunk_prefix = st->d_chunk_prefix ? st->d_chunk_prefix + (size_t)pe.id_buffers * st->chunk_capacity : nullptr;
+		ids->id_scratch = st->d_id_scratch ? st->d_id_scratch + (size_t)pe.id_buffers * st->id_scratch_capacity : nullptr;
 		ids->max_id = d->counts + st->num_datasets() + use.dataset;      // the dataset's word behind the survivor counts
 		ids->survivors = d->counts + use.dataset;
 		ids->instance_offset = ds.InstanceOffset;
@@ -522,6 +524,110 @@ uint32_t grid_for(uint32_t tiles, uint32_t instances_per_lane, bool full, bool m
 	static const uint32_t forced = getenv("VVM_DEBUG_WG_PER_CU") ? (uint32_t)atoi(getenv("VVM_DEBUG_WG_PER_CU")) : 0u;      // (measurement aid)
 	if (forced) per_cu = std::min(per_cu, forced);
 	return std::max<uint32_t>(1, std::min<uint32_t>(tiles, (uint32_t)g_dev.num_cus * per_cu * (256u / VVM_BLOCK_THREADS)));
+}
+
+// update_id's buffers (survivors before each of the reference's chunks, every instance's ID): `pieces` of them, each for
+// `num_chunks` chunks and `instances` instances.
+int ensure_id_buffers(vvm_state* st, uint32_t pieces, uint32_t num_chunks, uint32_t instances, hipStream_t stream)
+{
+	if (pieces <= st->id_buffer_pieces && num_chunks <= st->chunk_capacity && instances <= st->id_scratch_capacity) return VVM_OK;
+	HIP_TRY(hipStreamSynchronize(stream));
+	if (st->d_chunk_prefix) HIP_TRY(hipFree(st->d_chunk_prefix));
+	if (st->d_id_scratch) HIP_TRY(hipFree(st->d_id_scratch));
+	st->d_chunk_prefix = nullptr; st->d_id_scratch = nullptr;
+	st->id_buffer_pieces = std::max(pieces, st->id_buffer_pieces);
+	st->chunk_capacity = std::max(st->chunk_capacity, num_chunks + num_chunks / 4 + 64);
+	st->id_scratch_capacity = std::max(st->id_scratch_capacity, instances + instances / 4 + 1024);
+	HIP_TRY(hipMalloc((void**)&st->d_chunk_prefix, (size_t)st->id_buffer_pieces * st->chunk_capacity * 4));
+	HIP_TRY(hipMalloc((void**)&st->d_id_scratch, (size_t)st->id_buffer_pieces * st->id_scratch_capacity * 4));
+	return VVM_OK;
+}
+
+// The ID counters of the datasets a pass works on, as they are when the Exec is enqueued; MaxUsedID goes to its device word
+// (the kernel only ever raises it, VectorVMRuntime.cpp:1383-1399).
+int stage_id_counters(vvm_state* st, const vvm_exec_context* ctx, const vvm::LinkedProgram& lp, hipStream_t stream)
+{
+	for (const vvm::LinkedProgram::IdUse& use : lp.id_uses) {
+		const vvm_dataset_meta& ds = ctx->DataSets.data[use.dataset];
+		st->id_num_free_start[use.dataset] = *ds.NumFreeIDs;
+		st->id_num_spawned_start[use.dataset] = ds.NumSpawnedIDs ? *ds.NumSpawnedIDs : 0;
+		if (use.updates) {
+			const size_t nd = st->num_datasets();
+			st->h_counts[2 * nd + use.dataset] = *ds.MaxUsedID;
+			HIP_TRY(hipMemcpyAsync(st->d_counts + nd + use.dataset, st->h_counts + 2 * nd + use.dataset, 4, hipMemcpyHostToDevice, stream));
+		}
+	}
+	return VVM_OK;
+}
+
+// A script that acquires several datasets has one program per dataset (a pass).  When all passes run four instances per lane,
+// or all one, they go out as ONE launch of a FULL kernel that runs every pass on a tile before it moves to the next tile: one
+// launch instead of several, and the passes' look-back chains advance together.  Passes that would run eight instances per
+// lane are launched one after the other, on the faster eight-wide kernels (measured on 64 Mi instances, two datasets:
+// 1.48 ms against 1.86 ms fused; the later passes do not find the shared streams in the L2 either way, the tiles in flight
+// are several times its size).  `handled` stays false when the passes have to be launched one after the other.
+int enqueue_fused_passes(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, hipStream_t stream, VvmLaunchState* d_launch, bool timed, bool& handled)
+{
+	handled = false;
+	const uint32_t K = st->wide.num_passes;
+	vvm_exec_options o = opt ? *opt : vvm_exec_options{};
+	std::vector<PreparedExec> pes(K);
+	bool many = false, ids = false;
+	uint32_t spill = 0;
+	for (uint32_t k = 0; k < K; ++k) {
+		const int rc = prepare(st, ctx, &o, pes[k], k);
+		if (rc != VVM_OK) return rc;
+		if (pes[k].instances_per_lane != pes[0].instances_per_lane || pes[k].instances_per_lane == 8) return VVM_OK;      // (the FULL kernels run four or one)
+		many = many || pes[k].launch_many();
+		spill = std::max(spill, pes[k].lp->lds_spill_slots);
+		ids = ids || pes[k].lp->updates_ids;
+		pes[k].id_buffers = k;
+	}
+	const uint32_t lanes = pes[0].instances_per_lane, tiles = pes[0].tiles;
+	if ((size_t)vvm_kernel_lds_fixed_bytes((int)lanes, 1) + (size_t)spill * VVM_BLOCK_THREADS * 4u * lanes > (size_t)(160 * 1024 - 64)) return VVM_OK;      // (the CU's LDS: the passes then go one after the other)
+	if ((uint64_t)K * tiles > 0xFFFFFFFFull) return VVM_OK;
+	int rc = ensure_status(st, K * tiles);      // every pass has look-back words of its own
+	if (rc != VVM_OK) return rc;
+	st->cur_status = st->d_status;
+	st->cur_status_words = (size_t)st->status_capacity;
+	if (ids) {
+		rc = ensure_id_buffers(st, K, pes[0].num_chunks, (uint32_t)ctx->NumInstances, stream);
+		if (rc != VVM_OK) return rc;
+	}
+	// the slot: the K descriptors side by side (the kernel indexes them), then every pass's block as fill_params lays it out
+	std::vector<size_t> block_off(K);
+	size_t total = align_up(K * sizeof(VvmExecDesc), 256);
+	for (uint32_t k = 0; k < K; ++k) { block_off[k] = total; total += pes[k].bytes; }
+	rc = st->ring.reserve(total);
+	if (rc != VVM_OK) return rc;
+	int slot = -1;
+	rc = st->ring.acquire(slot);
+	if (rc != VVM_OK) return rc;
+	uint8_t* const host = st->ring.host[slot];
+	uint8_t* const dev = st->ring.dev[slot];
+	for (uint32_t k = 0; k < K; ++k) {
+		rc = stage_id_counters(st, ctx, *pes[k].lp, stream);
+		if (rc != VVM_OK) return rc;
+		rc = fill_params(st, ctx, &o, pes[k], host + block_off[k], dev + block_off[k], st->d_status + (size_t)k * tiles, 0);
+		if (rc != VVM_OK) return rc;
+		memcpy(host + k * sizeof(VvmExecDesc), host + block_off[k], sizeof(VvmExecDesc));      // (its table fields are device addresses)
+	}
+	HIP_TRY(hipMemcpyAsync(dev, host, total, hipMemcpyHostToDevice, stream));
+	st->last_width = lanes;
+	if (timed) HIP_TRY(hipEventRecord(st->ev_start[st->ev_used], stream));
+	const int lrc = vvm_launch_exec_kernel((int)lanes, (const VvmExecDesc*)dev, K, tiles, d_launch, many ? 1 : 0, spill, 1, grid_for(tiles, lanes, true, many), stream, nullptr, 0, 0u, 1);
+	if (lrc != 0) return hip_fail((hipError_t)lrc, "kernel launch (fused passes)");
+	if (timed) { HIP_TRY(hipEventRecord(st->ev_stop[st->ev_used], stream)); st->ev_used++; }
+	for (uint32_t k = 0; k < K; ++k)
+		for (size_t u = 0; u < pes[k].lp->id_uses.size(); ++u) {
+			if (!pes[k].lp->id_uses[u].updates) continue;
+			const int mrc = vvm_launch_max_id_kernel((const VvmIdDesc*)(dev + block_off[k] + pes[k].off_ids) + u, pes[k].num_chunks, stream);
+			if (mrc != 0) return hip_fail((hipError_t)mrc, "MaxUsedID kernel launch");
+		}
+	HIP_TRY(hipEventRecord(st->ring.done[slot], stream));
+	st->ring.pending[slot] = true;
+	handled = true;
+	return VVM_OK;
 }
 
 int write_back_counts(vvm_state* st, vvm_exec_context* ctx, bool ran_kernel)
@@ -691,35 +797,26 @@ static int exec_enqueue(vvm_exec_context* ctx, const vvm_exec_options* opt, bool
 			st->ev_start.push_back(a); st->ev_stop.push_back(b);
 		}
 	}
-	// One launch per pass (one pass unless the script runs acquireindex for several datasets).  The passes share the look-back
-	// words: every launch leaves a new epoch behind, which invalidates the words of the one before.
 	const uint32_t num_passes = pe.lp->num_passes;
+	if (num_passes > 1 && !no_alloc && !(opt && (opt->Flags & VVM_EXEC_SEPARATE_PASSES))) {
+		bool handled = false;
+		rc = enqueue_fused_passes(st, ctx, opt, stream, d_launch, timed, handled);
+		if (rc != VVM_OK) return rc;
+		if (handled) { st->results_pending = true; return VVM_OK; }
+	}
+	// Otherwise one launch per pass (one pass unless the script runs acquireindex for several datasets).  The passes share the
+	// look-back words: every launch leaves a new epoch behind, which invalidates the words of the one before.
 	for (uint32_t pass = 0; pass < num_passes; ++pass) {
 		if (pass != 0) {
 			rc = prepare(st, ctx, opt, pe, pass);
 			if (rc != VVM_OK) return rc;
 		}
-		for (const vvm::LinkedProgram::IdUse& use : pe.lp->id_uses) {
-			const vvm_dataset_meta& ds = ctx->DataSets.data[use.dataset];
-			st->id_num_free_start[use.dataset] = *ds.NumFreeIDs;
-			st->id_num_spawned_start[use.dataset] = ds.NumSpawnedIDs ? *ds.NumSpawnedIDs : 0;
-			if (use.updates) {
-				// (one update_id per pass, and the passes follow each other on the stream: they share the two buffers)
-				if (pe.num_chunks > st->chunk_capacity || (uint32_t)ctx->NumInstances > st->id_scratch_capacity) {
-					HIP_TRY(hipStreamSynchronize(stream));
-					if (st->d_chunk_prefix) HIP_TRY(hipFree(st->d_chunk_prefix));
-					if (st->d_id_scratch) HIP_TRY(hipFree(st->d_id_scratch));
-					st->chunk_capacity = pe.num_chunks + pe.num_chunks / 4 + 64;
-					st->id_scratch_capacity = (uint32_t)ctx->NumInstances + (uint32_t)ctx->NumInstances / 4 + 1024;
-					HIP_TRY(hipMalloc((void**)&st->d_chunk_prefix, (size_t)st->chunk_capacity * 4));
-					HIP_TRY(hipMalloc((void**)&st->d_id_scratch, (size_t)st->id_scratch_capacity * 4));
-				}
-				// MaxUsedID starts from the caller's value (the kernel only ever raises it, VectorVMRuntime.cpp:1383-1399)
-				const size_t nd = st->num_datasets();
-				st->h_counts[2 * nd + use.dataset] = *ds.MaxUsedID;
-				HIP_TRY(hipMemcpyAsync(st->d_counts + nd + use.dataset, st->h_counts + 2 * nd + use.dataset, 4, hipMemcpyHostToDevice, stream));
-			}
+		if (pe.lp->updates_ids) {      // (one update_id per pass, and the passes follow each other on the stream: they share one piece of the buffers)
+			rc = ensure_id_buffers(st, 1, pe.num_chunks, (uint32_t)ctx->NumInstances, stream);
+			if (rc != VVM_OK) return rc;
 		}
+		rc = stage_id_counters(st, ctx, *pe.lp, stream);
+		if (rc != VVM_OK) return rc;
 		// A small block travels as a kernel argument; a larger one, or one whose ID descriptor other kernels read, through a slot
 		// of the ring (pinned copy, device copy, one host-to-device copy ahead of the launch).
 		const bool fits_inline = pe.bytes <= VVM_INLINE_PARAM_BYTES && !pe.lp->uses_ids;
@@ -743,7 +840,7 @@ static int exec_enqueue(vvm_exec_context* ctx, const vvm_exec_options* opt, bool
 		const int lrc = vvm_launch_exec_kernel((int)pe.instances_per_lane, inline_block ? nullptr : (const VvmExecDesc*)st->ring.dev[slot], 1, pe.tiles, d_launch,
 		                                       pe.launch_many() ? 1 : 0, pe.lp->lds_spill_slots, pe.lp->full_kernel ? 1 : 0,
 		                                       grid_for(pe.tiles, pe.instances_per_lane, pe.lp->full_kernel, pe.launch_many()), stream,
-		                                       inline_block ? local_block : nullptr, inline_block ? (uint32_t)pe.bytes : 0u, 0u);
+		                                       inline_block ? local_block : nullptr, inline_block ? (uint32_t)pe.bytes : 0u, 0u, 0);
 		if (lrc != 0) return hip_fail((hipError_t)lrc, "kernel launch");
 		if (timed && pass + 1 == num_passes) { HIP_TRY(hipEventRecord(st->ev_stop[st->ev_used], stream)); st->ev_used++; }
 		for (size_t u = 0; u < pe.lp->id_uses.size(); ++u) {
@@ -1087,7 +1184,7 @@ int batch_launch_slice(BatchWorkspace& ws, const BatchPlan& plan, int sl, size_t
 		const uint32_t launch_tag = ws.next_tag++;
 		const int lrc = vvm_launch_exec_kernel((int)pe0.instances_per_lane, (const VvmExecDesc*)(ws.dev + grp.desc_off), (uint32_t)grp.members.size(), grp.tiles,
 		                                       ws.d_launch[g], pe0.launch_many() ? 1 : 0, grp.spill, lp.full_kernel ? 1 : 0,
-		                                       grid_for(grp.tiles, pe0.instances_per_lane, lp.full_kernel, pe0.launch_many()), ws.stream, nullptr, 0, launch_tag);
+		                                       grid_for(grp.tiles, pe0.instances_per_lane, lp.full_kernel, pe0.launch_many()), ws.stream, nullptr, 0, launch_tag, 0);
 		if (lrc != 0) { (void)hipStreamSynchronize(ws.stream); return hip_fail((hipError_t)lrc, "batched kernel launch"); }
 		HIP_TRY(hipMemcpyAsync(&ws.h_launch[(size_t)sl * 8 + g], ws.d_launch[g], 80, hipMemcpyDeviceToHost, ws.stream));
 	}

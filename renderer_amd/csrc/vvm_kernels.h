@@ -14,7 +14,9 @@ extern "C" {
 // (for launches that share one array of look-back words through several sets of launch words).
 int vvm_launch_exec_kernel(int instances_per_lane, const VvmExecDesc* descs, uint32_t num_execs, uint32_t total_tiles,
                            VvmLaunchState* ls, int many_registers, uint32_t lds_spill_slots, int full, uint32_t grid, hipStream_t stream,
-                           const void* inline_block, uint32_t inline_bytes, uint32_t tag);
+                           const void* inline_block, uint32_t inline_bytes, uint32_t tag, int fused);
+// (fused != 0: the `num_execs` descriptors are the passes of one Exec, run tile by tile on the same instances by a FULL kernel;
+// total_tiles = the tiles of one pass)
 // update_id's MaxUsedID pass over an Exec that has run (same stream).
 int vvm_launch_max_id_kernel(const VvmIdDesc* ids, uint32_t num_chunks, hipStream_t stream);
 int vvm_kernel_max_dynamic_lds(void);

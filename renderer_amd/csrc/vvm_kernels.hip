@@ -1015,6 +1015,11 @@ struct KernelEnv {
 	// Launches that share one array of look-back words but not one set of launch words (a batch) get their tags from the
 	// host, one counter per array, so that no word written earlier can carry the tag of a later launch.
 	uint32_t tag;
+	// Not 0 (FULL kernels only): the launch's Execs are the passes of ONE Exec over the same instances (a script that acquires
+	// several datasets: one program per dataset).  Every ticket is one tile of all of them: the workgroup runs the passes on the
+	// tile one after the other, so that the streams the passes share come from memory once; total_tiles counts tiles, not
+	// tiles x passes, and every pass has its own look-back words.
+	uint32_t fused;
 	// A single Exec's parameter block (descriptor and tables, VVM_DESC_RELATIVE) rides in the kernel-argument segment: no
 	// host-to-device copy ahead of the launch (a copy is a launch of its own on the stream, and cost more than half of the
 	// 13 us between two Execs).  The kernel never names this member; it reads the segment through scalar loads.
@@ -1564,7 +1569,7 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (IS_LIGHT(V, SPILL) ? 3 : V
 	const uint32_t cls = blockIdx.x % classes;
 	const uint32_t tag = env.tag ? env.tag : (SCALAR(__hip_atomic_load((gu32*)&env.ls->epoch, RLX_AGENT)) & 0x3FFFFFFFu);
 	bool perlin_ready = false;
-	uint32_t resolves = 0;
+	uint32_t resolves = 0, started = 0;
 	// (where the descriptors are, and what the table fields of a descriptor are relative to, see KernelEnv::block: per tile, below)
 
 	if (wave == 0) lds_ctrl[LC_STATS + (lane & 7u)] = 0;
@@ -1601,9 +1606,12 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (IS_LIGHT(V, SPILL) ? 3 : V
 		const uint64_t block_addr = karg + offsetof(KernelEnv, block);
 		const VvmExecDesc* descs = given ? (const VvmExecDesc*)given : (const VvmExecDesc*)block_addr;
 		const uint64_t rel = given ? 0ull : block_addr;
-		// which Exec owns this ticket: the last descriptor with first_tile <= ticket
-		uint32_t e = 0;
-		if (env.num_execs > 1) {
+		// which Exec owns this ticket: the last descriptor with first_tile <= ticket; fused passes: all of them, in turn
+		uint32_t e = 0, e_end = 1;
+		bool fused = false;
+		if constexpr (FULL) fused = env.fused != 0;
+		if (fused) e_end = env.num_execs;
+		else if (env.num_execs > 1) {
 			uint32_t lo = 0, hi = env.num_execs;
 			while (hi - lo > 1) {
 				const uint32_t mid = (lo + hi) >> 1;
@@ -1611,6 +1619,8 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (IS_LIGHT(V, SPILL) ? 3 : V
 			}
 			e = lo;
 		}
+		bool first_pass = true;
+		do {
 		const void* dp = (const void*)(descs + e);
 		const uint32_t num_instances = DESC_U32(dp, num_instances);
 		const uint32_t tile_local = ticket - DESC_U32(dp, first_tile);
@@ -1638,10 +1648,12 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (IS_LIGHT(V, SPILL) ? 3 : V
 		c.num_instances = num_instances;
 		c.tile_first = tile_first;
 		c.valid = min(num_instances - tile_first, (uint32_t)(VVM_BLOCK_THREADS * V));
-		c.phase = phase;
+		c.phase = FULL ? started++ : phase;      // (tiles this workgroup has started: with fused passes more than one per ticket)
 		if (!(dbgw & 1u))
-			run_tile<V, SPILL, FULL>((const VvmIns*)DESC_PTR(dp, prog), (gu64*)DESC_PTR(dp, status), last_tile, c, lds, tile_local, tag, env.ls, dbgw, pend, resolves, pre, have_pre,
+			run_tile<V, SPILL, FULL>((const VvmIns*)DESC_PTR(dp, prog), (gu64*)DESC_PTR(dp, status), last_tile, c, lds, tile_local, tag, env.ls, dbgw, pend, resolves, pre, have_pre && first_pass,
 			                         K0, K1, K2, K3, K4, K5, K6, K7);
+		first_pass = false;
+		} while (FULL && ++e < e_end);
 	}
 	if (pend.active) {
 		Ctx c;
@@ -1702,7 +1714,7 @@ extern "C" int vvm_launch_max_id_kernel(const VvmIdDesc* idp, uint32_t num_chunk
 // ---- host-callable launcher --------------------------------------------------------------------------
 extern "C" int vvm_launch_exec_kernel(int instances_per_lane, const VvmExecDesc* descs, uint32_t num_execs, uint32_t total_tiles,
                                       VvmLaunchState* ls, int many_registers, uint32_t lds_spill_slots, int full, uint32_t grid, hipStream_t stream,
-                                      const void* inline_block, uint32_t inline_bytes, uint32_t tag)
+                                      const void* inline_block, uint32_t inline_bytes, uint32_t tag, int fused)
 {
 	// instances_per_lane 8 with many_registers set names the light eight-wide kernel (eight resident registers, six staging slots)
 	const bool light = instances_per_lane == 8 && many_registers != 0;
@@ -1714,7 +1726,8 @@ extern "C" int vvm_launch_exec_kernel(int instances_per_lane, const VvmExecDesc*
 	} else if (!descs) {
 		return (int)hipErrorInvalidValue;
 	}
-	env.descs = descs; env.num_execs = num_execs; env.total_tiles = total_tiles; env.ls = ls; env.lds_spill_slots = lds_spill_slots; env.tag = tag;
+	if (fused && (!full || !descs || instances_per_lane == 8)) return (int)hipErrorInvalidValue;      // (the FULL kernels run fused passes)
+	env.descs = descs; env.num_execs = num_execs; env.total_tiles = total_tiles; env.ls = ls; env.lds_spill_slots = lds_spill_slots; env.tag = tag; env.fused = fused ? 1u : 0u;
 	{ const char* dbg = getenv("VVM_DEBUG_SKIP"); env.debug_skip = dbg ? (uint32_t)strtoul(dbg, nullptr, 0) : 0u; }
 	const size_t lds_bytes = (instances_per_lane == 8 ? LDS_SPILL_OFF(8, full != 0, light) : instances_per_lane == 4 ? LDS_SPILL_OFF(4, full != 0, false) : LDS_SPILL_OFF(1, full != 0, false)) +
 	                         (size_t)lds_spill_slots * VVM_BLOCK_THREADS * 4u * (size_t)instances_per_lane;

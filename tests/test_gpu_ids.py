@@ -134,8 +134,9 @@ def test_acquire_id_on_two_datasets(n, page_kb):
     _same_tables(got_b, want_b)
 
 
+@pytest.mark.parametrize("flags", [0, abi.VVM_EXEC_SEPARATE_PASSES])
 @pytest.mark.parametrize("n,page_kb", [(9, 64), (3001, 2), (120001, 2)])
-def test_update_id_on_two_acquired_datasets(n, page_kb):
+def test_update_id_on_two_acquired_datasets(n, page_kb, flags):
     import struct
     rng = np.random.default_rng(n + 1)
     x = rng.random(n).astype(f32)
@@ -148,7 +149,7 @@ def test_update_id_on_two_acquired_datasets(n, page_kb):
     ref, ref_n, _ = run_oracle(script, consts, [x, ids0, ids1], [f32, np.int32], n, ids=want0, more_datasets=[[f32, np.int32]], more_results=ref_more,
                                more_ids=[want1], page_kb=page_kb)
     out, out_n, _ = run_hip(script, consts, [x, ids0, ids1], [f32, np.int32], n, ids=got0, more_datasets=[[f32, np.int32]], more_results=got_more,
-                            more_ids=[got1], page_kb=page_kb)
+                            more_ids=[got1], page_kb=page_kb, flags=flags)
     assert out_n == ref_n and got_more[0][1] == ref_more[0][1]
     for a, b in zip(out, ref):
         assert np.array_equal(a[:out_n].view(np.uint32), b[:ref_n].view(np.uint32))

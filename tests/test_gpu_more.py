@@ -418,8 +418,10 @@ def test_streams_larger_than_4_gib():
 
 # ---- two datasets ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n,secondary_first,many", [(1, False, False), (1000, False, False), (5003, True, False), (300007, False, True), (300007, True, False)])
-def test_two_datasets_match_the_oracle(n, secondary_first, many):
-    """acquireindex on two datasets: one pass of the kernel per dataset, each with its own mask, count and output positions."""
+@pytest.mark.parametrize("flags", [0, abi.VVM_EXEC_SEPARATE_PASSES])
+def test_two_datasets_match_the_oracle(n, secondary_first, many, flags):
+    """acquireindex on two datasets: one pass per dataset, each with its own mask, count and output positions; the passes run
+    tile by tile in one launch, or (flag) as launches of their own."""
     import dataset_cases
     rng = np.random.default_rng(n)
     x, y = rng.random(n).astype(f32), rng.random(n).astype(f32)
@@ -428,7 +430,7 @@ def test_two_datasets_match_the_oracle(n, secondary_first, many):
     dt0 = [f32] * (11 if many else 2)
     ref_more, got_more = [], []
     ref, ref_n, _ = run_oracle(script, consts, [x, y], dt0, n, more_datasets=[[f32, np.int32]], more_results=ref_more)
-    got, got_n, _ = run_hip(script, consts, [x, y], dt0, n, more_datasets=[[f32, np.int32]], more_results=got_more)
+    got, got_n, _ = run_hip(script, consts, [x, y], dt0, n, more_datasets=[[f32, np.int32]], more_results=got_more, flags=flags)
     assert got_n == ref_n and got_more[0][1] == ref_more[0][1]
     for a, b in zip(got, ref):
         assert np.array_equal(_bits(a[:got_n]), _bits(b[:ref_n]))

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--which", default="transcendental,kill_half,batch")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--no-light", action="store_true", help="keep eight-wide Execs on the general kernel")
+    ap.add_argument("--separate-passes", action="store_true", help="two_datasets: one launch per dataset instead of one launch for both")
     ap.add_argument("--batch-flags", type=int, default=0, help="vvm_exec_options.Flags of every member of the batch (4: force eight instances per lane)")
     args = ap.parse_args()
     import torch
@@ -121,6 +122,55 @@ def main():
         w.constants = struct.pack("<6f", 1.0 / 60.0, 0.0, 0.0, -980.0, 0.98, 1.0) + bytes(8)
         n = 64 * 1024 * 1024
         run_single("fountain with six outputs, 64Mi", w, scripts.fountain_streams_torch(0, n, dev, pad=PAD), 6, n)
+    if "two_datasets" in which:
+        # the fountain update with a second dataset that receives the particles that die this tick (position and age): both
+        # datasets' programs read all eight streams
+        from renderer_amd.assembler import FLOAT, Script
+        import struct
+        s = Script()
+        dt, drag = s.const(0), s.const(4)
+        pos = [s.input(0, FLOAT, k) for k in range(3)]
+        vel = [s.input(0, FLOAT, 3 + k) for k in range(3)]
+        age, life = s.input(0, FLOAT, 6), s.input(0, FLOAT, 7)
+        age1 = s.temp(); s.op("add", age, dt, age1)
+        alive, dead = s.temps(2)
+        s.op("cmplt", age1, life, alive)
+        s.op("cmpge", age1, life, dead)
+        s.acquireindex(alive, 0)
+        s.acquireindex(dead, 1)
+        v1, p1 = s.temps(3), s.temps(3)
+        for c in range(3):
+            s.op("mad_mul", s.const(1 + c), dt, vel[c], drag, v1[c])
+            s.op("mad", v1[c], dt, pos[c], p1[c])
+        s.output_data(FLOAT, 0, [(p1[c], s.output(0, FLOAT, c)) for c in range(3)] + [(v1[c], s.output(0, FLOAT, 3 + c)) for c in range(3)] +
+                      [(age1, s.output(0, FLOAT, 6)), (life, s.output(0, FLOAT, 7))])
+        s.output_data(FLOAT, 1, [(p1[c], s.output(1, FLOAT, c)) for c in range(3)] + [(age1, s.output(1, FLOAT, 3))])
+        built = s.build()
+        consts = struct.pack("<6f", 1.0 / 60.0, 0.0, 0.0, -980.0, 0.98, 1.0) + bytes(8)
+        n = 64 * 1024 * 1024
+        ins = scripts.fountain_streams_torch(0, n, dev, kill_half=True, pad=PAD)
+        outs0 = [torch.zeros(n + PAD, dtype=torch.float32, device=dev) for _ in range(8)]
+        outs1 = [torch.zeros(n + PAD, dtype=torch.float32, device=dev) for _ in range(4)]
+        torch.cuda.synchronize()
+        st = VectorVMState(built.blob, be)
+        frame = st.frame([abi.DataSet([t.data_ptr() for t in ins], [t.data_ptr() for t in outs0], 0), abi.DataSet([], [t.data_ptr() for t in outs1], 0)], n, [consts])
+        o = abi.ExecOptions(0, 0, 0, None, abi.VVM_EXEC_SEPARATE_PASSES if args.separate_passes else 0)
+        for _ in range(3):
+            st.exec(frame, o)
+        st.enable_timing(True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            st.exec_async(frame, o)
+        s0 = st.finish(frame)
+        el = time.perf_counter() - t0
+        ms, launches = st.collect_kernel_ms()
+        s1 = frame.survivors(1)
+        st.close()
+        alg = 32.0 * n + 32.0 * s0 + 16.0 * s1
+        print(json.dumps({"config": "fountain with a second dataset for the particles that die (8 streams in, 8 + 4 out), 64Mi, " +
+                          ("one launch per dataset" if args.separate_passes else "both datasets in one launch"),
+                          "particles": n, "survivors": [s0, s1], "steps": args.steps, "ms_per_step": el / args.steps * 1e3, "kernel_ms_per_exec": ms / max(launches, 1),
+                          "algorithmic_GBps": alg / (ms / max(launches, 1)) / 1e6, "algorithmic_bytes": alg}), flush=True)
     if "transcendental" in which:
         n = 16 * 1024 * 1024
         w = scripts.transcendental(True)
