@@ -305,12 +305,14 @@ template <typename F> static void fold_compares_into_acquires(std::vector<Decode
 		if (j == k) continue;
 		const uint32_t code = acquire_compare_code(ins[j].op);
 		if (code == VVM_ACQ_SIGN || ins[j].kind != K_ORD || ins[j].out.size() != 1 || ins[j].in.size() != 2) continue;
-		// nobody else reads the mask (any instruction, before or after: the register may be reused, but then the fold is skipped)
+		// nobody else reads the mask: no instruction from the compare up to the one that next writes the register (or the end)
 		bool other_reader = false;
-		for (size_t q = 0; q < ins.size() && !other_reader; ++q) {
-			if (q == k) continue;
-			other_reader |= std::find(ins[q].in.begin(), ins[q].in.end(), r) != ins[q].in.end();
-			for (auto& pr : ins[q].pairs) other_reader |= pr.first == r;
+		for (size_t q = j + 1; q < ins.size() && !other_reader; ++q) {
+			if (q != k) {
+				other_reader |= std::find(ins[q].in.begin(), ins[q].in.end(), r) != ins[q].in.end();
+				for (auto& pr : ins[q].pairs) other_reader |= pr.first == r;
+			}
+			if (q != k && std::find(ins[q].out.begin(), ins[q].out.end(), r) != ins[q].out.end()) break;      // (reads its inputs before it writes)
 		}
 		if (other_reader) continue;
 		// the compare's operands still hold the same values at the acquireindex
