@@ -34,9 +34,9 @@ enum : uint32_t {
 	VVM_DOP_LOADN  = 191,  // load up to 8 32-bit input streams into consecutive virtual registers (program prologue only):
 	                       // aux = count, aux2 = first register, w1 = first slot of VvmExecDesc::load_ptrs
 	VVM_DOP_LOADN16 = 190, // the same for 16-bit streams: the raw bits, zero-extended
-	VVM_DOP_ACQUIRE = 192, // acquireindex: aux = dataset, o0 = predicate (keep = its sign bit, aux2 = VVM_ACQ_SIGN), or, with the compare that
+	VVM_DOP_ACQUIRE = 192, // acquireindex: aux = chain (0; 1 = the second dataset of a program that acquires two in one pass), o0 = predicate (keep = its sign bit, aux2 = VVM_ACQ_SIGN), or, with the compare that
 	                       // made the predicate folded in, keep = o0 <aux2> o1; every opcode from here on produces no register result
-	VVM_DOP_OUTPUT32 = 193, // up to 3 (src,dst) pairs of outputdata_float / outputdata_int32: aux = count, aux2 = dataset,
+	VVM_DOP_OUTPUT32 = 193, // up to 3 (src,dst) pairs of outputdata_float / outputdata_int32: aux = count, aux2 = chain of the dataset,
 	                        // o0..o2 = sources, w3 = the first pair's slot of VvmExecDesc::out_list (the pairs of one
 	                        // instruction lie in one group of VVM_STAGE_SLOTS slots)
 	VVM_DOP_OUTPUT16 = 194, // up to 3 pairs of outputdata_half (float register -> half stream)
@@ -66,6 +66,7 @@ enum : uint32_t {
 // entry of VvmExecDesc::out_list: byte address in the low 48 bits (0 = nothing is written), flags above
 #define VVM_OUT_IS16 (1ull << 62)         // the destination stream has 16-bit elements
 #define VVM_OUT_GROUP16 (1ull << 61)      // on a group's first entry: some entry of the group has VVM_OUT_IS16 or VVM_OUT_UPDATE_ID
+#define VVM_OUT_CHAIN1 (1ull << 59)       // the entry belongs to the program's second chain (the second of two datasets acquired in one pass)
 #define VVM_OUT_UPDATE_ID (1ull << 60)    // the slot holds the ID register of an update_id; the address is the Exec's VvmIdDesc
 #define VVM_OUT_ADDR_MASK 0x0000FFFFFFFFFFFFull
 

@@ -248,7 +248,8 @@ struct PreparedExec {
 	uint32_t instances_per_lane = 4;                   // of the kernel this Exec runs on (8, 4 or 1)
 	bool light = false;                                // ... the light eight-wide kernel
 	uint32_t id_buffers = 0;                           // which piece of the state's update_id buffers this pass works in (fused passes run together)
-	bool launch_many() const { return light || lp->many_registers; }      // what vvm_launch_exec_kernel takes as many_registers
+	// what vvm_launch_exec_kernel takes as many_registers (a program with two chains runs four-wide on the kernel with 32 registers: it has the second chain)
+	bool launch_many() const { return light || lp->many_registers || (lp->num_chains > 1 && instances_per_lane == 4); }
 };
 
 int g_page_kb = 64;      // vm.PageSizeInKB, VectorVMRuntime.cpp:44-50
@@ -458,6 +459,7 @@ int fill_params(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* op
 	memset(out_list, 0, pe.bytes - pe.off_out);
 	{   // the entry before the list: where the Exec's last tile writes the survivor count of the acquired dataset
 		out_list[-1] = (uint64_t)(uintptr_t)(d->counts + lp.pass_dataset);
+		if (lp.num_chains > 1) out_list[-2] = (uint64_t)(uintptr_t)(d->counts + lp.chain_dataset[1]);      // (the second chain's)
 	}
 	for (size_t k = 0; k < lp.out_list.size(); ++k) {
 		const int32_t i = lp.out_list[k];
@@ -472,7 +474,7 @@ int fill_params(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* op
 		if (!ds.OutputRegisters.data[idx]) continue;
 		const uint64_t addr = (uint64_t)(uintptr_t)ds.OutputRegisters.data[idx] + (uint64_t)(int64_t)ds.InstanceOffset * stride;
 		if (addr & ~VVM_OUT_ADDR_MASK) return fail(VVM_E_INVALID_ARG, "output register address does not fit 48 bits");
-		out_list[k] = addr | (lp.out_is16[k] ? VVM_OUT_IS16 : 0);
+		out_list[k] = addr | (lp.out_is16[k] ? VVM_OUT_IS16 : 0) | ((k < lp.out_chain.size() && lp.out_chain[k]) ? VVM_OUT_CHAIN1 : 0);
 	}
 	for (size_t k = 0; k < lp.out_list.size(); ++k) {
 		if (lp.out_is16[k]) out_list[k & ~(size_t)(VVM_STAGE_SLOTS - 1)] |= VVM_OUT_GROUP16;
@@ -566,10 +568,9 @@ int stage_id_counters(vvm_state* st, const vvm_exec_context* ctx, const vvm::Lin
 // lane are launched one after the other, on the faster eight-wide kernels (measured on 64 Mi instances, two datasets:
 // 1.48 ms against 1.86 ms fused; the later passes do not find the shared streams in the L2 either way, the tiles in flight
 // are several times its size).  `handled` stays false when the passes have to be launched one after the other.
-int enqueue_fused_passes(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, hipStream_t stream, VvmLaunchState* d_launch, bool timed, bool& handled)
+int enqueue_fused_passes(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, uint32_t K, hipStream_t stream, VvmLaunchState* d_launch, bool timed, bool& handled)
 {
 	handled = false;
-	const uint32_t K = st->wide.num_passes;
 	vvm_exec_options o = opt ? *opt : vvm_exec_options{};
 	std::vector<PreparedExec> pes(K);
 	bool many = false, ids = false;
@@ -754,7 +755,7 @@ static int exec_enqueue(vvm_exec_context* ctx, const vvm_exec_options* opt, bool
 	if (no_alloc) {
 		if (!scratch_ptr) return fail(VVM_E_HIP, "vvm_exec_noalloc: the scratch array of this device has no address");
 		const uint32_t lanes = pe.instances_per_lane;
-		if (pe.tiles > VVM_NOALLOC_MAX_TILES) {
+		if ((uint64_t)pe.tiles * pe.lp->num_chains > VVM_NOALLOC_MAX_TILES) {      // (every chain has look-back words of its own)
 			char msg[192];
 			snprintf(msg, sizeof msg, "vvm_exec_noalloc: %d instances are %u tiles at %u instances per lane; the scratch array holds look-back words for %u tiles",
 			         ctx->NumInstances, pe.tiles, lanes, VVM_NOALLOC_MAX_TILES);
@@ -782,7 +783,8 @@ static int exec_enqueue(vvm_exec_context* ctx, const vvm_exec_options* opt, bool
 		return VVM_OK;
 	}
 	if (!no_alloc) {
-		rc = ensure_status(st, pe.tiles);
+		if ((uint64_t)pe.tiles * pe.lp->num_chains > 0xFFFFFFFFull) return fail(VVM_E_TOO_LARGE, "too many tiles");
+		rc = ensure_status(st, pe.tiles * pe.lp->num_chains);      // (every chain has look-back words of its own)
 		if (rc != VVM_OK) return rc;
 	}
 	unsigned long long* const d_status = no_alloc ? (unsigned long long*)(scratch_ptr + VVM_NOALLOC_STATUS_OFF) : st->d_status;
@@ -800,7 +802,7 @@ static int exec_enqueue(vvm_exec_context* ctx, const vvm_exec_options* opt, bool
 	const uint32_t num_passes = pe.lp->num_passes;
 	if (num_passes > 1 && !no_alloc && !(opt && (opt->Flags & VVM_EXEC_SEPARATE_PASSES))) {
 		bool handled = false;
-		rc = enqueue_fused_passes(st, ctx, opt, stream, d_launch, timed, handled);
+		rc = enqueue_fused_passes(st, ctx, opt, num_passes, stream, d_launch, timed, handled);
 		if (rc != VVM_OK) return rc;
 		if (handled) { st->results_pending = true; return VVM_OK; }
 	}
@@ -1085,7 +1087,7 @@ int batch_plan(BatchWorkspace& ws, vvm_exec_context* ctxs, int n, const vvm_exec
 			const vvm::LinkedProgram& lp = *plan.pes[(size_t)i].lp;
 			// Scripts with ID instructions (they need the MaxUsedID pass and the dataset's counters) and scripts that take one kernel
 			// pass per acquired dataset do not share a launch: they are enqueued one by one behind the batched kernels, on the same stream.
-			if (lp.uses_ids || lp.num_passes > 1) { plan.single[(size_t)i] = 1; continue; }
+			if (lp.uses_ids || lp.num_passes > 1 || lp.num_chains > 1) { plan.single[(size_t)i] = 1; continue; }
 			const int key = kernel_key(plan.pes[(size_t)i]);
 			BatchGroup* g = nullptr;
 			for (BatchGroup& c : slice.groups) if (c.key == key) g = &c;
@@ -1462,7 +1464,7 @@ static void fill_info(const vvm::ThawedScript& s, const vvm::LinkedProgram& lp, 
 	out->LdsSpillRegisters = lp.lds_spill_slots;
 	out->BytesInPerInstance = lp.bytes_in_per_instance;
 	out->BytesOutPerInstance = lp.bytes_out_per_instance;
-	out->Flags = s.flags | (lp.full_kernel ? 0x10000u : 0u);      // (vvm_state_info adds 0x20000: a program for the light eight-wide kernel exists)
+	out->Flags = s.flags | (lp.full_kernel ? 0x10000u : 0u) | (lp.num_chains > 1 ? 0x40000u : 0u);      // (vvm_state_info adds 0x20000: a program for the light eight-wide kernel exists; 0x40000: two acquired datasets in one pass)
 }
 
 VVM_API int vvm_state_info(const vvm_state* st, vvm_program_info* out)

@@ -95,6 +95,9 @@ template <> struct RegTraits<8, false> { typedef vec16f vec; static constexpr ui
 typedef float vec8f __attribute__((ext_vector_type(10)));
 template <> struct RegTraits<8, true> { typedef vec8f vec; static constexpr uint32_t RV = 8; };
 #define IS_LIGHT(V, SPILL) ((V) == 8 && (SPILL))
+// Two acquired datasets in one pass ("chains": each has its own keep mask, ranks, count and look-back words): the general
+// eight-wide kernel and the four-wide kernel with 32 registers have the registers to spare for the second set.
+#define HAS_TWO_CHAINS(V, SPILL, FULL) (!(FULL) && (((V) == 8 && !(SPILL)) || ((V) == 4 && (SPILL))))
 #define VVM_LIGHT_STAGE_SLOTS 6u
 
 // Instance slots of a lane.  V = 1: the lane's one instance.  V = 4: four consecutive instances, [4 tid, 4 tid + 4) of the
@@ -717,6 +720,8 @@ DEV uint32_t look_back(gu64* status, uint32_t tile, uint32_t tag, uint32_t lane,
 #define LC_PREFIX      16     // [2]     resolved prefix, by parity of the resolve
 #define LC_TICKET      18     // [2]     claimed ticket, by parity of the tile
 #define LC_STATS       24     // [8]     profiling sums
+#define LC_WAVE_TOTALS1 32    // [2][2][4]  the same two for the second chain
+#define LC_PREFIX1     48     // [2]
 
 // acquireindex, first half: rank the tile's survivors and publish the tile's count.
 // keep_bits: bit k = instance k of the lane survives.  Returns (rank of the lane's first survivor within the tile, survivors
@@ -725,7 +730,8 @@ DEV uint32_t look_back(gu64* status, uint32_t tile, uint32_t tag, uint32_t lane,
 // With eight instances per lane the tile's two halves are ranked one after the other (all of the first half's survivors come
 // first): HALVES = 2, bits 0..3 / 4..7 of keep_bits, and .y of the result is the rank of the lane's first survivor of the
 // second half.
-template <int HALVES> DEV uint3 acquire_rank_and_publish(uint32_t keep_bits, const Ctx& c, uint32_t* lds_ctrl, gu64* status, uint32_t tile_local, uint32_t tag, uint32_t dbg)
+template <int HALVES> DEV uint3 acquire_rank_and_publish(uint32_t keep_bits, const Ctx& c, uint32_t* lds_ctrl, gu64* status, uint32_t tile_local, uint32_t tag, uint32_t dbg,
+                                                         uint32_t chain = 0)
 {
 	const uint32_t lane = c.tid & 63u;
 	uint32_t below[2] = {0, 0}, wave_total[2] = {0, 0};
@@ -737,7 +743,7 @@ template <int HALVES> DEV uint3 acquire_rank_and_publish(uint32_t keep_bits, con
 			below[h] += lanes_below(b);
 			wave_total[h] += (uint32_t)__popcll(b);
 		}
-	uint32_t* totals = lds_ctrl + LC_WAVE_TOTALS + 8u * (c.phase & 1u);
+	uint32_t* totals = lds_ctrl + (chain ? LC_WAVE_TOTALS1 : LC_WAVE_TOTALS) + 8u * (c.phase & 1u);
 	totals[c.wave] = wave_total[0];            // every lane writes the wave's value
 	if constexpr (HALVES == 2) totals[4u + c.wave] = wave_total[1];
 	__syncthreads();                        // (the words alternate between tiles, so one barrier is enough)
@@ -777,6 +783,10 @@ struct Pending {
 	uint32_t tile_local;
 	gu64*    status;
 	const uint64_t* out_list;      // the Exec's output list; the entry before it is the address of the survivor count
+	// the second chain of a program that acquires two datasets (kernels with HAS_TWO_CHAINS): its look-back words follow the
+	// first chain's, `tiles` words on
+	bool     unresolved1;
+	uint32_t total1, base1, tiles;
 	uint32_t ride;                 // per lane, light kernel: the lane's acquireindex result for the outputs that wait in registers:
 	                               // keep bits [0:8), rank of the lane's first survivor [8:20), of its first one in the second half [20:32)
 };
@@ -792,13 +802,16 @@ struct Pending {
 //                 each staged output.  A thread moves V consecutive values, so every tile stores 128 bits per lane whatever
 //                 its death rate.  Issued after the next tile's loads have arrived: stores and loads share one completion
 //                 counter, and a wait for loads would otherwise also wait for these stores.
-template <int V> DEV void resolve_tile(Pending& p, const Ctx& c, uint32_t* lds_ctrl, uint32_t& resolves, uint32_t tag, VvmLaunchState* ls, uint32_t dbg,
+template <int V, bool TWO = false> DEV void resolve_tile(Pending& p, const Ctx& c, uint32_t* lds_ctrl, uint32_t& resolves, uint32_t tag, VvmLaunchState* ls, uint32_t dbg,
                                      const u64 (&pre)[VVM_LB_WORDS_PER_LANE], bool have_pre)
 {
-	if (p.unresolved && p.tile_local != 0) {
+	const bool need0 = p.unresolved && p.tile_local != 0;
+	const bool need1 = TWO && p.unresolved1 && p.tile_local != 0;
+	if (need0 || need1) {
 		uint32_t* slot = lds_ctrl + LC_PREFIX + (resolves & 1u);
+		uint32_t* slot1 = lds_ctrl + LC_PREFIX1 + (resolves & 1u);
 		++resolves;
-		if (c.wave == 0) {
+		if (c.wave == 0 && need0) {
 			const uint32_t lane = c.tid & 63u;
 			uint32_t rounds = 0, polls = 0;
 			const u64 t0 = (dbg & 128u) ? __builtin_amdgcn_s_memtime() : 0;
@@ -811,14 +824,29 @@ template <int V> DEV void resolve_tile(Pending& p, const Ctx& c, uint32_t* lds_c
 				st[0] = s0; st[1] = s1; st[2] = s2; st[3] = s3;
 			}
 		}
+		if constexpr (TWO) {
+			if (c.wave == 1 && need1) {      // the second chain's look-back runs beside the first one's, on the next wave
+				const uint32_t lane = c.tid & 63u;
+				uint32_t rounds = 0, polls = 0;
+				gu64* status1 = p.status + p.tiles;
+				const u64 none[VVM_LB_WORDS_PER_LANE] = {};
+				const uint32_t ex = look_back(status1, p.tile_local, tag, lane, ls, rounds, polls, none, false);
+				*slot1 = ex;
+				store_u64_first_lane(status1 + p.tile_local, ((u64)tag << 34) | (VVM_LB_INCLUSIVE << 32) | (ex + p.total1), lane);
+			}
+		}
 		__syncthreads();
-		p.base = SCALAR(*slot);
+		if (need0) p.base = SCALAR(*slot);
+		if (need1) p.base1 = SCALAR(*slot1);
 	} else {
 		__syncthreads();
-		if (p.unresolved) p.base = 0;
 	}
+	if (p.unresolved && p.tile_local == 0) p.base = 0;
+	if (TWO && p.unresolved1 && p.tile_local == 0) p.base1 = 0;
 	if (p.unresolved && p.last && c.wave == 0 && !(dbg & 16u)) *(int32_t*)sload64(p.out_list - 1, 0) = (int32_t)(p.base + p.total);
+	if (TWO && p.unresolved1 && p.last && c.wave == 0) *(int32_t*)sload64(p.out_list - 2, 0) = (int32_t)(p.base1 + p.total1);
 	p.unresolved = false;
+	p.unresolved1 = false;
 }
 // One staging slot to its destination: entry `e` of the output list, 32-bit values at src[0..V).  off4 = 4 * base and
 // rec4 = 4 * total come from the caller (the same for every slot).  Elements at and past `total` are dropped by the bounds
@@ -867,13 +895,16 @@ struct StoreArgs {
 	uint32_t rec4;             // 4 * total
 	uint32_t base, tile_first; // for update_id
 	const uint32_t* keep_word; // the thread's acquireindex result in LDS
+	uint64_t off4b;            // the same two for the entries of the second chain (VVM_OUT_CHAIN1)
+	uint32_t rec4b;
 };
 // LAST: the group's last slot, the only one that can hold an update_id (only the FULL kernels run scripts with ID instructions)
-template <int V, bool ANY16, bool LAST> DEV void store_slot(uint64_t e, const float* q, const StoreArgs& a)
+template <int V, bool ANY16, bool LAST, bool TWO> DEV void store_slot(uint64_t e, const float* q, const StoreArgs& a)
 {
 	const uint32_t i0 = a.i0;
-	const uint64_t off4 = a.off4;
-	const uint32_t rec4 = a.rec4;
+	const bool second = TWO && (e & VVM_OUT_CHAIN1);
+	const uint64_t off4 = second ? a.off4b : a.off4;
+	const uint32_t rec4 = second ? a.rec4b : a.rec4;
 	const uint64_t ptr = e & VVM_OUT_ADDR_MASK;
 	if constexpr (ANY16 && LAST && V != 8) {
 		if (e & VVM_OUT_UPDATE_ID) {
@@ -902,10 +933,10 @@ template <int V, bool ANY16, bool LAST> DEV void store_slot(uint64_t e, const fl
 		__builtin_amdgcn_raw_buffer_store_b32(fbits(q[0]), rs, (int)(i0 * 4u), 0, AUX_STREAM_STORE);
 	}
 }
-template <int V, bool ANY16, bool FULL> DEV void store_slots(const uint64_t (&entry)[VVM_STAGE_SLOTS], uint32_t n, const float* src, const StoreArgs& a)
+template <int V, bool ANY16, bool FULL, bool TWO> DEV void store_slots(const uint64_t (&entry)[VVM_STAGE_SLOTS], uint32_t n, const float* src, const StoreArgs& a)
 {
 	// the staged slots are 0 .. n-1: enter the chain at slot n-1 and fall through to slot 0 (no per-slot loop test)
-#define VVM_SLOT(s) store_slot<V, ANY16, FULL && (s) == VVM_STAGE_SLOTS - 1>(entry[s], src + (s) * (VVM_BLOCK_THREADS * V), a)
+#define VVM_SLOT(s) store_slot<V, ANY16, FULL && (s) == VVM_STAGE_SLOTS - 1, TWO>(entry[s], src + (s) * (VVM_BLOCK_THREADS * V), a)
 	switch (n) {
 	case 8: VVM_SLOT(7); [[fallthrough]];
 	case 7: VVM_SLOT(6); [[fallthrough]];
@@ -919,7 +950,7 @@ template <int V, bool ANY16, bool FULL> DEV void store_slots(const uint64_t (&en
 	}
 #undef VVM_SLOT
 }
-template <int V, bool FULL, bool LIGHT, typename VEC> DEV void store_tile(Pending& p, const Ctx& c, unsigned char* lds, uint32_t dbg,
+template <int V, bool FULL, bool LIGHT, bool TWO, typename VEC> DEV void store_tile(Pending& p, const Ctx& c, unsigned char* lds, uint32_t dbg,
                                                                        VEC R0, VEC R1, VEC R2, VEC R3, VEC R4, VEC R5, VEC R6, VEC R7)
 {
 	static_assert(VVM_STAGE_SLOTS == 8, "store_slots is written for eight slots");
@@ -930,10 +961,11 @@ template <int V, bool FULL, bool LIGHT, typename VEC> DEV void store_tile(Pendin
 		sload64x8(p.out_list, STAGED_FIRST(p.stage_end), entry);
 		StoreArgs a;
 		a.i0 = c.tid * lane_stride<V>(); a.off4 = 4ull * p.base; a.rec4 = 4u * p.total; a.base = p.base; a.tile_first = p.tile_local * (VVM_BLOCK_THREADS * V);
+		a.off4b = TWO ? 4ull * p.base1 : 0; a.rec4b = TWO ? 4u * p.total1 : 0;
 		a.keep_word = (const uint32_t*)(lds + LDS_STAGE_KEEP_OFF(V, FULL, LIGHT)) + c.tid;
 		const float* src = (const float*)(lds + LDS_STAGE_OFF(FULL)) + a.i0;
-		if (entry[0] & VVM_OUT_GROUP16) store_slots<V, true, FULL>(entry, n_staged, src, a);
-		else store_slots<V, false, FULL>(entry, n_staged, src, a);
+		if (entry[0] & VVM_OUT_GROUP16) store_slots<V, true, FULL, TWO>(entry, n_staged, src, a);
+		else store_slots<V, false, FULL, TWO>(entry, n_staged, src, a);
 		if constexpr (LIGHT) {
 			// Entries six and seven of a light program's list: their values never went to a staging slot, they are still in the registers
 			// the tile left them in (the program that runs now writes those only after this point).  A full tile's values go out as
@@ -1041,6 +1073,11 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 	uint32_t t_keep = 0, t_rank = 0, t_rank_b = 0;      // (t_rank_b: the second half of an eight-instance tile)
 	uint32_t t_total = 0, t_base = 0;
 	bool t_pending = false;          // the tile's count is published, its prefix not yet resolved
+	// the same for the second chain of a program that acquires two datasets (acquireindex's aux and an output's aux2 say which)
+	constexpr bool TWO = HAS_TWO_CHAINS(V, SPILL, FULL);
+	uint32_t u_keep = 0, u_rank = 0, u_rank_b = 0, u_total = 0, u_base = 0;
+	bool u_pending = false;
+	const uint32_t exec_tiles = TWO ? DESC_U32(c.dp, num_tiles) : 0u;
 	uint32_t stage_end = 0;          // output-list index one past the last slot this tile has staged (0: nothing staged)
 
 	// Uniform registers: lane i of `uni` holds constant i.  Filled by scalar loads and lane writes (the table is padded to a
@@ -1447,15 +1484,17 @@ leave_run:
 #pragma unroll
 			for (int k = 0; k < V; ++k)
 				kb |= ((fbits(p[k]) >> 31) & ((c.inst0 + slot_offset<V>(k) < c.num_instances) ? 1u : 0u)) << k;
-			const uint3 rt = acquire_rank_and_publish<(V == 8 ? 2 : 1)>(kb, c, lds_ctrl, status, tile_local, tag, dbg);
-			t_keep = kb; t_rank = rt.x; t_rank_b = rt.y; t_total = SCALAR(rt.z); t_pending = true;
+			const uint32_t chain = TWO ? aux : 0u;
+			const uint3 rt = acquire_rank_and_publish<(V == 8 ? 2 : 1)>(kb, c, lds_ctrl, status + (size_t)chain * exec_tiles, tile_local, tag, dbg, chain);
+			if (TWO && chain) { u_keep = kb; u_rank = rt.x; u_rank_b = rt.y; u_total = SCALAR(rt.z); u_pending = true; }
+			else { t_keep = kb; t_rank = rt.x; t_rank_b = rt.y; t_total = SCALAR(rt.z); t_pending = true; }
 		}
 		// The previous tile is finished here: after this tile has published its own count (every later tile's look-back waits
 		// for that word, so it goes out first), and before this tile needs the staging slots.  The first poll of the previous
 		// tile's look-back has been in flight since this tile was claimed.
 		if (pend.active) {
-			resolve_tile<V>(pend, c, lds_ctrl, resolves, tag, ls, dbg, pre, have_pre);
-			store_tile<V, FULL, IS_LIGHT(V, SPILL)>(pend, c, lds, dbg, RARGS);
+			resolve_tile<V, TWO>(pend, c, lds_ctrl, resolves, tag, ls, dbg, pre, have_pre);
+			store_tile<V, FULL, IS_LIGHT(V, SPILL), TWO>(pend, c, lds, dbg, RARGS);
 			__syncthreads();      // every thread has read its staged values: the slots may be written again
 		}
 		if (op == VVM_DOP_ACQUIRE) continue;
@@ -1468,10 +1507,12 @@ leave_run:
 			cur.active = true; cur.unresolved = t_pending; cur.total = t_total; cur.base = t_base;
 			cur.stage_end = stage_end; cur.last = last_tile;
 			cur.tile_local = tile_local; cur.status = status; cur.out_list = c.out_list; cur.ride = 0;
-			resolve_tile<V>(cur, c, lds_ctrl, resolves, tag, ls, dbg, pre, false);
-			store_tile<V, FULL, IS_LIGHT(V, SPILL)>(cur, c, lds, dbg, RARGS);
+			cur.unresolved1 = u_pending; cur.total1 = u_total; cur.base1 = u_base; cur.tiles = exec_tiles;
+			resolve_tile<V, TWO>(cur, c, lds_ctrl, resolves, tag, ls, dbg, pre, false);
+			store_tile<V, FULL, IS_LIGHT(V, SPILL), TWO>(cur, c, lds, dbg, RARGS);
 			__syncthreads();      // the slots are written again right away
 			t_base = cur.base; t_pending = false; stage_end = 0;
+			u_base = cur.base1; u_pending = false;
 			continue;
 		}
 
@@ -1497,7 +1538,9 @@ leave_run:
 		// out later.  Without an acquireindex before it nothing survives (VectorVMRuntime.cpp:565, 769): everything goes to
 		// the sink, and the host leaves such an output's list entry empty.
 		{
-			const bool all_alive = (t_total == VVM_BLOCK_THREADS * V);
+			const bool second = TWO && aux2 != 0;      // the output's chain
+			const uint32_t o_total = second ? u_total : t_total, o_keep = second ? u_keep : t_keep, o_rank = second ? u_rank : t_rank, o_rank_b = second ? u_rank_b : t_rank_b;
+			const bool all_alive = (o_total == VVM_BLOCK_THREADS * V);
 			const uint32_t kind = op - VVM_DOP_OUTPUT32;          // 0: 32-bit value  1: float -> half  2: low 16 bits as they are  3: half bits -> float
 			const uint32_t first_slot = o4 | (o5 << 16);
 			float* slot = (float*)(lds + LDS_STAGE_OFF(FULL)) + (first_slot & (VVM_STAGE_SLOTS - 1u)) * (VVM_BLOCK_THREADS * V);
@@ -1521,11 +1564,11 @@ leave_run:
 					if constexpr (V == 8) { f4a x; x.x = v[4]; x.y = v[5]; x.z = v[6]; x.w = v[7]; *(f4a*)(slot + VVM_HALF_TILE + c.tid * 4) = x; }
 				} else {
 					// survivor j of the lane goes to rank + j; a dead instance's value goes to the thread's sink dword (no per-lane branch)
-					uint32_t r = t_rank;
+					uint32_t r = o_rank;
 #pragma unroll
 					for (int k = 0; k < V; ++k) {
-						if (V == 8 && k == 4) r = t_rank_b;
-						const bool keep = (t_keep >> k) & 1u;
+						if (V == 8 && k == 4) r = o_rank_b;
+						const bool keep = (o_keep >> k) & 1u;
 						float* q = keep ? (slot + r) : sink;
 						*q = v[k];
 						r += keep ? 1u : 0u;
@@ -1541,7 +1584,8 @@ leave_run:
 		st[5] = s5; st[6] = s6;
 	}
 	// hand the rest of the tile's work to the next tile's load phase
-	pend.active = (stage_end != 0) || t_pending;
+	pend.active = (stage_end != 0) || t_pending || u_pending;
+	pend.unresolved1 = u_pending; pend.total1 = u_total; pend.base1 = u_base; pend.tiles = exec_tiles;
 	pend.unresolved = t_pending; pend.total = t_total; pend.base = t_base; pend.stage_end = stage_end; pend.last = last_tile;
 	pend.tile_local = tile_local; pend.status = status; pend.out_list = c.out_list;
 	pend.ride = t_keep | (t_rank << 8) | (t_rank_b << 20);
@@ -1561,6 +1605,7 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (IS_LIGHT(V, SPILL) ? 3 : V
 	Pending pend;
 	pend.active = false; pend.unresolved = false; pend.last = false; pend.total = 0; pend.base = 0; pend.stage_end = 0; pend.tile_local = 0;
 	pend.status = nullptr; pend.out_list = nullptr; pend.ride = 0;
+	pend.unresolved1 = false; pend.total1 = 0; pend.base1 = 0; pend.tiles = 0;
 	const uint32_t tid = threadIdx.x;
 	const uint32_t wave = SCALAR(tid >> 6), lane = tid & 63u;
 	// ticket counter of this workgroup's class (see VvmLaunchState); with fewer workgroups than classes only the first
@@ -1660,8 +1705,8 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (IS_LIGHT(V, SPILL) ? 3 : V
 		c.dp = nullptr; c.rel = 0; c.consts = nullptr; c.out_list = nullptr; c.spill = lds_spill;
 		c.tid = tid; c.wave = wave; c.inst0 = 0; c.num_instances = 0; c.tile_first = 0; c.valid = 0; c.phase = 0;
 		const u64 none[VVM_LB_WORDS_PER_LANE] = {};
-		resolve_tile<V>(pend, c, lds_ctrl, resolves, tag, env.ls, dbgw, none, false);
-		store_tile<V, FULL, IS_LIGHT(V, SPILL)>(pend, c, lds, dbgw, K0, K1, K2, K3, K4, K5, K6, K7);
+		resolve_tile<V, HAS_TWO_CHAINS(V, SPILL, FULL)>(pend, c, lds_ctrl, resolves, tag, env.ls, dbgw, none, false);
+		store_tile<V, FULL, IS_LIGHT(V, SPILL), HAS_TWO_CHAINS(V, SPILL, FULL)>(pend, c, lds, dbgw, K0, K1, K2, K3, K4, K5, K6, K7);
 	}
 
 	// the last workgroup to leave re-arms the launch words for the next launch

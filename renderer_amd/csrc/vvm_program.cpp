@@ -327,8 +327,26 @@ template <typename F> static void fold_compares_into_acquires(std::vector<Decode
 	}
 }
 
+static int link_program_as(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, std::string& err, uint32_t pass, bool light, bool allow_chains, bool& chains_failed);
+
 int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, std::string& err, uint32_t pass, bool light)
 {
+	// first as one pass with two chains, where the script has two acquired datasets; if the program then needs a kernel that
+	// has no second chain, as one pass per dataset
+	const bool try_chains = !light && !force_narrow && pass == 0 && !getenv("VVM_NO_CHAINS");
+	bool chains_failed = false;
+	int rc = link_program_as(s, force_narrow, lp, err, pass, light, try_chains, chains_failed);
+	if (chains_failed) {
+		lp = LinkedProgram();
+		err.clear();
+		rc = link_program_as(s, force_narrow, lp, err, pass, light, false, chains_failed);
+	}
+	return rc;
+}
+
+static int link_program_as(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, std::string& err, uint32_t pass, bool light, bool allow_chains, bool& chains_failed)
+{
+	chains_failed = false;
 	std::vector<Decoded> ins;
 	int rc = decode(s, ins, err);
 	if (rc != VVM_OK) return rc;
@@ -441,11 +459,16 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 	// A script that runs acquireindex for several datasets is executed in one pass per dataset: every pass runs the whole
 	// script, but only the pass's dataset is compacted and written (the others' acquireindex and outputs are left out of the
 	// pass's program).  The instructions are pure functions of the inputs, so every pass computes the same values.
-	lp.num_passes = std::max<uint32_t>(1, (uint32_t)lp.acquire_order.size());
+	const bool chains = allow_chains && lp.acquire_order.size() == 2 && lp.id_uses.empty();
+	lp.num_chains = chains ? 2 : 1;
+	lp.num_passes = chains ? 1 : std::max<uint32_t>(1, (uint32_t)lp.acquire_order.size());
 	if (pass >= lp.num_passes) { err = "pass index out of range"; return VVM_E_INVALID_ARG; }
 	const bool multi_pass = lp.num_passes > 1;
 	const uint32_t pass_dataset = lp.acquire_order.empty() ? 0 : lp.acquire_order[pass];
 	lp.pass_dataset = pass_dataset;
+	lp.chain_dataset[0] = pass_dataset;
+	lp.chain_dataset[1] = chains ? lp.acquire_order[1] : pass_dataset;
+	auto chain_of = [&](uint32_t dataset) -> uint32_t { return (chains && dataset == lp.acquire_order[1]) ? 1u : 0u; };
 	// update_id runs in its dataset's pass; acquire_id in every pass (its register results may feed any dataset's outputs; what it
 	// writes to the ID tables depends on the instance index alone, so every pass writes the same)
 	if (multi_pass)
@@ -610,7 +633,8 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 	emit_loads(prefetch32, VVM_DOP_LOADN);
 	emit_loads(prefetch16, VVM_DOP_LOADN16);
 	uint32_t rand_ordinal = 0;
-	int acquired_dataset = -1;       // dataset of the acquireindex seen so far (a script has at most one)
+	int acquired_dataset = -1;       // dataset of the acquireindex seen so far (a pass has one; with two chains: the first chain's)
+	int acquired_second = -1;        // ... the second chain's
 	// The output list is cut into groups of VVM_STAGE_SLOTS entries (one staging slot each).  An output instruction never
 	// straddles two groups, and a flush instruction precedes the first instruction that stages into a new group.  When the
 	// script has an update_id, the last entry of every group is kept for it (-1 where it is not used).
@@ -686,9 +710,9 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 		}
 		case K_ACQUIRE:
 			if (multi_pass && d.dataset != pass_dataset) break;       // another pass's dataset
-			acquired_dataset = (int)d.dataset;
+			if (chain_of(d.dataset)) acquired_second = (int)d.dataset; else acquired_dataset = (int)d.dataset;
 			if (acquire_at == (size_t)-1) acquire_at = lp.code.size();
-			k.w0 = VVM_INS_W0(VVM_DOP_ACQUIRE, 1, 0, d.dataset, d.in.size() == 2 ? d.fn : VVM_ACQ_SIGN);      // (fn: the folded compare, see fold_compares_into_acquires)
+			k.w0 = VVM_INS_W0(VVM_DOP_ACQUIRE, 1, 0, chain_of(d.dataset), d.in.size() == 2 ? d.fn : VVM_ACQ_SIGN);      // (fn: the folded compare, see fold_compares_into_acquires)
 			k.w1 = operand(d.in[0]) | (d.in.size() == 2 ? operand(d.in[1]) << 16 : 0u);
 			lp.code.push_back(k);
 			break;
@@ -700,7 +724,8 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 			if (multi_pass && d.dataset != pass_dataset) break;       // another pass's dataset
 			// An output that no acquireindex precedes, or whose dataset is not the acquired one, writes nothing
 			// (VectorVMRuntime.cpp:565, 769): its list entry stays empty.
-			const bool live = acquired_dataset >= 0 && (uint32_t)acquired_dataset == d.dataset;
+			const bool live = (acquired_dataset >= 0 && (uint32_t)acquired_dataset == d.dataset) || (acquired_second >= 0 && (uint32_t)acquired_second == d.dataset);
+			const uint32_t chain = chain_of(d.dataset);
 			for (size_t i = 0; i < d.pairs.size();) {
 				if (light && dop == VVM_DOP_OUTPUT32 && live && rides_.size() < 2) {
 					const uint32_t src = operand(d.pairs[i].first);
@@ -728,9 +753,11 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 					o[j] = operand(d.pairs[i + j].first);
 					lp.out_list[at + j] = live ? (int32_t)(d.pairs[i + j].second - out0) : -1;      // output serial index
 					lp.out_is16[at + j] = (dop == VVM_DOP_OUTPUT16 || dop == VVM_DOP_OUTPUT16_FROM16);
+					if (lp.out_chain.size() < lp.out_list.size()) lp.out_chain.resize(lp.out_list.size(), 0);
+					lp.out_chain[at + j] = (uint8_t)chain;
 				}
 				out_cursor = at + n;
-				k.w0 = VVM_INS_W0(dop, 0, 0, n, d.dataset);
+				k.w0 = VVM_INS_W0(dop, 0, 0, n, chain);
 				k.w1 = o[0] | (o[1] << 16); k.w2 = o[2];
 				lp.code.push_back(k);
 				i += n;
@@ -822,6 +849,8 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 		err = msg;
 		return VVM_E_TOO_LARGE;
 	}
+	if (chains && (lp.full_kernel || V != 4)) { chains_failed = true; err = "two chains need a kernel that has them"; return VVM_E_UNSUPPORTED_OP; }
+	lp.out_chain.resize(lp.out_list.size(), 0);
 	if (light) {
 		// the light eight-wide kernel: eight resident registers, one load instruction of 32-bit streams into registers 0.., ops of at
 		// most four operands, none of the transcendental / noise / ID instructions, one acquired dataset, and at most eight outputs: with

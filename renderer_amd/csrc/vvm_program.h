@@ -56,6 +56,13 @@ struct LinkedProgram {
 	std::vector<uint32_t> acquire_order;     // those datasets in program order
 	uint32_t num_passes = 1;                 // one pass per acquired dataset (see link_program)
 	uint32_t pass_dataset = 0;               // the dataset this program compacts and writes
+	// A script that acquires exactly two datasets and needs neither the transcendental / noise / ID instructions nor the
+	// one-instance-per-lane kernel is linked as ONE pass with two chains instead (num_passes = 1, num_chains = 2): both
+	// acquireindex run in it, each with its own keep mask, count and look-back words, and every output belongs to the chain of
+	// its dataset.  chain_dataset[c] = the dataset of chain c (chain 0 = pass_dataset); out_chain[k] = the chain of output-list entry k.
+	uint32_t num_chains = 1;
+	uint32_t chain_dataset[2] = {0, 0};
+	std::vector<uint8_t> out_chain;
 	uint32_t bytes_in_per_instance = 0, bytes_out_per_instance = 0;
 	uint32_t num_prefetched_inputs = 0;
 	std::vector<uint8_t> input_used;   // per remapped input: some instruction of this program reads it

@@ -418,10 +418,14 @@ def test_streams_larger_than_4_gib():
 
 # ---- two datasets ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n,secondary_first,many", [(1, False, False), (1000, False, False), (5003, True, False), (300007, False, True), (300007, True, False)])
-@pytest.mark.parametrize("flags", [0, abi.VVM_EXEC_SEPARATE_PASSES])
-def test_two_datasets_match_the_oracle(n, secondary_first, many, flags):
-    """acquireindex on two datasets: one pass per dataset, each with its own mask, count and output positions; the passes run
-    tile by tile in one launch, or (flag) as launches of their own."""
+@pytest.mark.parametrize("mode", ["chains", "fused", "separate"])
+def test_two_datasets_match_the_oracle(n, secondary_first, many, mode, monkeypatch):
+    """acquireindex on two datasets, each with its own mask, count and output positions.  chains: both in one pass of the kernel
+    (the default for scripts like this one); fused / separate: one program per dataset, run tile by tile in one launch / as
+    launches of their own (what scripts get whose kernels have no second chain)."""
+    if mode != "chains":
+        monkeypatch.setenv("VVM_NO_CHAINS", "1")      # (read when the state is allocated)
+    flags = abi.VVM_EXEC_SEPARATE_PASSES if mode == "separate" else 0
     import dataset_cases
     rng = np.random.default_rng(n)
     x, y = rng.random(n).astype(f32), rng.random(n).astype(f32)
@@ -430,7 +434,8 @@ def test_two_datasets_match_the_oracle(n, secondary_first, many, flags):
     dt0 = [f32] * (11 if many else 2)
     ref_more, got_more = [], []
     ref, ref_n, _ = run_oracle(script, consts, [x, y], dt0, n, more_datasets=[[f32, np.int32]], more_results=ref_more)
-    got, got_n, _ = run_hip(script, consts, [x, y], dt0, n, more_datasets=[[f32, np.int32]], more_results=got_more, flags=flags)
+    got, got_n, info = run_hip(script, consts, [x, y], dt0, n, more_datasets=[[f32, np.int32]], more_results=got_more, flags=flags)
+    assert bool(info.Flags & 0x40000) == (mode == "chains")      # both datasets in one pass
     assert got_n == ref_n and got_more[0][1] == ref_more[0][1]
     for a, b in zip(got, ref):
         assert np.array_equal(_bits(a[:got_n]), _bits(b[:ref_n]))

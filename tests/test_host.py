@@ -407,16 +407,29 @@ def test_id_instructions_link():
     assert sorted(c["aux"] for c in acq) == [0, 1] and all(c["nin"] == 0 for c in acq)
 
 
-def test_two_acquire_datasets_link_to_one_program_per_dataset():
+def test_two_acquire_datasets_link_to_one_pass_with_two_chains():
+    """Both acquireindex in one program (aux = chain), every output instruction names the chain of its dataset."""
     import dataset_cases
     blob = dataset_cases.two_dataset_script().blob
     info = be().inspect_blob(blob)
+    code = [decode(i) for i in be().inspect_code(blob)]
+    acq = [c for c in code if c["op"] == DOP_ACQUIRE]
+    outs = [c for c in code if c["op"] == DOP_OUT32]
+    assert [c["aux"] for c in acq] == [0, 1]
+    assert sorted(c["aux2"] for c in outs) == [0, 1, 1] and sum(c["aux"] for c in outs) == 4      # two outputs of dataset 0, a float and an int of dataset 1
+    assert info.InstancesPerLane == 4
+
+
+def test_two_acquire_datasets_link_to_one_program_per_dataset_without_chains(monkeypatch):
+    """VVM_NO_CHAINS (read at every link): one program per dataset, as for scripts whose kernels have no second chain."""
+    import dataset_cases
+    monkeypatch.setenv("VVM_NO_CHAINS", "1")
+    blob = dataset_cases.two_dataset_script().blob
     code = [decode(i) for i in be().inspect_code(blob)]                           # the first pass: dataset 0 only
     acq = [c for c in code if c["op"] == DOP_ACQUIRE]
     outs = [c for c in code if c["op"] == DOP_OUT32]
     assert len(acq) == 1 and acq[0]["aux"] == 0
     assert len(outs) == 1 and outs[0]["aux"] == 2 and outs[0]["aux2"] == 0
-    assert info.InstancesPerLane == 4
 
 
 def test_unsupported_features_are_named():
