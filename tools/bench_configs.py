@@ -183,6 +183,27 @@ def main():
         n = 250_000_000
         w = scripts.fountain()
         run_single("fountain 250M, 50% death (one GPU's share of 2G particles)", w, scripts.fountain_streams_torch(0, n, dev, kill_half=True, pad=PAD), 8, n)
+    if "small_sizes" in which:
+        # one Exec of the fountain script at small sizes, four-wide against the (forced) light eight-wide kernel
+        w = scripts.fountain()
+        for n in (16 * 1024, 64 * 1024, 128 * 1024, 256 * 1024, 1024 * 1024):
+            ins = scripts.fountain_streams_torch(0, n, dev, pad=PAD)
+            for label, flag in (("four-wide", abi.VVM_EXEC_NO_EIGHT_WIDE), ("eight-wide forced", abi.VVM_EXEC_FORCE_EIGHT_WIDE)):
+                args.no_light, keep = False, args.no_light
+                outs = [torch.zeros(n + PAD, dtype=torch.float32, device=dev) for _ in range(8)]
+                st = VectorVMState(w.script.blob, be)
+                frame = st.frame([abi.DataSet([t.data_ptr() for t in ins], [t.data_ptr() for t in outs], 0)], n, [w.constants])
+                o = abi.ExecOptions(0, 0, 0, None, flag)
+                for _ in range(3):
+                    st.exec(frame, o)
+                st.enable_timing(True)
+                for _ in range(50):
+                    st.exec_async(frame, o)
+                st.finish(frame)
+                ms, launches = st.collect_kernel_ms()
+                print(json.dumps({"config": "fountain %d instances, %s" % (n, label), "kernel_us": ms / launches * 1e3, "width": st.last_exec_width()}), flush=True)
+                st.close()
+                args.no_light = keep
     if "one_million" in which:
         n = 1024 * 1024
         w = scripts.fountain()
