@@ -393,6 +393,15 @@ enum {
 VVM_API int vvm_optimize_script(const uint8_t* bytecode, int32_t num_bytes, const vvm_ext_fn_io* ext_fns, int32_t num_ext_fns,
                                 uint64_t hash_id, uint32_t flags, uint8_t** blob, size_t* blob_bytes, uint32_t* error_flags);
 VVM_API void vvm_free_blob(uint8_t* blob);
+/* GenerateHumanReadableScript (VectorVMOptimizer.h:18, VectorVMOptimizer.cpp:220-253): the optimizer's instruction list for the
+ * script, as text in the reference's layout (summary, constant-table section, one "<position>\t| <instruction>;" line per
+ * instruction that survives, registers as R / C / I / O [index]); op names as in editor builds of the reference.  The reference
+ * prints from the intermediate state that VVMFlag_OptSaveIntermediateState (flags bit 0, VectorVM.h:531) keeps in the optimizer
+ * context; this call optimizes the script for the listing.  *text is NUL-terminated malloc'd memory, released with
+ * vvm_free_text; error reporting as vvm_optimize_script. */
+VVM_API int vvm_generate_human_readable_script(const uint8_t* bytecode, int32_t num_bytes, const vvm_ext_fn_io* ext_fns, int32_t num_ext_fns,
+                                               uint32_t flags, char** text, size_t* text_bytes, uint32_t* error_flags);
+VVM_API void vvm_free_text(char* text);
 
 /* Thread-local text of the last failure in this library. */
 VVM_API const char* vvm_last_error(void);

@@ -337,6 +337,11 @@ class HipBackend(Backend):
                                           C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32)]
         L.vvm_free_blob.restype = None
         L.vvm_free_blob.argtypes = [C.c_void_p]
+        L.vvm_generate_human_readable_script.restype = C.c_int
+        L.vvm_generate_human_readable_script.argtypes = [C.c_char_p, C.c_int32, C.c_void_p, C.c_int32, C.c_uint32,
+                                                         C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32)]
+        L.vvm_free_text.restype = None
+        L.vvm_free_text.argtypes = [C.c_void_p]
 
     def _check(self, rc: int, where: str) -> None:
         if rc != VVM_OK:
@@ -467,6 +472,19 @@ class HipBackend(Backend):
             return C.string_at(blob, size.value) if blob.value else b""
         finally:
             self.lib.vvm_free_blob(blob)
+
+    def human_readable_script(self, bytecode: bytes, ext_fns: Sequence = (), flags: int = 0) -> str:
+        """GenerateHumanReadableScript (VectorVMOptimizer.cpp:220-253): the optimized instruction list of a compiler-format script."""
+        io = (C.c_int32 * (2 * len(ext_fns)))(*[v for pair in ext_fns for v in pair]) if ext_fns else None
+        text, size, err = C.c_void_p(), C.c_size_t(), C.c_uint32()
+        rc = self.lib.vvm_generate_human_readable_script(bytecode, len(bytecode), C.cast(io, C.c_void_p) if io else None, len(ext_fns), flags,
+                                                         C.byref(text), C.byref(size), C.byref(err))
+        if rc != VVM_OK:
+            raise VVMError(rc, "vvm_generate_human_readable_script", "optimizer error flags 0x%x" % err.value)
+        try:
+            return C.string_at(text, size.value).decode("ascii")
+        finally:
+            self.lib.vvm_free_text(text)
 
 
 def hip_library_path() -> str:

@@ -379,3 +379,22 @@ def test_listing_reads_like_the_script():
     text = listing(optimize(oc.fountain()[0]))
     assert "  1 | cmplt                  o0 = (o6, i7)" in text and "acquireindex           o0, dataset 0" in text
     assert "c2   = constant dword 4" in text and "i7   = dataset 0 float input 7" in text and text.count("outputdata_float") == 3
+
+
+def test_human_readable_script_of_the_fountain():
+    """GenerateHumanReadableScript's layout (VectorVMOptimizer.cpp:104-253): summary, empty constant-table section, one numbered
+    line per instruction that was not folded into another (the positions of the folded ones are skipped)."""
+    o, meta = oc.fountain()
+    text = be().human_readable_script(o.done(), o.ext)
+    lines = text.split("\n")
+    assert lines[1:4] == ["-------------------------------", "Summary", "-------------------------------"]
+    assert "Num Constants: 5" in lines and any(l.startswith("Byte Code (") for l in lines)
+    body = [l for l in lines if "\t| " in l]
+    assert body[0].endswith("= inputdata_float();") and body[-1].endswith("| done();")
+    ops = [l.split("| ")[1] for l in body]
+    assert "O[6] = add(I[6], C[0]);" in ops and "O[0] = acquireindex(O[0]);" in ops
+    assert sum("mad_mul(" in l for l in ops) == 3 and not any(" mul(" in l for l in ops)      # mad + mul are listed as the merged op only
+    numbers = [int(l.split("\t")[0]) for l in body]
+    assert numbers == sorted(numbers) and len(numbers) < numbers[-1] + 1      # positions of merged instructions are missing
+    assert sum(l.startswith("outputdata_float(0, ") for l in ops) == 8
+    assert be().human_readable_script(b"", ()).count("Num Byte Code Ops: 0") == 1
