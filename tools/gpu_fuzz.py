@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """usage: gpu_fuzz.py <first seed> <last seed>   (on a GPU box)  random compiler-format scripts (the generator of
 tests/test_optimizer_fuzz.py) through the optimizer, then on libvvm_hip.so against the CPU oracle, bit for bit; every script runs
-on the four-wide kernel and, where the linker allows it, on the eight-wide one."""
+on the four-wide kernel and, where the linker allows it, on the eight-wide ones (light and general)."""
 import os
 import sys
 
@@ -27,7 +27,7 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     dts = [f32] * fo + [np.int32] * io
     blob = Blob(optimize(o))
     ref = run_oracle(blob, [consts], ins, dts, n)
-    for flags in (abi.VVM_EXEC_NO_EIGHT_WIDE, abi.VVM_EXEC_FORCE_EIGHT_WIDE):
+    for flags in (abi.VVM_EXEC_NO_EIGHT_WIDE, abi.VVM_EXEC_FORCE_EIGHT_WIDE, abi.VVM_EXEC_FORCE_EIGHT_WIDE | abi.VVM_EXEC_NO_LIGHT_KERNEL):
         got = run_hip(blob, [consts], ins, dts, n, flags=flags)
         ok = got[1] == ref[1]
         for k in range(len(dts)):

@@ -212,7 +212,7 @@ def main():
             more = [dts1] if dts1 else []
             ref_more, got_more = [], []
             ref = run_oracle(built, [consts], ins, dts, n, seed=seed, instance_offset=offset, more_datasets=more, more_results=ref_more, ext_fns=list(gen.ext), ids=want_ids)
-            got = run_hip(built, [consts], ins, dts, n, seed=seed, instance_offset=offset, flags=abi.VVM_EXEC_FORCE_EIGHT_WIDE if seed % 2 else 0,
+            got = run_hip(built, [consts], ins, dts, n, seed=seed, instance_offset=offset, flags=(0, abi.VVM_EXEC_FORCE_EIGHT_WIDE, abi.VVM_EXEC_SEPARATE_PASSES, abi.VVM_EXEC_FORCE_EIGHT_WIDE | abi.VVM_EXEC_NO_LIGHT_KERNEL)[seed % 4],
                           more_datasets=more, more_results=got_more, ext_fns=list(gen.ext), ids=got_ids)
         except abi.VVMError as e:
             if e.code == abi.VVM_E_TOO_LARGE:
