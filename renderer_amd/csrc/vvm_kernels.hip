@@ -1640,8 +1640,14 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (IS_LIGHT(V, SPILL) ? 3 : V
 			const uint32_t s4 = st[4] + (uint32_t)((__builtin_amdgcn_s_memtime() - tk0) >> 4), s7 = st[7] + 1u;
 			st[4] = s4; st[7] = s7;
 		}
-		if (draw >= (env.total_tiles + classes - 1u - cls) / classes) break;      // this class has that many tiles
-		const uint32_t ticket = draw * classes + cls;
+#ifndef VVM_TILE_RUN
+#define VVM_TILE_RUN 2u
+#endif
+		// draw c of class k is tile (c / RUN) * RUN * classes + k * RUN + c % RUN: a class works through runs of RUN adjacent tiles
+		// (RUN = 1: tile c * classes + k); increasing in c, so the class is done at the first tile past the end.  Measured on the
+		// 64 Mi fountain Exec: RUN 1 0.770 ms, 2 0.758 ms, 4 0.760 ms, 8 0.762 ms, 16 0.771 ms
+		const uint32_t ticket = (draw / VVM_TILE_RUN) * (VVM_TILE_RUN * classes) + cls * VVM_TILE_RUN + (draw % VVM_TILE_RUN);
+		if (ticket >= env.total_tiles) break;
 
 		// Both are re-read from the kernel-argument segment for every tile (one scalar load): kept across the tile they cost four
 		// scalar registers that the four-wide kernel does not have to spare (1.7 % on the half-dying workload).
