@@ -1,0 +1,25 @@
+// host-only sanitizer driver: thaws and links every blob given on the command line in all link modes
+#include "vvm_program.h"
+#include <cstdio>
+#include <fstream>
+#include <iterator>
+#include <vector>
+int main(int argc, char** argv)
+{
+	int bad = 0;
+	for (int i = 1; i < argc; ++i) {
+		std::ifstream f(argv[i], std::ios::binary);
+		std::vector<uint8_t> b((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+		vvm::ThawedScript s;
+		std::string err;
+		if (vvm::thaw_blob(b.data(), b.size(), s, err) != 0) { ++bad; continue; }
+		for (int mode = 0; mode < 3; ++mode) {
+			vvm::LinkedProgram lp;
+			int rc = vvm::link_program(s, mode == 1, lp, err, 0, mode == 2);
+			if (rc == 0)
+				for (uint32_t k = 1; k < lp.num_passes; ++k) { vvm::LinkedProgram more; vvm::link_program(s, mode == 1, more, err, k, false); }
+		}
+	}
+	printf("done, %d blobs did not thaw\n", bad);
+	return 0;
+}
