@@ -220,15 +220,37 @@ def main():
     # the library's own communicator: rank 0 draws the id, torch.distributed (already up for the barriers) carries it to the others
     comm, last_result, pending = None, [None], [0]
     if distributed and args.comm == "c-abi" and args.backend == "nccl":
-        try:
-            id_t = torch.zeros(128, dtype=torch.uint8, device=dev)
-            if rank == 0:
+        # every rank takes part in both collectives below whatever happens on it, so that a rank without the library's
+        # communicator cannot leave the others waiting in one of them
+        id_t = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            try:
                 id_t.copy_(torch.frombuffer(bytearray(be.comm_unique_id()), dtype=torch.uint8))
-            dist.broadcast(id_t, 0)
-            comm = be.comm_create_rccl(rank, world, bytes(id_t.cpu().numpy().tobytes()))
-        except Exception as e:      # noqa: BLE001  (no RCCL to load, or the communicator could not be set up: the torch path still measures the step)
-            sys.stderr.write("rank %d: library communicator unavailable (%s); the exchange stays in torch.distributed\n" % (rank, e))
-            comm = None
+            except Exception as e:      # noqa: BLE001  (no RCCL to load: the id stays zero, which every rank reads as "no communicator")
+                sys.stderr.write("rank 0: no RCCL id (%s); the exchange stays in torch.distributed\n" % e)
+        dist.broadcast(id_t, 0)
+        id_bytes = bytes(id_t.cpu().numpy().tobytes())
+        if any(id_bytes):
+            # the communicator is set up on a thread of its own: if that does not return in two minutes the bench goes on with
+            # torch.distributed instead of hanging (the thread is left behind)
+            import threading
+            made, failure = [None], [None]
+
+            def create():
+                try:
+                    torch.cuda.set_device(dev)
+                    made[0] = be.comm_create_rccl(rank, world, id_bytes)
+                except Exception as e:      # noqa: BLE001
+                    failure[0] = e
+
+            t = threading.Thread(target=create, daemon=True)
+            t.start()
+            t.join(120.0)
+            if t.is_alive() or failure[0] is not None:
+                sys.stderr.write("rank %d: library communicator unavailable (%s); the exchange stays in torch.distributed\n"
+                                 % (rank, "no answer from ncclCommInitRank in 120 s" if t.is_alive() else failure[0]))
+            else:
+                comm = made[0]
         ok = torch.tensor([1 if comm else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0 and comm:
