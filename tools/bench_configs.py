@@ -122,6 +122,7 @@ def main():
         w.constants = struct.pack("<6f", 1.0 / 60.0, 0.0, 0.0, -980.0, 0.98, 1.0) + bytes(8)
         n = 64 * 1024 * 1024
         run_single("fountain with six outputs, 64Mi", w, scripts.fountain_streams_torch(0, n, dev, pad=PAD), 6, n)
+        run_single("fountain with six outputs, 64Mi, 50% death", w, scripts.fountain_streams_torch(0, n, dev, kill_half=True, pad=PAD), 6, n)
     if "two_datasets" in which:
         # the fountain update with a second dataset that receives the particles that die this tick (position and age): both
         # datasets' programs read all eight streams
