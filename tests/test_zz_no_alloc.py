@@ -81,3 +81,35 @@ def test_no_alloc_entry_point_refuses_what_does_not_fit():
     finally:
         st.close()
         s.free()
+
+
+def test_no_alloc_entry_point_with_two_datasets_in_one_pass():
+    """A script that acquires two datasets (two chains, each with look-back words of its own in the scratch array) through both entry
+    points: same counts and streams for both datasets."""
+    import dataset_cases
+    be = abi.load_hip_backend()
+    blob = dataset_cases.two_dataset_script().blob
+    consts = dataset_cases.constants(0.5, 0.7)
+    st_ref, st_new = VectorVMState(blob, be), VectorVMState(blob, be)
+    held = []
+    try:
+        assert st_new.info().Flags & 0x40000
+        for n in (300_000, 9_001):
+            rng = np.random.default_rng(n)
+            host = [rng.random(n).astype(f32), rng.random(n).astype(f32)]
+            a, b = _Streams(be, host, n, outs=4), _Streams(be, host, n, outs=4)
+            held += [a, b]
+            frames = []
+            for st, s in ((st_ref, a), (st_new, b)):
+                frames.append(st.frame([abi.DataSet(s.ins, s.outs[:2], 0), abi.DataSet([], s.outs[2:], 0, [0, 0, 0], [0, 1, 2])], n, [consts]))
+            be.exec_ex(frames[0], abi.ExecOptions(0, 0, 0, None, 0))
+            be.exec_noalloc(frames[1], abi.ExecOptions(0, 0, 0, None, 0))
+            assert frames[0].survivors(0) == frames[1].survivors(0) == int((host[0] < f32(0.5)).sum())
+            assert frames[0].survivors(1) == frames[1].survivors(1) == int((host[1] > f32(0.7)).sum())
+            for k in range(4):
+                assert np.array_equal(b.download(k), a.download(k)), "n = %d, stream %d" % (n, k)
+    finally:
+        st_ref.close()
+        st_new.close()
+        for s in held:
+            s.free()
