@@ -224,6 +224,9 @@ enum {
 	VVM_EXEC_SEPARATE_PASSES = 1u << 5
 };
 #define VVM_EIGHT_WIDE_MIN_INSTANCES (256 * 1024)
+/* ... and inside vvm_exec_batch / vvm_batch_exec, where the launch is shared, a member whose script fits the light eight-wide
+ * kernel (eight per-lane registers; bit 0x20000 of vvm_state_info's Flags) runs eight-wide from this size on */
+#define VVM_BATCH_LIGHT_MIN_INSTANCES (8 * 1024)
 
 /* ---- entry points ---- */
 

@@ -247,6 +247,7 @@ struct PreparedExec {
 	uint32_t chunk_instances = 0, num_chunks = 0;      // the reference's chunking of this Exec
 	uint32_t instances_per_lane = 4;                   // of the kernel this Exec runs on (8, 4 or 1)
 	bool light = false;                                // ... the light eight-wide kernel
+	bool in_batch = false;                             // set by the caller: the Exec is a member of a batch (decides the kernel of small Execs, see prepare)
 	uint32_t id_buffers = 0;                           // which piece of the state's update_id buffers this pass works in (fused passes run together)
 	// what vvm_launch_exec_kernel takes as many_registers (a program with two chains runs four-wide on the kernel with 32 registers: it has the second chain)
 	bool launch_many() const { return light || lp->many_registers || (lp->num_chains > 1 && instances_per_lane == 4); }
@@ -346,10 +347,15 @@ int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, P
 		const bool can = pe.lp->instances_per_lane == 4 && !pe.lp->full_kernel && !pe.lp->many_registers && !(flags & VVM_EXEC_NO_EIGHT_WIDE);
 		// (the size of the Exec itself decides, also inside a batch: many small Execs measured faster four wide, 0.88 ms against
 		// 0.92 ms for 4096 Execs of 16 Ki instances)
-		if (can && (ctx->NumInstances >= VVM_EIGHT_WIDE_MIN_INSTANCES || (flags & VVM_EXEC_FORCE_EIGHT_WIDE))) {
+		// scripts that get by with eight registers have a program for the light eight-wide kernel (three workgroups per CU)
+		const bool light_ok = can && st->light_ready && pass == 0 && !narrow && !(flags & VVM_EXEC_NO_LIGHT_KERNEL);
+		// (a member of a batch shares its launch with the other members, so the light kernel pays off from a few tiles on: 4096
+		// emitters of 16 Ki instances, all fit for it, 0.735 ms against 0.904 ms four-wide; a single Exec of that size takes the
+		// same 13.5 us on either)
+		const bool big = ctx->NumInstances >= VVM_EIGHT_WIDE_MIN_INSTANCES || (pe.in_batch && light_ok && ctx->NumInstances >= VVM_BATCH_LIGHT_MIN_INSTANCES);
+		if (can && (big || (flags & VVM_EXEC_FORCE_EIGHT_WIDE))) {
 			pe.instances_per_lane = 8;
-			// scripts that get by with eight registers have a program for the light eight-wide kernel (three workgroups per CU)
-			if (st->light_ready && pass == 0 && !narrow && !(flags & VVM_EXEC_NO_LIGHT_KERNEL)) { pe.lp = &st->light; pe.d_code = st->d_code_light; pe.light = true; }
+			if (light_ok) { pe.lp = &st->light; pe.d_code = st->d_code_light; pe.light = true; }
 		}
 	}
 	const uint32_t tile = VVM_BLOCK_THREADS * pe.instances_per_lane;
@@ -1082,6 +1088,7 @@ int batch_plan(BatchWorkspace& ws, vvm_exec_context* ctxs, int n, const vvm_exec
 			if (st->device != ws.device) return fail(VVM_E_INVALID_ARG, "a state of the batch was allocated on another device than the one that is current");
 			if (st->batch_stamp == stamp) return fail(VVM_E_INVALID_ARG, "a state appears twice in one batch (one Exec at a time per state)");
 			st->batch_stamp = stamp;
+			plan.pes[(size_t)i].in_batch = true;
 			int rc = prepare(st, &ctxs[i], opts ? &opts[i] : nullptr, plan.pes[(size_t)i]);
 			if (rc != VVM_OK) return rc;
 			const vvm::LinkedProgram& lp = *plan.pes[(size_t)i].lp;
@@ -1394,6 +1401,7 @@ VVM_API int vvm_batch_exec(vvm_batch* b, uint32_t changed)
 			any = true;
 			if (plan.single[(size_t)i]) { b->last_instances[(size_t)i] = b->ctxs[i].NumInstances; continue; }
 			PreparedExec pe;
+			pe.in_batch = true;
 			rc = prepare(b->ctxs[i].VVMState, &b->ctxs[i], opts ? &opts[i] : nullptr, pe);
 			if (rc != VVM_OK) return rc;
 			if (kernel_key(pe) != kernel_key(plan.pes[(size_t)i]) || pe.bytes != plan.pes[(size_t)i].bytes) replan = true;

@@ -97,8 +97,8 @@ def test_a_batch_kept_over_ticks():
             em.set_constants(c.tobytes())
         tick(abi.VVM_BATCH_CHANGED_CONSTANTS, "constants")
         # one emitter grows past the eight-wide threshold, another one shrinks below it: the batch is planned again
-        ems[7].n, ems[6].n = 290_000, 100_000
-        arr[7].NumInstances, arr[6].NumInstances = 290_000, 100_000
+        ems[7].n, ems[6].n = 290_000, 5_000          # (in a batch, scripts that fit the light kernel run eight-wide from 8 Ki instances on)
+        arr[7].NumInstances, arr[6].NumInstances = 290_000, 5_000
         tick(abi.VVM_BATCH_CHANGED_INSTANCES, "kernel change")
         assert ems[7].state.last_exec_width() == 8 and ems[6].state.last_exec_width() == 4
         # new output streams

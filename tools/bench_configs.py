@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--no-light", action="store_true", help="keep eight-wide Execs on the general kernel")
     ap.add_argument("--separate-passes", action="store_true", help="two_datasets: one launch per dataset instead of one launch for both")
+    ap.add_argument("--batch-variants", type=int, default=64, help="bytecode variants of the batch (the first 16 all fit the light kernel)")
     ap.add_argument("--batch-flags", type=int, default=0, help="vvm_exec_options.Flags of every member of the batch (4: force eight instances per lane)")
     args = ap.parse_args()
     import torch
@@ -215,7 +216,7 @@ def main():
         ins = scripts.fountain_streams_torch(0, total, dev, kill_half=True, pad=PAD)
         outs = [torch.zeros(total + PAD, dtype=torch.float32, device=dev) for _ in range(8)]
         torch.cuda.synchronize()
-        workloads = [scripts.fountain(variant=v) for v in range(64)]
+        workloads = [scripts.fountain(variant=v % args.batch_variants) for v in range(64)]
         states, frames, opts = [], [], []
         for e in range(emitters):
             w = workloads[e % 64]
