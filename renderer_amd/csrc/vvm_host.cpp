@@ -362,7 +362,7 @@ int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, P
 	pe.tiles = ((uint32_t)ctx->NumInstances + tile - 1) / tile;
 	const uint32_t O = std::max<uint32_t>(s.num_outputs_remapped, s.num_output_instructions);
 	pe.off_consts = align_up(sizeof(VvmExecDesc), 16);
-	pe.off_in = align_up(pe.off_consts + 4u * (size_t)s.num_consts, 16);     // (so the table is padded to a multiple of 4 dwords)
+	pe.off_in = align_up(pe.off_consts + 4u * ((size_t)s.num_consts + pe.lp->derived.size()), 16);     // (so the table is padded to a multiple of 4 dwords)
 	pe.off_load = align_up(pe.off_in + 8u * (size_t)s.num_inputs, 64);
 	pe.off_out = align_up(pe.off_load + 8u * pe.lp->load_list.size(), 64) + 64;      // (the entry before the list is in use too)
 	pe.off_ids = align_up(pe.off_out + 8u * align_up(pe.lp->out_list.size(), VVM_STAGE_SLOTS), 16);
@@ -398,7 +398,9 @@ int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, P
 
 // The script's remapped constants, one dword each, from the call's constant tables (VectorVMRuntime.cpp:2204-2207; the kernel
 // broadcasts them).
-int fill_constants(vvm_state* st, const vvm_exec_context* ctx, uint32_t* consts)
+// Behind them the program's derived constants (LinkedProgram::derived): sums, differences and products of constants, computed here
+// in the arithmetic the kernel would use per instance (IEEE single precision, unfused; 32-bit wrap-around for the integer ops).
+int fill_constants(vvm_state* st, const vvm_exec_context* ctx, uint32_t* consts, const vvm::LinkedProgram& lp)
 {
 	const vvm::ThawedScript& s = st->script;
 	for (uint32_t i = 0; i < s.num_consts; ++i) {
@@ -407,6 +409,23 @@ int fill_constants(vvm_state* st, const vvm_exec_context* ctx, uint32_t* consts)
 			return fail(VVM_E_INVALID_ARG, "a constant the script reads lies outside the constant tables of this call");
 		const uint8_t* table = ctx->ConstantTableData[st->const_table[i]];
 		memcpy(&consts[i], table + 4u * (size_t)st->const_dword[i], 4);
+	}
+	for (size_t j = 0; j < lp.derived.size(); ++j) {
+		const vvm::LinkedProgram::Derived& d = lp.derived[j];
+		const uint32_t ua = consts[d.a], ub = consts[d.b];
+		volatile float fa, fb;      // (volatile: the operation is done at run time, in single precision, as written)
+		memcpy((void*)&fa, &ua, 4); memcpy((void*)&fb, &ub, 4);
+		uint32_t r = 0;
+		float fr = 0.0f;
+		switch (d.op) {
+		case VVM_OP_add: fr = fa + fb; memcpy(&r, &fr, 4); break;
+		case VVM_OP_sub: fr = fa - fb; memcpy(&r, &fr, 4); break;
+		case VVM_OP_mul: fr = fa * fb; memcpy(&r, &fr, 4); break;
+		case VVM_OP_addi: r = ua + ub; break;
+		case VVM_OP_subi: r = ua - ub; break;
+		default: r = ua * ub; break;      // muli
+		}
+		consts[s.num_consts + j] = r;
 	}
 	return VVM_OK;
 }
@@ -439,12 +458,12 @@ int fill_params(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* op
 	d->rand_seed_hi = opt ? (uint32_t)(opt->RandSeed >> 32) : 0;
 	d->rand_instance_base = opt ? opt->RandInstanceBase : 0;
 	d->flags = (lp.uses_perlin ? VVM_DESC_USES_PERLIN : 0) | (dev_block ? 0 : VVM_DESC_RELATIVE);
-	d->num_unif = std::min<uint32_t>((s.num_consts + 3u) & ~3u, VVM_MAX_UNIFORMS);
+	d->num_unif = std::min<uint32_t>((s.num_consts + (uint32_t)lp.derived.size() + 3u) & ~3u, VVM_MAX_UNIFORMS);
 
 	uint32_t* consts = (uint32_t*)(host + pe.off_consts);
 	memset(consts, 0, pe.off_in - pe.off_consts);
 	{
-		const int crc = fill_constants(st, ctx, consts);
+		const int crc = fill_constants(st, ctx, consts, lp);
 		if (crc != VVM_OK) return crc;
 	}
 	uint64_t* in_ptrs = (uint64_t*)(host + pe.off_in);                                                  // RT.cpp:366-416
@@ -1441,7 +1460,7 @@ VVM_API int vvm_batch_exec(vvm_batch* b, uint32_t changed)
 	} else if (changed & VVM_BATCH_CHANGED_CONSTANTS) {
 		for (int i = 0; i < plan.n; ++i) {
 			if (plan.single[(size_t)i]) continue;
-			rc = fill_constants(b->ctxs[i].VVMState, &b->ctxs[i], (uint32_t*)(ws.host + plan.const_off[(size_t)i]));
+			rc = fill_constants(b->ctxs[i].VVMState, &b->ctxs[i], (uint32_t*)(ws.host + plan.const_off[(size_t)i]), *plan.pes[(size_t)i].lp);
 			if (rc != VVM_OK) return rc;
 		}
 		upload = std::max(upload, plan.slices[0].head_bytes);

@@ -433,6 +433,38 @@ static int link_program_as(const ThawedScript& s, bool force_narrow, LinkedProgr
 			touch(r);
 		}
 	}
+	// Derived constants (see LinkedProgram::derived): registers [out0 + O, ...) stand for them in the decoded instructions from
+	// here on.  A register holds a derived constant from the folded instruction that wrote it to the next write of the register.
+	const uint32_t derived0 = out0 + O;
+	if (!getenv("VVM_NO_CONSTANT_FOLDING")) {
+		std::vector<int32_t> holds_derived((size_t)out0 + O, -1);
+		auto is_value_reg = [&](uint16_t r) { return r != VVM_INVALID_REG && (r < T || (r >= out0 && r < out0 + O)); };
+		auto uniform_index = [&](uint16_t r) -> int32_t {      // the uniform a register operand names, or -1
+			if (r == VVM_INVALID_REG) return -1;
+			if (r >= T && r < T + C) return (int32_t)(r - T);
+			if (r >= derived0) return (int32_t)(C + (r - derived0));
+			return -1;
+		};
+		for (size_t k = 0; k < ins.size(); ++k) {
+			Decoded& d = ins[k];
+			auto rewrite = [&](uint16_t& r) { if (is_value_reg(r) && holds_derived[r] >= 0) r = (uint16_t)(derived0 + (uint32_t)holds_derived[r]); };
+			for (uint16_t& r : d.in) rewrite(r);
+			for (auto& pr : d.pairs) rewrite(pr.first);
+			bool folded = false;
+			const bool foldable_op = d.op == VVM_OP_add || d.op == VVM_OP_sub || d.op == VVM_OP_mul || d.op == VVM_OP_addi || d.op == VVM_OP_subi || d.op == VVM_OP_muli;
+			if (d.kind == K_ORD && foldable_op && d.in.size() == 2 && d.out.size() == 1 && is_value_reg(d.out[0])) {
+				const int32_t a = uniform_index(d.in[0]), b = uniform_index(d.in[1]);
+				if (a >= 0 && b >= 0 && lp.derived.size() < 255 && derived0 + lp.derived.size() + 1 < VVM_INVALID_REG && C + lp.derived.size() + 1 <= VVM_MAX_OPND_INDEX) {
+					holds_derived[d.out[0]] = (int32_t)lp.derived.size();
+					lp.derived.push_back(LinkedProgram::Derived{d.op, (uint16_t)a, (uint16_t)b});
+					folded = true;
+				}
+			}
+			if (folded) { ins.erase(ins.begin() + (ptrdiff_t)k); --k; continue; }
+			for (uint16_t r : d.out) if (is_value_reg(r)) holds_derived[r] = -1;
+		}
+	}
+
 	// A device instruction has one destination, so the reference's multi-output instructions are split.  The reference reads
 	// all inputs before it writes any output (per 4 lanes); when more than one destination is also an input of the same
 	// instruction, all but the last of those are computed into scratch registers and copied afterwards.
@@ -488,7 +520,7 @@ static int link_program_as(const ThawedScript& s, bool force_narrow, LinkedProgr
 	std::vector<uint8_t> needed(ins.size(), 1);
 	{
 		std::vector<uint8_t> live((size_t)out0 + O, 0);
-		auto holds_value = [&](uint16_t r) { return r != VVM_INVALID_REG && (r < T || r >= out0); };
+		auto holds_value = [&](uint16_t r) { return r != VVM_INVALID_REG && (r < T || (r >= out0 && r < derived0)); };      // (not the derived constants)
 		heavy = false; uses_perlin = false;
 		for (size_t k = ins.size(); k-- > 0;) {
 			const Decoded& d = ins[k];
@@ -582,6 +614,10 @@ static int link_program_as(const ThawedScript& s, bool force_narrow, LinkedProgr
 			return VVM_OPND(lp.inputs[i].type == 2 ? VVM_OPC_NOADV_HALF : VVM_OPC_NOADV, i);
 		}
 		if (r < out0) return VVM_OPND(VVM_OPC_NONE, 0);   // input base copies: never operands
+		if (r >= derived0) {                              // a derived constant: the uniforms behind the script's constants
+			const uint32_t u = C + (r - derived0);
+			return (u < VVM_MAX_UNIFORMS) ? VVM_OPND(VVM_OPC_UNIF, u) : VVM_OPND(VVM_OPC_CONST, u);
+		}
 		return VVM_OPND(VVM_OPC_VREG, place[(size_t)out_vreg[r - out0]]);
 	};
 

@@ -60,6 +60,12 @@ struct LinkedProgram {
 	// one-instance-per-lane kernel is linked as ONE pass with two chains instead (num_passes = 1, num_chains = 2): both
 	// acquireindex run in it, each with its own keep mask, count and look-back words, and every output belongs to the chain of
 	// its dataset.  chain_dataset[c] = the dataset of chain c (chain 0 = pass_dataset); out_chain[k] = the chain of output-list entry k.
+	// Derived constants: an add / sub / mul (float or integer) whose operands are all constants of the script yields the same value
+	// for every instance; the linker takes such instructions out of the program and the host computes them when it fills an Exec's
+	// constants (the arithmetic is IEEE single precision / 32-bit wrap-around on both sides).  Uniform index num_consts + j names
+	// derived[j]; a and b are uniform indices (constants or earlier derived ones).
+	struct Derived { uint8_t op; uint16_t a, b; };
+	std::vector<Derived> derived;
 	uint32_t num_chains = 1;
 	uint32_t chain_dataset[2] = {0, 0};
 	std::vector<uint8_t> out_chain;

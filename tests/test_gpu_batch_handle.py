@@ -125,20 +125,20 @@ def test_a_batch_kept_over_ticks():
 def test_a_batch_of_eight_wide_emitters():
     """Every member forced onto the eight-wide kernels: the members whose scripts fit the light kernel share one launch, so a
     workgroup finishes one emitter's tile (its two outputs that wait in registers included) while it runs the next emitter's
-    first tile; the others share a launch of the general kernel.  All against the oracle, over two ticks."""
+    first tile; the members kept off it share a launch of the general kernel.  All against the oracle, over two ticks."""
     be = abi.load_hip_backend()
     sizes = [1, 2047, 2048, 2049, 4096, 6000, 10_000, 33_333, 70_001, 5, 3000, 12_289] * 3
     ems = [_Emitter(be, e, n) for e, n in enumerate(sizes)]
     handle = None
     try:
-        opts = [abi.ExecOptions(0, 0, 0, None, abi.VVM_EXEC_FORCE_EIGHT_WIDE) for _ in ems]
+        # (every third member is kept off the light kernel, so the batch has a launch of each eight-wide kernel)
+        opts = [abi.ExecOptions(0, 0, 0, None, abi.VVM_EXEC_FORCE_EIGHT_WIDE | (abi.VVM_EXEC_NO_LIGHT_KERNEL if i % 3 == 2 else 0)) for i in range(len(ems))]
         arr, oarr = be.pack_batch([em.frame for em in ems], opts)
         be.exec_batch_packed(arr, oarr)
         for i, em in enumerate(ems):
             em.check("plain batch, emitter %d" % i)
             assert em.state.last_exec_width() == 8
-        assert sum(1 for em in ems if em.state.info().Flags & 0x20000) >= 10      # (some on the light kernel, some not)
-        assert any(not (em.state.info().Flags & 0x20000) for em in ems)
+        assert all(em.state.info().Flags & 0x20000 for em in ems)      # (every variant of the script fits the light kernel)
         handle = be.batch_create(arr, oarr)
         for tick in range(2):
             for i, em in enumerate(ems):

@@ -209,3 +209,31 @@ def test_large_exec_takes_the_light_kernel_by_itself():
     assert info.Flags & LIGHT_PROGRAM and got_n == ref_n
     for k in range(6):
         assert np.array_equal(got[k][:got_n].view(np.uint32), ref[k][:ref_n].view(np.uint32))
+
+
+def test_arithmetic_on_constants_alone_is_left_to_the_host():
+    """tmp = dt * scale; age' = age + tmp: the product is the same for every instance, the linker takes it out of the program (the
+    script then fits eight registers) and the host computes it with the Exec's constants; also chained and integer forms, a derived
+    value that is output directly, and a temp that holds a per-instance value after it held a derived one."""
+    s = Script()
+    xs = [s.input(0, FLOAT, i) for i in range(8)]
+    c0, c1, c2 = s.const(0), s.const(1), s.const(2)
+    t = s.temp(); s.op("mul", c0, c1, t)                 # derived
+    u = s.temp(); s.op("add", t, c2, u)                  # derived from a derived one
+    k = s.temp(); s.op("muli", s.const(3), s.const(3), k)    # integer
+    keep = s.temp(); s.op("cmplt", xs[0], u, keep)
+    s.acquireindex(keep, 0)
+    a = s.temp(); s.op("mad", xs[1], t, u, a)
+    s.op("sub", xs[2], a, t)                             # the temp again, now per instance
+    b = s.temp(); s.op("add", t, xs[3], b)
+    s.output_data(FLOAT, 0, [(a, s.output(0, FLOAT, 0)), (b, s.output(0, FLOAT, 1)), (u, s.output(0, FLOAT, 2)), (t, s.output(0, FLOAT, 3))])
+    s.output_data(INT32, 0, [(k, s.output(0, INT32, 0))])
+    built = s.build()
+    n = 10_007
+    rng = np.random.default_rng(12)
+    ins = [rng.standard_normal(n).astype(f32) for _ in range(8)]
+    consts = struct.pack("<fffi", 0.3, 1.7, -0.25, 70000)
+    code = abi.load_hip_backend().inspect_code(built.blob, 0)
+    assert sum(1 for w in code if 0 < (w[0] & 0xFF) < 190) == 3      # mad, sub, add are left: the three constant-only instructions are gone
+    survivors = _both(built, [consts], ins, [f32] * 4 + [np.int32], n)
+    assert 0 < survivors < n
