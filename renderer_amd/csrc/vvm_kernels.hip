@@ -1052,6 +1052,7 @@ struct KernelEnv {
 	// tile one after the other, so that the streams the passes share come from memory once; total_tiles counts tiles, not
 	// tiles x passes, and every pass has its own look-back words.
 	uint32_t fused;
+	uint32_t run_shift;      // log2 of the run of adjacent tiles a ticket class works through (see the ticket draw)
 	// A single Exec's parameter block (descriptor and tables, VVM_DESC_RELATIVE) rides in the kernel-argument segment: no
 	// host-to-device copy ahead of the launch (a copy is a launch of its own on the stream, and cost more than half of the
 	// 13 us between two Execs).  The kernel never names this member; it reads the segment through scalar loads.
@@ -1640,13 +1641,13 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (IS_LIGHT(V, SPILL) ? 3 : V
 			const uint32_t s4 = st[4] + (uint32_t)((__builtin_amdgcn_s_memtime() - tk0) >> 4), s7 = st[7] + 1u;
 			st[4] = s4; st[7] = s7;
 		}
-#ifndef VVM_TILE_RUN
-#define VVM_TILE_RUN 2u
-#endif
 		// draw c of class k is tile (c / RUN) * RUN * classes + k * RUN + c % RUN: a class works through runs of RUN adjacent tiles
-		// (RUN = 1: tile c * classes + k); increasing in c, so the class is done at the first tile past the end.  Measured on the
-		// 64 Mi fountain Exec: RUN 1 0.770 ms, 2 0.758 ms, 4 0.760 ms, 8 0.762 ms, 16 0.771 ms
-		const uint32_t ticket = (draw / VVM_TILE_RUN) * (VVM_TILE_RUN * classes) + cls * VVM_TILE_RUN + (draw % VVM_TILE_RUN);
+		// (RUN = 1: tile c * classes + k); increasing in c, so the class is done at the first tile past the end.  RUN = 1 << run_shift
+		// comes with the launch: 2 when there are several rounds of tiles (measured on the 64 Mi fountain Exec: RUN 1 0.770 ms,
+		// 2 0.758 ms, 4 0.760 ms, 8 0.762 ms, 16 0.771 ms), 1 for small launches (with RUN 2 half of the workgroups would take
+		// two tiles each and the other half none)
+		const uint32_t rs = env.run_shift;
+		const uint32_t ticket = ((draw >> rs) * classes << rs) + (cls << rs) + (draw & ((1u << rs) - 1u));
 		if (ticket >= env.total_tiles) break;
 
 		// Both are re-read from the kernel-argument segment for every tile (one scalar load): kept across the tile they cost four
@@ -1779,6 +1780,7 @@ extern "C" int vvm_launch_exec_kernel(int instances_per_lane, const VvmExecDesc*
 	}
 	if (fused && (!full || !descs || instances_per_lane == 8)) return (int)hipErrorInvalidValue;      // (the FULL kernels run fused passes)
 	env.descs = descs; env.num_execs = num_execs; env.total_tiles = total_tiles; env.ls = ls; env.lds_spill_slots = lds_spill_slots; env.tag = tag; env.fused = fused ? 1u : 0u;
+	env.run_shift = (total_tiles >= 4u * grid) ? 1u : 0u;
 	{ const char* dbg = getenv("VVM_DEBUG_SKIP"); env.debug_skip = dbg ? (uint32_t)strtoul(dbg, nullptr, 0) : 0u; }
 	const size_t lds_bytes = (instances_per_lane == 8 ? LDS_SPILL_OFF(8, full != 0, light) : instances_per_lane == 4 ? LDS_SPILL_OFF(4, full != 0, false) : LDS_SPILL_OFF(1, full != 0, false)) +
 	                         (size_t)lds_spill_slots * VVM_BLOCK_THREADS * 4u * (size_t)instances_per_lane;
