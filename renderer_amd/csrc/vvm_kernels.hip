@@ -1621,7 +1621,11 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (IS_LIGHT(V, SPILL) ? 3 : V
 	if (wave == 0) lds_ctrl[LC_STATS + (lane & 7u)] = 0;
 	// A tile is claimed when the workgroup is ready to start it, never ahead of time: the look-back of a tile waits for the
 	// counts of all earlier tiles, so a tile that is claimed but not yet running stalls every later one.
+	uint32_t next_floor = 0;      // no draw of this workgroup's class can yield a tile below this one any more
 	for (uint32_t phase = 0;; ++phase) {
+		// (a class hands out increasing tiles: when even its next draw lies past the end, the draw and its round trip are left
+		// out; a launch with one round of tiles ends 1.5 us sooner)
+		if (next_floor >= env.total_tiles) break;
 		const u64 tk0 = (dbgw & 128u) ? __builtin_amdgcn_s_memtime() : 0;
 		uint32_t* slot = lds_ctrl + LC_TICKET + (phase & 1u);
 		// Wave 0 draws the ticket and, in the shadow of that round trip, issues the first look-back poll for the tile the
@@ -1649,6 +1653,7 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (IS_LIGHT(V, SPILL) ? 3 : V
 		const uint32_t rs = env.run_shift;
 		const uint32_t ticket = ((draw >> rs) * classes << rs) + (cls << rs) + (draw & ((1u << rs) - 1u));
 		if (ticket >= env.total_tiles) break;
+		next_floor = (((draw + 1u) >> rs) * classes << rs) + (cls << rs) + ((draw + 1u) & ((1u << rs) - 1u));
 
 		// Both are re-read from the kernel-argument segment for every tile (one scalar load): kept across the tile they cost four
 		// scalar registers that the four-wide kernel does not have to spare (1.7 % on the half-dying workload).
