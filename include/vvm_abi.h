@@ -218,9 +218,11 @@ enum {
 	 * file, of which three workgroups fit a CU instead of two.  This flag keeps them on the general eight-wide kernel (tests /
 	 * comparison).  The results are the same either way. */
 	VVM_EXEC_NO_LIGHT_KERNEL = 1u << 4,
-	/* A script that runs acquireindex for several datasets is executed as one pass per dataset; the passes normally go out as one
-	 * launch that runs all of them on a tile of instances before it moves on (the streams they share are read from memory
-	 * once).  This flag launches the passes one after the other instead (tests / comparison).  The results are the same. */
+	/* A script that runs acquireindex for two datasets normally runs both in one pass of the kernel.  Where that form does not
+	 * apply (more datasets; transcendental, noise or ID instructions beside them; the one-instance-per-lane kernel) the script is
+	 * executed as one program per dataset (a pass), and passes that run four or one instance per lane go out as one launch that
+	 * runs all of them on a tile of instances before it moves on.  This flag launches the passes one after the other instead
+	 * (tests / comparison).  The results are the same. */
 	VVM_EXEC_SEPARATE_PASSES = 1u << 5
 };
 #define VVM_EIGHT_WIDE_MIN_INSTANCES (256 * 1024)
