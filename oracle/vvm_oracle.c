@@ -554,7 +554,10 @@ static inline float p_lerp(float a, float b, float t) { return a + t * (b - a); 
 static float perlin3(float px, float py, float pz)               /* UnrealMath.cpp:3658-3699 */
 {
 	float xf = floorf(px), yf = floorf(py), zf = floorf(pz);
-	int xi = (int)xf & 255, yi = (int)yf & 255, zi = (int)zf & 255;
+	/* (int32)floor & 255, :3665-3667: the cast is the truncating SSE conversion on the reference's x86 targets, which gives
+	 * 0x80000000 (cell 0) for NaN and for a coordinate outside the int32 range; taken explicitly here, a plain C cast of such
+	 * a value being undefined */
+	int xi = _mm_cvttss_si32(_mm_set_ss(xf)) & 255, yi = _mm_cvttss_si32(_mm_set_ss(yf)) & 255, zi = _mm_cvttss_si32(_mm_set_ss(zf)) & 255;
 	float x = px - xf, y = py - yf, z = pz - zf;
 	float xm = x - 1.0f, ym = y - 1.0f, zm = z - 1.0f;
 	const int32_t* P = k_perlin_perm;

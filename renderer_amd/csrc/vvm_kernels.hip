@@ -436,7 +436,11 @@ __device__ __noinline__ float perlin3(float px, float py, float pz)             
 {
 	const lds_u8p P = PERLIN_LDS;
 	const float xf = floorf(px), yf = floorf(py), zf = floorf(pz);
-	const int xi = (int)xf & 255, yi = (int)yf & 255, zi = (int)zf & 255;
+	// (int32)floor & 255 as the reference's cast comes out on x86 (:3665-3667): 0x80000000 for NaN and for what does not fit, so
+	// the cell index of such a coordinate is 0.  The device's conversion saturates instead: it agrees except above the range, where
+	// it yields 0x7FFFFFFF (no float below 2^31 converts to that value, the nearest is 2147483520)
+	const int qx = (int)xf, qy = (int)yf, qz = (int)zf;
+	const int xi = qx == 0x7FFFFFFF ? 0 : qx & 255, yi = qy == 0x7FFFFFFF ? 0 : qy & 255, zi = qz == 0x7FFFFFFF ? 0 : qz & 255;
 	const float x = px - xf, y = py - yf, z = pz - zf;
 	const float xm = x - 1.0f, ym = y - 1.0f, zm = z - 1.0f;
 	const int a = P[xi] + yi, aa = P[a] + zi, ab = P[a + 1] + zi;

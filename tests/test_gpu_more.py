@@ -127,6 +127,34 @@ def test_perlin_builtin():
     assert ulp_diff(got[0][:n], ref[0][:n]).max() <= 2
 
 
+def test_perlin_builtin_on_coordinates_outside_the_int32_range():
+    """The cell index is (int32)floor(p) & 255 with the x86 cast (UnrealMath.cpp:3665-3667): NaN and what does not fit land in
+    cell 0.  The device's own conversion saturates, which would pick cell 255 above the range."""
+    s = Script()
+    s.acquireindex(s.const(0), 0)
+    x = [s.input(0, FLOAT, i) for i in range(3)]
+    t = s.temp()
+    f = s.ext_fn(3, 1)
+    s.call(f, x, [t])
+    s.output_data(FLOAT, 0, [(t, s.output(0, FLOAT, 0))])
+    built = s.build()
+    special = np.array([3e9, -3e9, 1e30, -1e30, np.inf, -np.inf, np.nan, 2147483520.0, 2147483648.0, -2147483648.0, -2147483904.0,
+                        4294967296.0, 1e10, 2.5e9, 16777216.0, -16777217.0], f32)
+    n = 3 * len(special) * 64
+    rng = np.random.default_rng(11)
+    ins = [(rng.standard_normal(n) * 40).astype(f32) for _ in range(3)]
+    for axis in range(3):                                                 # every special value on every axis, the others ordinary
+        for k, v in enumerate(special):
+            ins[axis][(axis * len(special) + k) * 64:(axis * len(special) + k + 1) * 64:2] = v
+    ins[0][1::7] = special[np.arange(len(ins[0][1::7])) % len(special)]    # and mixed on several axes at once
+    ins[1][1::7] = special[(np.arange(len(ins[1][1::7])) * 5 + 3) % len(special)]
+    ref, _, _ = run_oracle(built, [ALL_ONES], ins, [f32], n, ext_fns=[abi.VVM_EXTFN_PERLIN3])
+    got, got_n, _ = run_hip(built, [ALL_ONES], ins, [f32], n, ext_fns=[abi.VVM_EXTFN_PERLIN3])
+    assert got_n == n
+    assert np.array_equal(np.isnan(got[0][:n]), np.isnan(ref[0][:n]))
+    assert ulp_diff(got[0][:n], ref[0][:n]).max() <= 2
+
+
 def test_host_callback_is_refused_by_the_gpu_executor():
     w = scripts.transcendental(True)
     n = 16
