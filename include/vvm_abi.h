@@ -201,6 +201,17 @@ typedef struct vvm_exec_options {
 	                             * dataset it runs acquireindex for, instead of the state's own words (vvm_state_device_counts). For
 	                             * callers that hand the counts on device-side (the multi-GPU all-gather) without a copy in between.
 	                             * Ignored for scripts with ID instructions and by vvm_exec_batch. */
+	const uint32_t* RandXorwowState; /* host memory, 24 words, or NULL.  Not NULL: random / randomi / random_add / random_2x draw from the
+	                             * reference's own generator (the four-lane xorwow of VectorVMRuntime.cpp:468-483, stepped once per draw
+	                             * and loop in the reference's execution order: chunk by chunk, instruction by instruction), started
+	                             * from this state instead of the cycle-counter seed of :445-466, which no caller can reproduce:
+	                             * State[0][lane 0..3] .. State[4][lane 0..3], then Counters[lane 0..3] (FVectorVMBatchState::RandState;
+	                             * vvm_xorwow_seed derives it the way the reference does).  The output then depends on the instance's
+	                             * place in the Exec and on vm.PageSizeInKB (vvm_set_page_size_kb), as in the reference; RandSeed and
+	                             * RandInstanceBase are not used.  The draws are laid out by a kernel of their own ahead of the Exec
+	                             * (4 bytes of device memory per draw and instance, held by the state) and the Exec runs four
+	                             * instances per lane or one.  Refused (VVM_E_UNSUPPORTED_OP): vvm_exec_noalloc, vvm_exec_batch /
+	                             * vvm_batch_*, scripts that acquire two datasets in one pass (set VVM_NO_CHAINS in the environment). */
 } vvm_exec_options;
 
 enum {
@@ -245,6 +256,10 @@ VVM_API void vvm_free_state(vvm_state* state);
  * One Exec at a time per state (the reference mutates its state the same way). */
 VVM_API int vvm_exec(vvm_exec_context* ctx);
 VVM_API int vvm_exec_ex(vvm_exec_context* ctx, const vvm_exec_options* opt);
+
+/* SetupRandStateForBatch (VectorVMRuntime.cpp:445-464) with its three sources of entropy as arguments: the two readings of the
+ * cycle counter (:447, :449) and the address of the batch state (:448).  Fills the 24 words vvm_exec_options.RandXorwowState takes. */
+VVM_API void vvm_xorwow_seed(uint64_t cycles_first, uint64_t cycles_second, uint64_t batch_state_address, uint32_t* state24);
 
 /* Enqueue-only form of vvm_exec_ex and its completion. Between the two calls the context, its dataset
  * array and the state must stay alive and untouched. vvm_exec_finish blocks on the stream, then writes

@@ -36,7 +36,10 @@
  *   - random ops: the reference seeds a 4-lane xorwow from the CPU cycle counter
  *     (VectorVMRuntime.cpp:445-483), so it has no reproducible output.  Here they use a counter-based
  *     generator keyed by (seed, instance index, ordinal of the random op in the script); the
- *     bits -> float mapping is the reference's (VectorVMRuntime.cpp:955).
+ *     bits -> float mapping is the reference's (VectorVMRuntime.cpp:955).  vvm_oracle_set_xorwow() switches to
+ *     the reference's own generator (the step of :468-483, advanced once per loop and draw in execution order:
+ *     chunk by chunk, instruction by instruction) started from a state the caller injects in place of the
+ *     cycle-counter seed; vvm_oracle_xorwow_seed() restates the seeding of :445-464 for three given numbers.
  *   - randomi writes its OUTPUT register with f2i(random(i2f(a))); the reference stores to the input
  *     register and never writes the output (VectorVMRuntime.cpp:1032, 1040).
  *   - exec_index* in a one-loop chunk returns StartInstance + lane; the reference returns 0..3 there
@@ -91,12 +94,41 @@ static int      g_page_kb = 64;           /* cvar vm.PageSizeInKB, VectorVMRunti
 static uint64_t g_rand_seed = 0;
 static int32_t  g_exec_index_base = 0;
 static int32_t  g_rand_instance_base = 0;
+static int      g_xorwow = 0;             /* random ops draw from the reference's xorwow, started from g_xorwow_start at every Exec */
+static uint32_t g_xorwow_start[24];       /* State[0..4] (four lanes each), then Counters (four lanes): FVectorVMBatchState::RandState */
 
 ORACLE_API void vvm_oracle_set_strict(int s) { g_strict = s; }
 ORACLE_API void vvm_oracle_set_page_kb(int kb) { g_page_kb = kb > 0 ? kb : 64; }
 ORACLE_API void vvm_oracle_set_options(uint64_t seed, int32_t exec_index_base, int32_t rand_instance_base)
 {
 	g_rand_seed = seed; g_exec_index_base = exec_index_base; g_rand_instance_base = rand_instance_base;
+}
+
+/* state24 = State[0][0..3] ... State[4][0..3], Counters[0..3]; NULL switches back to the counter-based generator */
+ORACLE_API void vvm_oracle_set_xorwow(const uint32_t* state24)
+{
+	g_xorwow = state24 != NULL;
+	if (state24) memcpy(g_xorwow_start, state24, sizeof g_xorwow_start);
+}
+
+/* SetupRandStateForBatch, VectorVMRuntime.cpp:445-464, with its three sources of entropy as arguments: the two readings of the
+ * cycle counter (:447, :449) and the address of the batch state (:448). */
+ORACLE_API void vvm_oracle_xorwow_seed(uint64_t cycles_first, uint64_t cycles_second, uint64_t batch_state_address, uint32_t* state24)
+{
+	uint64_t pcg_state = cycles_first;
+	uint64_t pcg_inc = ((batch_state_address << 32) ^ 0xCAFEF00DD15EA5E5ull) | 1;
+	pcg_state ^= cycles_second << 32;
+	for (int i = 0; i < 5; ++i)
+		for (int j = 0; j < 4; ++j) {
+			uint64_t old_state = pcg_state;
+			pcg_state = old_state * 6364136223846793005ull + pcg_inc;
+			uint32_t xor_shifted = (uint32_t)(((old_state >> 18) ^ old_state) >> 27);
+			uint32_t rot = (uint32_t)(old_state >> 59);
+			state24[4 * i + j] = (xor_shifted >> rot) | (xor_shifted << ((0u - rot) & 31));
+		}
+	/* MakeVectorRegisterInt64(pcg_inc, pcg_state), :464: two 64-bit lanes = four 32-bit counters, low half first */
+	state24[20] = (uint32_t)pcg_inc;   state24[21] = (uint32_t)(pcg_inc >> 32);
+	state24[22] = (uint32_t)pcg_state; state24[23] = (uint32_t)(pcg_state >> 32);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -526,11 +558,28 @@ static inline uint32_t rand_u32(uint64_t seed, uint32_t instance, uint32_t ordin
 	h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
 	return h;
 }
-static inline __m128 rand4(uint32_t first_instance, uint32_t ordinal, __m128 a)    /* value mapping: RT.cpp:953-956 */
+/* VVMXorwowStep, VectorVMRuntime.cpp:468-483: four independent generators side by side, one per lane */
+static inline __m128i xorwow_step(__m128i* st /* State[0..4], Counters */)
 {
-	uint32_t r[4];
-	for (int i = 0; i < 4; ++i) r[i] = (rand_u32(g_rand_seed, first_instance + (uint32_t)i, ordinal) >> 9) | 0x3F800000u;
-	__m128 f = cf(_mm_loadu_si128((__m128i*)r));
+	__m128i t = st[4], s = st[0];
+	st[4] = st[3]; st[3] = st[2]; st[2] = st[1]; st[1] = s;
+	t = _mm_xor_si128(t, _mm_srli_epi32(t, 2));
+	t = _mm_xor_si128(t, _mm_slli_epi32(t, 1));
+	t = _mm_xor_si128(t, _mm_xor_si128(s, _mm_xor_si128(s, _mm_slli_epi32(s, 4))));     /* as written at :478: s cancels, s << 4 remains */
+	st[0] = t;
+	st[5] = _mm_add_epi32(st[5], _mm_set1_epi32(362437));
+	return _mm_add_epi32(t, st[5]);
+}
+static inline __m128 rand4(__m128i* xorwow, uint32_t first_instance, uint32_t ordinal, __m128 a)    /* value mapping: RT.cpp:953-956 */
+{
+	__m128i bits;
+	if (g_xorwow) bits = xorwow_step(xorwow);
+	else {
+		uint32_t r[4];
+		for (int i = 0; i < 4; ++i) r[i] = rand_u32(g_rand_seed, first_instance + (uint32_t)i, ordinal);
+		bits = _mm_loadu_si128((__m128i*)r);
+	}
+	__m128 f = cf(_mm_or_si128(_mm_srli_epi32(bits, 9), _mm_set1_epi32(0x3F800000)));
 	return _mm_mul_ps(_mm_sub_ps(f, set1(1.f)), a);
 }
 
@@ -636,6 +685,7 @@ typedef struct batch_state {
 	uint8_t*  ext_reg_inc;
 	__m128i*  dummy_regs;
 	int32_t*  rand_counters;
+	__m128i   xorwow[6];              /* FVectorVMBatchState::RandState: State[0..4], Counters */
 	int start_instance, num_instances, chunk_idx;
 	uint32_t max_loops;
 } batch_state;
@@ -1166,20 +1216,20 @@ static void exec_chunk(oracle_state* s, vvm_exec_context* ctx, batch_state* b, i
 			ip += 6; break; }
 		case VVM_OP_random: {   /* VectorVMRuntime.cpp:990-1016 */
 			uint8_t *p0 = RP(0), *d0 = RP(1); int i0 = RI(0);
-			for (int l = 0; l < loops; ++l) { STF(d0, rand4(inst0 + 4u * (uint32_t)l, rand_ordinal, LDF(p0))); p0 += i0; d0 += 16; }
+			for (int l = 0; l < loops; ++l) { STF(d0, rand4(b->xorwow, inst0 + 4u * (uint32_t)l, rand_ordinal, LDF(p0))); p0 += i0; d0 += 16; }
 			++rand_ordinal; ip += 4; break; }
 		case VVM_OP_randomi: {  /* VectorVMRuntime.cpp:1018-1043; intended semantics, see header */
 			uint8_t *p0 = RP(0), *d0 = RP(1); int i0 = RI(0);
-			for (int l = 0; l < loops; ++l) { STF(d0, cf(F2I(rand4(inst0 + 4u * (uint32_t)l, rand_ordinal, I2F(ci(LDF(p0))))))); p0 += i0; d0 += 16; }
+			for (int l = 0; l < loops; ++l) { STF(d0, cf(F2I(rand4(b->xorwow, inst0 + 4u * (uint32_t)l, rand_ordinal, I2F(ci(LDF(p0))))))); p0 += i0; d0 += 16; }
 			++rand_ordinal; ip += 4; break; }
 		case VVM_OP_random_add: { /* VectorVMRuntime.cpp:1045-1077 */
 			uint8_t *p0 = RP(0), *p1 = RP(1), *d0 = RP(2); int i0 = RI(0), i1 = RI(1);
-			for (int l = 0; l < loops; ++l) { STF(d0, _mm_add_ps(rand4(inst0 + 4u * (uint32_t)l, rand_ordinal, LDF(p0)), LDF(p1))); p0 += i0; p1 += i1; d0 += 16; }
+			for (int l = 0; l < loops; ++l) { STF(d0, _mm_add_ps(rand4(b->xorwow, inst0 + 4u * (uint32_t)l, rand_ordinal, LDF(p0)), LDF(p1))); p0 += i0; p1 += i1; d0 += 16; }
 			++rand_ordinal; ip += 6; break; }
 		case VVM_OP_random_2x: { /* VectorVMRuntime.cpp:1079-1111 */
 			uint8_t *p0 = RP(0), *d0 = RP(1), *d1 = RP(2); int i0 = RI(0);
 			for (int l = 0; l < loops; ++l) { __m128 a = LDF(p0); p0 += i0;
-				STF(d0, rand4(inst0 + 4u * (uint32_t)l, rand_ordinal, a)); STF(d1, rand4(inst0 + 4u * (uint32_t)l, rand_ordinal + 1, a)); d0 += 16; d1 += 16; }
+				STF(d0, rand4(b->xorwow, inst0 + 4u * (uint32_t)l, rand_ordinal, a)); STF(d1, rand4(b->xorwow, inst0 + 4u * (uint32_t)l, rand_ordinal + 1, a)); d0 += 16; d1 += 16; }
 			rand_ordinal += 2; ip += 6; break; }
 		case VVM_OP_exec_index: case VVM_OP_exec_indexf: {   /* VectorVMRuntime.cpp:880-923 */
 			uint8_t* d0 = RP(0);
@@ -1257,6 +1307,7 @@ ORACLE_API int vvm_oracle_exec(vvm_exec_context* ctx)
 	batch_state b;
 	int rc = setup_batch(s, ctx, &b, max_loops);
 	if (rc != VVM_OK) { free_batch(&b); return rc; }
+	memcpy(b.xorwow, g_xorwow_start, sizeof b.xorwow);      /* SetupRandStateForBatch: once per Exec (:2271-2274) */
 	int per_chunk = (int)ctx->Internal.MaxInstancesPerChunk;
 	int nchunks = (ctx->NumInstances + per_chunk - 1) / per_chunk;
 	int start = 0;

@@ -112,7 +112,8 @@ class ExecContext(C.Structure):
 
 class ExecOptions(C.Structure):
     _fields_ = [("RandSeed", C.c_uint64), ("ExecIndexBase", C.c_int32), ("RandInstanceBase", C.c_int32),
-                ("Stream", C.c_void_p), ("Flags", C.c_uint32), ("DeviceCounts", C.c_void_p)]
+                ("Stream", C.c_void_p), ("Flags", C.c_uint32), ("DeviceCounts", C.c_void_p),
+                ("RandXorwowState", C.POINTER(C.c_uint32))]
 
 
 MAX_SHARD_DATASETS = 8
@@ -311,6 +312,8 @@ class HipBackend(Backend):
         L.vvm_inspect_code.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_uint32), C.c_int32]
         L.vvm_state_last_exec_width.restype = C.c_int32
         L.vvm_state_last_exec_width.argtypes = [C.c_void_p]
+        L.vvm_xorwow_seed.restype = None
+        L.vvm_xorwow_seed.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]
         L.vvm_set_page_size_kb.restype = None
         L.vvm_set_page_size_kb.argtypes = [C.c_int]
         L.vvm_device_alloc.restype = C.c_void_p
@@ -439,6 +442,12 @@ class HipBackend(Backend):
         pi = ProgramInfo()
         self._check(self.lib.vvm_inspect_blob(blob, len(blob), C.byref(pi)), "vvm_inspect_blob")
         return pi
+
+    def xorwow_seed(self, cycles_first: int, cycles_second: int, batch_state_address: int):
+        """The 24 words of vvm_exec_options.RandXorwowState as the reference's seeding derives them (VectorVMRuntime.cpp:445-464)."""
+        out = (C.c_uint32 * 24)()
+        self.lib.vvm_xorwow_seed(cycles_first, cycles_second, batch_state_address, out)
+        return list(out)
 
     def set_page_size_kb(self, kb: int) -> None:
         """vm.PageSizeInKB of the reference (VectorVMRuntime.cpp:44-50); 0 restores the default of 64."""

@@ -125,8 +125,11 @@ struct VvmExecDesc {
 	int32_t  rand_instance_base;
 	uint32_t flags;
 	uint32_t num_unif;             // constants copied into the uniform register, a multiple of 4, at most VVM_MAX_UNIFORMS
-	uint32_t pad;
+	uint32_t rand_stride;          // rand_words: elements from one draw's words to the next draw's
 	const VvmIdDesc* ids;          // persistent-ID tables, one VvmIdDesc per dataset the script's update_id / acquire_id work on (acquire_id's aux2 = which)
+	const uint32_t* rand_words;    // null: the random ops use the counter-based generator.  Otherwise the 32 random bits of every draw,
+	                               // [ordinal of the draw][instance of the Exec], as the reference's xorwow yields them in its execution
+	                               // order (vvm_xorwow_fill_kernel); read by the FULL kernels only
 };
 
 enum : uint32_t {
@@ -135,6 +138,33 @@ enum : uint32_t {
 };
 // Largest parameter block (descriptor + tables) that is handed to the kernel as a kernel argument instead of through device memory.
 #define VVM_INLINE_PARAM_BYTES 1024u
+
+// The reference's random generator (VectorVMRuntime.cpp:445-483): four xorwow generators side by side (one per lane of a loop's
+// four instances), stepped once per random draw and loop in execution order: chunk by chunk (:2276-2295), within a chunk
+// instruction by instruction, within an instruction loop by loop (a random_2x steps twice per loop, :1093-1094).  So the n-th
+// step's output belongs to one (draw, loop), and n follows from the chunking in closed form.  The generator's state moves
+// linearly over GF(2) (plus a counter that advances by a constant), so the state after n steps is the start state times the n-th
+// power of the step matrix: vvm_xorwow_fill_kernel jumps to the start of a segment of loops with the precomputed powers
+// M^(2^b) and steps through the segment from there.
+#define VVM_XORWOW_STATE_BITS 160u
+#define VVM_XORWOW_JUMP_POWERS 40u        // n < 2^40: 255 draws x 2^29 loops
+#define VVM_XORWOW_SEGMENT_LOOPS 64u      // loops one thread steps through
+#define VVM_XORWOW_WEYL 362437u           // :480
+// jump table: [power b][state bit j][5 words] = column j of M^(2^b) (the state after 2^b steps from the state with only bit j set;
+// bit j of the state = bit j % 32 of word j / 32, word w = State[w] of the reference)
+#define VVM_XORWOW_JUMP_WORDS (VVM_XORWOW_JUMP_POWERS * VVM_XORWOW_STATE_BITS * 5u)
+struct VvmXorwowFill {
+	uint32_t state[24];          // State[0..4][lane 0..3], Counters[lane 0..3] when the Exec starts
+	uint32_t total_loops;        // loops of the whole Exec (four instances each)
+	uint32_t chunk_loops;        // loops of every chunk but the last (MaxInstancesPerChunk / 4)
+	uint32_t num_draws;          // draws per loop of the whole script
+	uint32_t stride;             // elements between the words of two draws
+	uint32_t num_instructions;   // random instructions
+	uint32_t jump_powers;        // powers needed for the largest n of this Exec
+	uint32_t pad[2];
+	uint8_t  first[256];         // per random instruction: ordinal of its first draw
+	uint8_t  width[256];         // ... and its draws per loop (1, or 2 for random_2x)
+};
 
 // Launch-wide words in device memory; the last block to leave a launch re-arms them for the next one.
 //

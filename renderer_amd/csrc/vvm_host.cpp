@@ -46,6 +46,15 @@ int hip_fail(hipError_t e, const char* where)
 
 constexpr int kParamSlots = 8;
 
+// hipMemset on device memory returns before the fill has run (it is enqueued on the null stream), and the Execs run on
+// non-blocking streams, which do not wait for the null stream: a kernel launched right after could run ahead of the fill and have
+// its look-back words wiped under it.  Every fill the library makes is therefore waited for.
+hipError_t memset_and_wait(void* dst, int value, size_t bytes)
+{
+	const hipError_t e = hipMemset(dst, value, bytes);
+	return e != hipSuccess ? e : hipStreamSynchronize(nullptr);
+}
+
 // Pinned staging + device copy of the per-Exec parameter block, used round-robin so that several Execs can be queued.
 struct ParamRing {
 	uint8_t* host[kParamSlots] = {};
@@ -102,6 +111,7 @@ struct DeviceInfo {
 	int num_cus = 256;
 	bool ready[64] = {};      // per device ordinal: the kernels' LDS limit has been raised there
 	uint8_t* scratch_ptr[64] = {};      // per device ordinal: where that device's copy of `scratch` lies
+	uint32_t* xorwow_jump[64] = {};     // per device ordinal: the jump table of the reference's random generator (built on first use)
 };
 DeviceInfo g_dev;
 std::mutex g_dev_mutex;
@@ -121,7 +131,7 @@ int ensure_device_info()
 	uint8_t* ptr = nullptr;
 	HIP_TRY(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
 	if (!ptr) return fail(VVM_E_HIP, "hipGetSymbolAddress(scratch) returned no address");
-	HIP_TRY(hipMemset(ptr, 0, VVM_NOALLOC_SCRATCH_BYTES));      // tag 0 is never valid
+	HIP_TRY(memset_and_wait(ptr, 0, VVM_NOALLOC_SCRATCH_BYTES));      // tag 0 is never valid
 	HIP_TRY(reset_launch_state((VvmLaunchState*)ptr));
 	g_dev.scratch_ptr[dev] = ptr;
 	g_dev.ready[dev] = true;
@@ -187,6 +197,9 @@ struct vvm_state {
 	uint32_t id_datasets = 0;              // one more than the highest dataset an update_id / acquire_id names
 	size_t num_datasets() const { return std::max<uint32_t>(std::max<uint32_t>(script.max_output_dataset, 1), id_datasets); }
 	size_t mirror_word() const { return 3 * num_datasets() + 4; }
+	uint32_t* d_rand_words = nullptr;  // the reference's generator: 32 bits per draw and instance of the Exec in flight (vvm_exec_options::RandXorwowState)
+	size_t    rand_words_capacity = 0; // words
+	uint32_t  rand_stride = 0;         // words from one draw's to the next draw's
 	uint32_t  last_width = 0;          // instances per lane of the kernel the last Exec ran on
 	int       device = -1;             // ordinal of the device that holds the state's memory (the one current at vvm_alloc_state)
 };
@@ -207,7 +220,7 @@ int ensure_status(vvm_state* st, uint32_t tiles)
 	if (st->d_status) HIP_TRY(hipFree(st->d_status));
 	const uint32_t cap = std::max<uint32_t>(1024, tiles + tiles / 4);
 	HIP_TRY(hipMalloc((void**)&st->d_status, (size_t)cap * 8));
-	HIP_TRY(hipMemset(st->d_status, 0, (size_t)cap * 8));     // tag 0 is never valid
+	HIP_TRY(memset_and_wait(st->d_status, 0, (size_t)cap * 8));     // tag 0 is never valid
 	st->status_capacity = cap;
 	return VVM_OK;
 }
@@ -249,6 +262,8 @@ struct PreparedExec {
 	bool light = false;                                // ... the light eight-wide kernel
 	bool in_batch = false;                             // set by the caller: the Exec is a member of a batch (decides the kernel of small Execs, see prepare)
 	uint32_t id_buffers = 0;                           // which piece of the state's update_id buffers this pass works in (fused passes run together)
+	bool reference_random = false;                     // the Exec's random ops read the reference generator's words (then it runs on a FULL kernel)
+	bool full() const { return lp->full_kernel || reference_random; }
 	// what vvm_launch_exec_kernel takes as many_registers (a program with two chains runs four-wide on the kernel with 32 registers: it has the second chain)
 	bool launch_many() const { return light || lp->many_registers || (lp->num_chains > 1 && instances_per_lane == 4); }
 };
@@ -340,11 +355,19 @@ int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, P
 		if (rc != VVM_OK) return rc;
 	}
 	pe.instances_per_lane = pe.lp->instances_per_lane;
+	pe.reference_random = opt && opt->RandXorwowState && !st->wide.rand_draws.empty();
+	if (pe.reference_random) {
+		if (pe.in_batch) return fail(VVM_E_UNSUPPORTED_OP, "RandXorwowState: not available to the members of a batch");
+		if (pe.lp->num_chains > 1) return fail(VVM_E_UNSUPPORTED_OP, "RandXorwowState: not available to a script that acquires two datasets in one pass (set VVM_NO_CHAINS)");
+		// (the random ops of the FULL kernels read the words; a program linked for the plain kernels runs on them as it is, given the LDS)
+		if ((size_t)vvm_kernel_lds_fixed_bytes((int)pe.instances_per_lane, 1) + (size_t)pe.lp->lds_spill_slots * VVM_BLOCK_THREADS * 4u * pe.instances_per_lane > (size_t)(160 * 1024 - 64))
+			return fail(VVM_E_UNSUPPORTED_OP, "RandXorwowState: the script's registers leave no room in the LDS of the kernels that read the generator's words");
+	}
 	{
 		// eight instances per lane: the same program, twice the work per interpreted instruction; only worth it when there are
 		// enough tiles left to keep every CU busy for several rounds
 		const uint32_t flags = opt ? opt->Flags : 0;
-		const bool can = pe.lp->instances_per_lane == 4 && !pe.lp->full_kernel && !pe.lp->many_registers && !(flags & VVM_EXEC_NO_EIGHT_WIDE);
+		const bool can = pe.lp->instances_per_lane == 4 && !pe.full() && !pe.lp->many_registers && !(flags & VVM_EXEC_NO_EIGHT_WIDE);
 		// (the size of the Exec itself decides, also inside a batch: many small Execs measured faster four wide, 0.88 ms against
 		// 0.92 ms for 4096 Execs of 16 Ki instances)
 		// scripts that get by with eight registers have a program for the light eight-wide kernel (three workgroups per CU)
@@ -457,6 +480,8 @@ int fill_params(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* op
 	d->rand_seed_lo = opt ? (uint32_t)opt->RandSeed : 0;
 	d->rand_seed_hi = opt ? (uint32_t)(opt->RandSeed >> 32) : 0;
 	d->rand_instance_base = opt ? opt->RandInstanceBase : 0;
+	d->rand_words = pe.reference_random ? st->d_rand_words : nullptr;
+	d->rand_stride = pe.reference_random ? st->rand_stride : 0;
 	d->flags = (lp.uses_perlin ? VVM_DESC_USES_PERLIN : 0) | (dev_block ? 0 : VVM_DESC_RELATIVE);
 	d->num_unif = std::min<uint32_t>((s.num_consts + (uint32_t)lp.derived.size() + 3u) & ~3u, VVM_MAX_UNIFORMS);
 
@@ -537,7 +562,7 @@ int fill_params(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* op
 // fresh launch words: everything zero, epoch 1
 hipError_t reset_launch_state(VvmLaunchState* d)
 {
-	hipError_t e = hipMemset(d, 0, sizeof(VvmLaunchState));
+	hipError_t e = memset_and_wait(d, 0, sizeof(VvmLaunchState));
 	if (e != hipSuccess) return e;
 	const uint32_t one = 1;
 	return hipMemcpy(&d->epoch, &one, 4, hipMemcpyHostToDevice);
@@ -593,6 +618,86 @@ int stage_id_counters(vvm_state* st, const vvm_exec_context* ctx, const vvm::Lin
 // lane are launched one after the other, on the faster eight-wide kernels (measured on 64 Mi instances, two datasets:
 // 1.48 ms against 1.86 ms fused; the later passes do not find the shared streams in the L2 either way, the tiles in flight
 // are several times its size).  `handled` stays false when the passes have to be launched one after the other.
+// One step of one of the reference generator's four lanes without the counter (VectorVMRuntime.cpp:470-479): the linear part,
+// from which the jump table is built.
+void xorwow_linear_step(uint32_t (&x)[5])
+{
+	uint32_t t = x[4];
+	const uint32_t s0 = x[0];
+	x[4] = x[3]; x[3] = x[2]; x[2] = x[1]; x[1] = s0;
+	t ^= t >> 2;
+	t ^= t << 1;
+	t ^= s0 ^ (s0 ^ (s0 << 4));      // as written at :478
+	x[0] = t;
+}
+
+// The jump table of the current device: column j of M^(2^b) for every state bit j and power b (see vvm_device.h).
+int ensure_xorwow_jump(int device, const uint32_t** out)
+{
+	if (!g_dev.xorwow_jump[device]) {
+		std::vector<uint32_t> table(VVM_XORWOW_JUMP_WORDS);
+		auto column = [&](uint32_t b, uint32_t j) { return &table[((size_t)b * VVM_XORWOW_STATE_BITS + j) * 5u]; };
+		for (uint32_t j = 0; j < VVM_XORWOW_STATE_BITS; ++j) {
+			uint32_t x[5] = {0, 0, 0, 0, 0};
+			x[j / 32] = 1u << (j % 32);
+			xorwow_linear_step(x);
+			memcpy(column(0, j), x, sizeof x);
+		}
+		for (uint32_t b = 1; b < VVM_XORWOW_JUMP_POWERS; ++b)      // M^(2^b) = M^(2^(b-1)) squared: its column j = the lower power applied to its own column j
+			for (uint32_t j = 0; j < VVM_XORWOW_STATE_BITS; ++j) {
+				const uint32_t* v = column(b - 1, j);
+				uint32_t y[5] = {0, 0, 0, 0, 0};
+				for (uint32_t i = 0; i < VVM_XORWOW_STATE_BITS; ++i)
+					if ((v[i / 32] >> (i % 32)) & 1u) { const uint32_t* ci = column(b - 1, i); for (int w = 0; w < 5; ++w) y[w] ^= ci[w]; }
+				memcpy(column(b, j), y, sizeof y);
+			}
+		uint32_t* d = nullptr;
+		HIP_TRY(hipMalloc((void**)&d, table.size() * 4));
+		const hipError_t e = hipMemcpy(d, table.data(), table.size() * 4, hipMemcpyHostToDevice);
+		if (e != hipSuccess) { (void)hipFree(d); return hip_fail(e, "hipMemcpy(xorwow jump table)"); }
+		g_dev.xorwow_jump[device] = d;
+	}
+	*out = g_dev.xorwow_jump[device];
+	return VVM_OK;
+}
+
+// vvm_exec_options::RandXorwowState: lays out, ahead of the Exec on its stream, the 32 bits of every draw and instance as the
+// reference's generator yields them in its execution order (VectorVMRuntime.cpp:2276-2295 over the chunks of this Exec).
+int enqueue_reference_random(vvm_state* st, const vvm_exec_context* ctx, const vvm_exec_options* opt, const PreparedExec& pe, hipStream_t stream)
+{
+	const std::vector<vvm::LinkedProgram::RandDraw>& draws = st->wide.rand_draws;      // (every program of the script numbers the draws alike)
+	const uint32_t total_loops = ((uint32_t)ctx->NumInstances + 3u) >> 2;
+	if (total_loops == 0 || draws.empty()) return VVM_OK;
+	// whole tiles of the widest kernel: the lanes past the last instance read too (their values go nowhere)
+	const uint64_t stride = ((uint64_t)total_loops * 4u + 2047u) & ~(uint64_t)2047u;
+	if (stride > 0xFFFFF800ull) return fail(VVM_E_TOO_LARGE, "RandXorwowState: too many instances");
+	const size_t need = (size_t)stride * draws.size();
+	if (need > st->rand_words_capacity) {
+		HIP_TRY(hipStreamSynchronize(stream));
+		if (st->d_rand_words) { HIP_TRY(hipFree(st->d_rand_words)); st->d_rand_words = nullptr; st->rand_words_capacity = 0; }
+		HIP_TRY(hipMalloc((void**)&st->d_rand_words, need * 4));
+		st->rand_words_capacity = need;
+	}
+	st->rand_stride = (uint32_t)stride;
+	const uint32_t* jump = nullptr;
+	const int rc = ensure_xorwow_jump(st->device, &jump);
+	if (rc != VVM_OK) return rc;
+	VvmXorwowFill p;
+	memset(&p, 0, sizeof p);
+	memcpy(p.state, opt->RandXorwowState, sizeof p.state);
+	p.total_loops = total_loops;
+	p.chunk_loops = pe.chunk_instances / 4u;
+	p.num_draws = (uint32_t)draws.size();
+	p.stride = (uint32_t)stride;
+	for (size_t o = 0; o < draws.size(); ++o)
+		if (draws[o].first == o) { p.first[p.num_instructions] = draws[o].first; p.width[p.num_instructions] = draws[o].width; ++p.num_instructions; }
+	const uint64_t steps = (uint64_t)total_loops * draws.size();
+	while (p.jump_powers < VVM_XORWOW_JUMP_POWERS && (steps >> p.jump_powers) != 0) ++p.jump_powers;
+	const int lrc = vvm_launch_xorwow_fill(&p, jump, st->d_rand_words, stream);
+	if (lrc != 0) return hip_fail((hipError_t)lrc, "kernel launch (random generator)");
+	return VVM_OK;
+}
+
 int enqueue_fused_passes(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, uint32_t K, hipStream_t stream, VvmLaunchState* d_launch, bool timed, bool& handled)
 {
 	handled = false;
@@ -674,6 +779,24 @@ extern "C" {
 
 VVM_API const char* vvm_last_error(void) { return g_last_error.c_str(); }
 
+VVM_API void vvm_xorwow_seed(uint64_t cycles_first, uint64_t cycles_second, uint64_t batch_state_address, uint32_t* state24)
+{
+	if (!state24) return;
+	// a PCG-like generator seeds the xorwow state, VectorVMRuntime.cpp:447-463
+	uint64_t seed_state = cycles_first ^ (cycles_second << 32);
+	const uint64_t increment = ((batch_state_address << 32) ^ 0xCAFEF00DD15EA5E5ull) | 1u;
+	for (int k = 0; k < 20; ++k) {
+		const uint64_t before = seed_state;
+		seed_state = before * 6364136223846793005ull + increment;
+		const uint32_t mixed = (uint32_t)(((before >> 18) ^ before) >> 27);
+		const uint32_t turn = (uint32_t)(before >> 59);
+		state24[k] = (mixed >> turn) | (mixed << ((0u - turn) & 31u));
+	}
+	// Counters = the two 64-bit numbers as four 32-bit lanes (:464)
+	state24[20] = (uint32_t)increment;  state24[21] = (uint32_t)(increment >> 32);
+	state24[22] = (uint32_t)seed_state; state24[23] = (uint32_t)(seed_state >> 32);
+}
+
 VVM_API void vvm_set_page_size_kb(int kb) { g_page_kb = (kb > 0 && kb <= 1 << 20) ? kb : 64; }
 
 VVM_API vvm_state* vvm_alloc_state(const uint8_t* blob, size_t num_bytes)
@@ -720,7 +843,7 @@ VVM_API vvm_state* vvm_alloc_state(const uint8_t* blob, size_t num_bytes)
 		st->counts_in_launch = true;
 	} else {
 		if ((e = hipMalloc((void**)&st->d_counts, ncounts * 4)) != hipSuccess) return bail(e, "hipMalloc(counts)");
-		if ((e = hipMemset(st->d_counts, 0, ncounts * 4)) != hipSuccess) return bail(e, "hipMemset(counts)");
+		if ((e = memset_and_wait(st->d_counts, 0, ncounts * 4)) != hipSuccess) return bail(e, "hipMemset(counts)");
 	}
 	const size_t host_bytes = st->mirror_word() * 4 + sizeof(VvmLaunchState);
 	if ((e = hipHostMalloc((void**)&st->h_counts, host_bytes, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc(counts)");
@@ -746,6 +869,7 @@ VVM_API void vvm_free_state(vvm_state* st)
 	if (st->d_counts && !st->counts_in_launch) (void)hipFree(st->d_counts);
 	if (st->d_chunk_prefix) (void)hipFree(st->d_chunk_prefix);
 	if (st->d_id_scratch) (void)hipFree(st->d_id_scratch);
+	if (st->d_rand_words) (void)hipFree(st->d_rand_words);
 	if (st->h_counts) (void)hipHostFree(st->h_counts);
 	for (hipEvent_t e : st->ev_start) (void)hipEventDestroy(e);
 	for (hipEvent_t e : st->ev_stop) (void)hipEventDestroy(e);
@@ -776,6 +900,7 @@ static int exec_enqueue(vvm_exec_context* ctx, const vvm_exec_options* opt, bool
 	PreparedExec pe;
 	int rc = prepare(st, ctx, opt, pe);
 	if (rc != VVM_OK) return rc;
+	if (no_alloc && pe.reference_random) return fail(VVM_E_UNSUPPORTED_OP, "vvm_exec_noalloc: RandXorwowState needs a buffer sized per Exec");
 	uint8_t* const scratch_ptr = no_alloc ? g_dev.scratch_ptr[st->device] : nullptr;
 	if (no_alloc) {
 		if (!scratch_ptr) return fail(VVM_E_HIP, "vvm_exec_noalloc: the scratch array of this device has no address");
@@ -824,6 +949,10 @@ static int exec_enqueue(vvm_exec_context* ctx, const vvm_exec_options* opt, bool
 			st->ev_start.push_back(a); st->ev_stop.push_back(b);
 		}
 	}
+	if (pe.reference_random) {
+		rc = enqueue_reference_random(st, ctx, opt, pe, stream);
+		if (rc != VVM_OK) return rc;
+	}
 	const uint32_t num_passes = pe.lp->num_passes;
 	if (num_passes > 1 && !no_alloc && !(opt && (opt->Flags & VVM_EXEC_SEPARATE_PASSES))) {
 		bool handled = false;
@@ -865,8 +994,8 @@ static int exec_enqueue(vvm_exec_context* ctx, const vvm_exec_options* opt, bool
 		}
 		if (timed && pass == 0) HIP_TRY(hipEventRecord(st->ev_start[st->ev_used], stream));
 		const int lrc = vvm_launch_exec_kernel((int)pe.instances_per_lane, inline_block ? nullptr : (const VvmExecDesc*)st->ring.dev[slot], 1, pe.tiles, d_launch,
-		                                       pe.launch_many() ? 1 : 0, pe.lp->lds_spill_slots, pe.lp->full_kernel ? 1 : 0,
-		                                       grid_for(pe.tiles, pe.instances_per_lane, pe.lp->full_kernel, pe.launch_many()), stream,
+		                                       pe.launch_many() ? 1 : 0, pe.lp->lds_spill_slots, pe.full() ? 1 : 0,
+		                                       grid_for(pe.tiles, pe.instances_per_lane, pe.full(), pe.launch_many()), stream,
 		                                       inline_block ? local_block : nullptr, inline_block ? (uint32_t)pe.bytes : 0u, 0u, 0);
 		if (lrc != 0) return hip_fail((hipError_t)lrc, "kernel launch");
 		if (timed && pass + 1 == num_passes) { HIP_TRY(hipEventRecord(st->ev_stop[st->ev_used], stream)); st->ev_used++; }
@@ -919,7 +1048,7 @@ VVM_API int vvm_exec_finish(vvm_exec_context* ctx)
 		if (ls->pad != 0) {
 			const bool lds_base = ls->pad == 2;
 			(void)reset_launch_state(st->cur_launch);
-			if (st->cur_status) (void)hipMemset(st->cur_status, 0, st->cur_status_words * 8);
+			if (st->cur_status) (void)memset_and_wait(st->cur_status, 0, st->cur_status_words * 8);
 			if (lds_base) return fail(VVM_E_HIP, "the kernel's dynamic LDS does not start at address 0 (the noise tables are addressed absolutely)");
 			return fail(VVM_E_HIP, "look-back timed out inside the kernel (a tile never published its count)");
 		}
@@ -1032,7 +1161,7 @@ struct BatchPlan {
 	uint32_t total_tiles = 0;
 };
 
-int kernel_key(const PreparedExec& pe) { return (int)pe.instances_per_lane * 4 + (pe.launch_many() ? 2 : 0) + (pe.lp->full_kernel ? 1 : 0); }
+int kernel_key(const PreparedExec& pe) { return (int)pe.instances_per_lane * 4 + (pe.launch_many() ? 2 : 0) + (pe.full() ? 1 : 0); }
 
 // Tiles, ticket numbers, look-back words and buffer offsets of every Exec, from the groups' member lists and the prepared sizes.
 void batch_layout(BatchPlan& plan, const vvm_exec_context* ctxs)
@@ -1140,7 +1269,7 @@ int batch_ensure_buffers(BatchWorkspace& ws, const BatchPlan& plan)
 		if (ws.d_status) (void)hipFree(ws.d_status);
 		ws.status_capacity = plan.total_tiles + plan.total_tiles / 4 + 1024;
 		HIP_TRY(hipMalloc((void**)&ws.d_status, (size_t)ws.status_capacity * 8));
-		HIP_TRY(hipMemset(ws.d_status, 0, (size_t)ws.status_capacity * 8));      // tag 0 is never valid
+		HIP_TRY(memset_and_wait(ws.d_status, 0, (size_t)ws.status_capacity * 8));      // tag 0 is never valid
 	}
 	const size_t launch_slots = 4 * 8;      // (slices x groups)
 	if (!ws.h_launch) HIP_TRY(hipHostMalloc((void**)&ws.h_launch, launch_slots * sizeof(VvmLaunchState), hipHostMallocDefault));
@@ -1251,7 +1380,7 @@ int batch_collect(BatchWorkspace& ws, const BatchPlan& plan, vvm_exec_context* c
 			if (slice.groups[g].tiles && ws.h_launch[sl * 8 + g].pad != 0) {
 				(void)hipStreamSynchronize(ws.stream);
 				for (size_t k = 0; k < 8; ++k) if (ws.d_launch[k]) (void)reset_launch_state(ws.d_launch[k]);
-				(void)hipMemset(ws.d_status, 0, (size_t)ws.status_capacity * 8);
+				(void)memset_and_wait(ws.d_status, 0, (size_t)ws.status_capacity * 8);
 				return fail(VVM_E_HIP, "look-back timed out inside the batched kernel");
 			}
 		for (int i = slice.first; i < slice.first + slice.count; ++i) {
@@ -1539,7 +1668,7 @@ VVM_API void* vvm_device_alloc(size_t num_bytes)
 VVM_API void vvm_device_free(void* p) { if (p) (void)hipFree(p); }
 VVM_API int vvm_device_upload(void* dst, const void* src, size_t n) { HIP_TRY(hipMemcpy(dst, src, n, hipMemcpyHostToDevice)); return VVM_OK; }
 VVM_API int vvm_device_download(void* dst, const void* src, size_t n) { HIP_TRY(hipMemcpy(dst, src, n, hipMemcpyDeviceToHost)); return VVM_OK; }
-VVM_API int vvm_device_memset(void* dst, int v, size_t n) { HIP_TRY(hipMemset(dst, v, n)); return VVM_OK; }
+VVM_API int vvm_device_memset(void* dst, int v, size_t n) { HIP_TRY(memset_and_wait(dst, v, n)); return VVM_OK; }
 VVM_API int vvm_device_synchronize(void) { HIP_TRY(hipDeviceSynchronize()); return VVM_OK; }
 VVM_API int vvm_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 VVM_API int vvm_set_device(int ordinal) { HIP_TRY(hipSetDevice(ordinal)); return VVM_OK; }
@@ -1658,8 +1787,8 @@ vvm_comm* comm_create_common(int32_t rank, int32_t world)
 	if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
 	if ((e = hipMalloc((void**)&c->d_send, send_words * 4)) != hipSuccess) return bail(e, "hipMalloc");
 	if ((e = hipMalloc((void**)&c->d_recv, recv_words * 4)) != hipSuccess) return bail(e, "hipMalloc");
-	if ((e = hipMemset(c->d_send, 0, send_words * 4)) != hipSuccess) return bail(e, "hipMemset");
-	if ((e = hipMemset(c->d_recv, 0, recv_words * 4)) != hipSuccess) return bail(e, "hipMemset");
+	if ((e = memset_and_wait(c->d_send, 0, send_words * 4)) != hipSuccess) return bail(e, "hipMemset");
+	if ((e = memset_and_wait(c->d_recv, 0, recv_words * 4)) != hipSuccess) return bail(e, "hipMemset");
 	if ((e = hipHostMalloc((void**)&c->h_send, send_words * 4, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
 	if ((e = hipHostMalloc((void**)&c->h_recv, recv_words * 4, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
 	for (int k = 0; k < kCommSlots; ++k) {

@@ -552,6 +552,20 @@ struct Ctx {
 	uint32_t phase;               // tiles this workgroup has started; its parity selects the LDS word of double-buffered exchanges
 };
 
+// The 32 random bits of draw `ordinal` for instance `inst` of the Exec: from the words laid out by vvm_xorwow_fill_kernel when the
+// Exec asks for the reference's generator (FULL kernels only: the host sends such an Exec there), else from the counter-based one.
+template <bool FULL> DEV uint32_t draw_bits(const Ctx& c, uint32_t inst, uint32_t ordinal)
+{
+	if constexpr (FULL) {
+		const uint64_t words = DESC_PTR(c.dp, rand_words);
+		if (words != 0) {
+			const uint64_t at = (uint64_t)ordinal * DESC_U32(c.dp, rand_stride) + inst;      // (inst < rand_stride: the stride covers whole tiles)
+			return *(const uint32_t*)(words + at * 4u);
+		}
+	}
+	return rand_u32(DESC_U32(c.dp, rand_seed_lo), DESC_U32(c.dp, rand_seed_hi), DESC_U32(c.dp, rand_instance_base) + inst, ordinal);
+}
+
 // Register access.  The index is wave-uniform.  The VGPR vectors are read and written unconditionally (a branch around an
 // element insert makes the compiler keep two copies of the whole vector); a write to a register that lives in LDS puts
 // the old value back into the element it aliases.
@@ -1245,7 +1259,7 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 				case VVM_OP_bit_and_i2f: SETF(i2f((int32_t)(UA & UB)));
 				case VVM_OP_neg_cmplt: SETM(f_neg(A) < B);
 				case VVM_OP_max_f2i: SETI(cvtt(f_max(A, B)));
-				case VVM_OP_random_add: SETF(rand01(rand_u32(DESC_U32(c.dp, rand_seed_lo), DESC_U32(c.dp, rand_seed_hi), DESC_U32(c.dp, rand_instance_base) + inst_i + slot_offset<V>(k), aux2)) * A + B);
+				case VVM_OP_random_add: SETF(rand01(draw_bits<FULL>(c, inst_i + slot_offset<V>(k), aux2)) * A + B);
 				default: { _Pragma("unroll") LANES r[k] = 0.0f; } break;
 				}
 			}
@@ -1356,8 +1370,8 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 				case VVM_OP_half_to_float: SETF(load_half(UA));             // RT.cpp:1113-1127
 				case VVM_OP_exec_index_addi: SETI(DESC_U32(c.dp, exec_index_base) + inst_i + slot_offset<V>(k) + UA);             // RT.cpp:925-951
 				// aux2 = ordinal of the random op within the script
-				case VVM_OP_random: SETF(rand01(rand_u32(DESC_U32(c.dp, rand_seed_lo), DESC_U32(c.dp, rand_seed_hi), DESC_U32(c.dp, rand_instance_base) + inst_i + slot_offset<V>(k), aux2)) * A);
-				case VVM_OP_randomi: SETI(cvtt(rand01(rand_u32(DESC_U32(c.dp, rand_seed_lo), DESC_U32(c.dp, rand_seed_hi), DESC_U32(c.dp, rand_instance_base) + inst_i + slot_offset<V>(k), aux2)) * i2f(IA)));
+				case VVM_OP_random: SETF(rand01(draw_bits<FULL>(c, inst_i + slot_offset<V>(k), aux2)) * A);
+				case VVM_OP_randomi: SETI(cvtt(rand01(draw_bits<FULL>(c, inst_i + slot_offset<V>(k), aux2)) * i2f(IA)));
 				default: { _Pragma("unroll") LANES r[k] = 0.0f; } break;
 				}
 			}
@@ -1769,6 +1783,86 @@ extern "C" int vvm_launch_max_id_kernel(const VvmIdDesc* idp, uint32_t num_chunk
 {
 	const uint32_t grid = num_chunks < 1024u ? (num_chunks ? num_chunks : 1u) : 1024u;
 	hipLaunchKernelGGL(vvm_max_id_kernel, dim3(grid), dim3(256), 0, stream, idp);
+	return (int)hipGetLastError();
+}
+
+// ---- the reference's xorwow, laid out per draw and instance --------------------------------------------
+// One step of the four generators (VectorVMRuntime.cpp:468-483); x[w][l] = lane l of State[w], ctr[l] = lane l of Counters.
+DEV void xorwow_step(uint32_t (&x)[5][4], uint32_t (&ctr)[4], uint32_t (&out)[4])
+{
+#pragma unroll
+	for (int l = 0; l < 4; ++l) {
+		uint32_t t = x[4][l];
+		const uint32_t s0 = x[0][l];
+		x[4][l] = x[3][l]; x[3][l] = x[2][l]; x[2][l] = x[1][l]; x[1][l] = s0;
+		t ^= t >> 2;
+		t ^= t << 1;
+		t ^= s0 ^ (s0 ^ (s0 << 4));      // as written at :478
+		x[0][l] = t;
+		ctr[l] += VVM_XORWOW_WEYL;
+		out[l] = t + ctr[l];
+	}
+}
+// Thread (s, i): random instruction i, loops [64 s, 64 s + 64) of the Exec.  Step number of (chunk c, instruction with first
+// draw f and width w, loop l of the chunk, draw j of the loop) = D * c * chunk_loops + f * loops(c) + l * w + j, D = draws per
+// loop of the whole script: the chunks before it ran every draw over all their loops, the instructions before it over this
+// chunk's loops.
+__global__ void __launch_bounds__(256) vvm_xorwow_fill_kernel(const VvmXorwowFill p, const uint32_t* __restrict__ jump, uint32_t* __restrict__ words)
+{
+	const uint32_t ins = blockIdx.y;
+	const uint32_t first = p.first[ins], width = p.width[ins];
+	uint32_t g = (blockIdx.x * 256u + threadIdx.x) * VVM_XORWOW_SEGMENT_LOOPS;
+	const uint32_t g_end = min(g + VVM_XORWOW_SEGMENT_LOOPS, p.total_loops);
+	while (g < g_end) {
+		const uint32_t chunk = g / p.chunk_loops, l = g - chunk * p.chunk_loops;
+		const uint32_t loops_here = min(p.chunk_loops, p.total_loops - chunk * p.chunk_loops);
+		const uint64_t n = (uint64_t)p.num_draws * chunk * p.chunk_loops + (uint64_t)first * loops_here + (uint64_t)l * width;
+		// the state after n steps
+		uint32_t x[5][4], ctr[4];
+#pragma unroll
+		for (int w = 0; w < 5; ++w)
+#pragma unroll
+			for (int k = 0; k < 4; ++k) x[w][k] = p.state[4 * w + k];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) ctr[k] = p.state[20 + k] + VVM_XORWOW_WEYL * (uint32_t)n;
+		for (uint32_t b = 0; b < p.jump_powers; ++b) {
+			if (!((n >> b) & 1u)) continue;
+			const uint32_t* col = jump + (size_t)b * VVM_XORWOW_STATE_BITS * 5u;
+			uint32_t y[5][4] = {};
+#pragma unroll
+			for (int w = 0; w < 5; ++w)
+				for (uint32_t bit = 0; bit < 32u; ++bit) {
+					const uint32_t* cj = col + ((uint32_t)w * 32u + bit) * 5u;
+					const uint32_t c0 = cj[0], c1 = cj[1], c2 = cj[2], c3 = cj[3], c4 = cj[4];
+#pragma unroll
+					for (int k = 0; k < 4; ++k) {
+						const uint32_t m = 0u - ((x[w][k] >> bit) & 1u);
+						y[0][k] ^= c0 & m; y[1][k] ^= c1 & m; y[2][k] ^= c2 & m; y[3][k] ^= c3 & m; y[4][k] ^= c4 & m;
+					}
+				}
+#pragma unroll
+			for (int w = 0; w < 5; ++w)
+#pragma unroll
+				for (int k = 0; k < 4; ++k) x[w][k] = y[w][k];
+		}
+		// ... and on through the loops of this segment that lie in the chunk
+		const uint32_t stop = min(g_end, (chunk + 1u) * p.chunk_loops);
+		for (; g < stop; ++g)
+			for (uint32_t j = 0; j < width; ++j) {
+				uint32_t out[4];
+				xorwow_step(x, ctr, out);
+				uint4 v; v.x = out[0]; v.y = out[1]; v.z = out[2]; v.w = out[3];
+				*(uint4*)(words + (size_t)(first + j) * p.stride + (size_t)g * 4u) = v;
+			}
+	}
+}
+extern "C" int vvm_launch_xorwow_fill(const VvmXorwowFill* params, const uint32_t* jump, uint32_t* words, hipStream_t stream)
+{
+	if (!params || !jump || !words || params->num_instructions == 0 || params->num_instructions > 255u || params->chunk_loops == 0 ||
+	    params->total_loops == 0 || params->jump_powers > VVM_XORWOW_JUMP_POWERS || (params->stride & 3u) || (uint64_t)params->total_loops * 4u > params->stride)
+		return (int)hipErrorInvalidValue;
+	const uint32_t segments = (params->total_loops + VVM_XORWOW_SEGMENT_LOOPS - 1u) / VVM_XORWOW_SEGMENT_LOOPS;
+	hipLaunchKernelGGL(vvm_xorwow_fill_kernel, dim3((segments + 255u) / 256u, params->num_instructions), dim3(256), 0, stream, *params, jump, words);
 	return (int)hipGetLastError();
 }
 

@@ -720,8 +720,9 @@ static int link_program_as(const ThawedScript& s, bool force_narrow, LinkedProgr
 		const Decoded& d = ins[at_ins];
 		if (!needed[at_ins]) {
 			// a draw that is left out keeps its place in the numbering: the draws that stay must not change
-			if (d.op == VVM_OP_random || d.op == VVM_OP_randomi || d.op == VVM_OP_random_add) rand_ordinal += 1;
-			else if (d.op == VVM_OP_random_2x) rand_ordinal += 2;
+			if (d.op == VVM_OP_random || d.op == VVM_OP_randomi || d.op == VVM_OP_random_add) { lp.rand_draws.push_back({(uint8_t)rand_ordinal, 1}); rand_ordinal += 1; }
+			else if (d.op == VVM_OP_random_2x) { lp.rand_draws.push_back({(uint8_t)rand_ordinal, 2}); lp.rand_draws.push_back({(uint8_t)rand_ordinal, 2}); rand_ordinal += 2; }
+			if (rand_ordinal > 255) { err = "more than 255 random draws in one script"; return VVM_E_TOO_LARGE; }
 			continue;
 		}
 		VvmIns k{0, 0, 0, 0};
@@ -733,8 +734,12 @@ static int link_program_as(const ThawedScript& s, bool force_narrow, LinkedProgr
 				if (VVM_OPND_CLS(operand(d.out[i])) != VVM_OPC_VREG) { err = "an op destination is not a temp or output register"; return VVM_E_BAD_BLOB; }
 			// per destination: the single-output device op and its aux / aux2
 			uint32_t op1 = d.op, aux[2] = {0, 0}, aux2[2] = {0, 0};
-			if (d.op == VVM_OP_random || d.op == VVM_OP_randomi || d.op == VVM_OP_random_add) aux2[0] = rand_ordinal++;
-			else if (d.op == VVM_OP_random_2x) { op1 = VVM_OP_random; aux2[0] = rand_ordinal; aux2[1] = rand_ordinal + 1; rand_ordinal += 2; }   // RT.cpp:1079-1111
+			if (d.op == VVM_OP_random || d.op == VVM_OP_randomi || d.op == VVM_OP_random_add) { lp.rand_draws.push_back({(uint8_t)rand_ordinal, 1}); aux2[0] = rand_ordinal++; }
+			else if (d.op == VVM_OP_random_2x) {                                                  // RT.cpp:1079-1111
+				op1 = VVM_OP_random; aux2[0] = rand_ordinal; aux2[1] = rand_ordinal + 1;
+				lp.rand_draws.push_back({(uint8_t)rand_ordinal, 2}); lp.rand_draws.push_back({(uint8_t)rand_ordinal, 2});
+				rand_ordinal += 2;
+			}
 			else if (d.op == VVM_OP_mul_2x) op1 = VVM_OP_mul;                                     // RT.cpp:1743-1777
 			else if (d.op == VVM_OP_b2i_2x) op1 = VVM_OP_b2i;                                     // RT.cpp:1875-1904
 			else if (d.op == VVM_OP_sin_cos) aux[1] = 1;                                          // RT.cpp:1491-1516: sine first, cosine second

@@ -69,6 +69,11 @@ struct LinkedProgram {
 	uint32_t num_chains = 1;
 	uint32_t chain_dataset[2] = {0, 0};
 	std::vector<uint8_t> out_chain;
+	// The script's random draws in program order (a random_2x makes two), whether or not this program keeps the instruction:
+	// draws[o] = {ordinal of the first draw of o's instruction, draws of that instruction}.  The reference's generator is stepped
+	// once per draw and loop in execution order (VectorVMRuntime.cpp:990-1111), which these say.
+	struct RandDraw { uint8_t first, width; };
+	std::vector<RandDraw> rand_draws;
 	uint32_t bytes_in_per_instance = 0, bytes_out_per_instance = 0;
 	uint32_t num_prefetched_inputs = 0;
 	std::vector<uint8_t> input_used;   // per remapped input: some instruction of this program reads it

@@ -23,6 +23,8 @@ class OracleBackend(abi.Backend):
         lib.vvm_oracle_set_strict.argtypes = [C.c_int]
         lib.vvm_oracle_set_page_kb.argtypes = [C.c_int]
         lib.vvm_oracle_set_options.argtypes = [C.c_uint64, C.c_int32, C.c_int32]
+        lib.vvm_oracle_set_xorwow.argtypes = [C.POINTER(C.c_uint32)]
+        lib.vvm_oracle_xorwow_seed.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]
         lib.vvm_oracle_perlin3.restype = C.c_float
         lib.vvm_oracle_perlin3.argtypes = [C.c_float] * 3
         lib.vvm_oracle_curl_noise3.argtypes = [C.c_float] * 3 + [C.POINTER(C.c_float)]
@@ -38,6 +40,15 @@ class OracleBackend(abi.Backend):
 
     def set_page_kb(self, kb: int):
         self.lib.vvm_oracle_set_page_kb(kb)
+
+    def set_xorwow(self, state24=None):
+        """state24: the reference generator's start state (24 words), or None for the counter-based generator."""
+        self.lib.vvm_oracle_set_xorwow((C.c_uint32 * 24)(*state24) if state24 is not None else None)
+
+    def xorwow_seed(self, cycles_first: int, cycles_second: int, batch_state_address: int):
+        out = (C.c_uint32 * 24)()
+        self.lib.vvm_oracle_xorwow_seed(cycles_first, cycles_second, batch_state_address, out)
+        return list(out)
 
     def set_options(self, seed: int = 0, exec_index_base: int = 0, rand_instance_base: int = 0):
         self.lib.vvm_oracle_set_options(seed, exec_index_base, rand_instance_base)

@@ -48,14 +48,16 @@ def run_oracle(script: BuiltScript, const_tables: Sequence[bytes], inputs: Seque
                seed: int = 0, exec_index_base: int = 0, rand_instance_base: int = 0, strict: bool = False,
                page_kb: int = 64, out_fill: int = 0xCD, ids: Optional[IdState] = None,
                more_datasets: Sequence[Sequence] = (), more_results: Optional[list] = None,
-               more_ids: Sequence[Optional[IdState]] = ()) -> Tuple[List[np.ndarray], int, abi.CallFrame]:
-    """more_datasets: output dtypes of datasets 1, 2, ... (outputs only); their (streams, survivors) are appended to more_results.
+               more_ids: Sequence[Optional[IdState]] = (), xorwow: Optional[Sequence[int]] = None) -> Tuple[List[np.ndarray], int, abi.CallFrame]:
+    """xorwow: start state of the reference's random generator (24 words); None = the counter-based generator keyed by `seed`.
+    more_datasets: output dtypes of datasets 1, 2, ... (outputs only); their (streams, survivors) are appended to more_results.
     more_ids: the ID tables of datasets 1, 2, ... (None: the dataset has none)."""
     from oracle_binding import load_oracle
     be = load_oracle()
     be.set_strict(strict)
     be.set_page_kb(page_kb)
     be.set_options(seed, exec_index_base, rand_instance_base)
+    be.set_xorwow(xorwow)
     total = instance_offset + n + PAD
     ins = []
     for a in inputs:
@@ -88,6 +90,7 @@ def run_oracle(script: BuiltScript, const_tables: Sequence[bytes], inputs: Seque
                 st.read_counters(frame.datasets[1 + i])
     finally:
         be.free_state(state)
+        be.set_xorwow(None)
     return outs, surv, frame
 
 
@@ -97,7 +100,7 @@ def run_hip(script: BuiltScript, const_tables: Sequence[bytes], inputs: Sequence
             out_fill: int = 0xCD, repeat: int = 1, ids: Optional[IdState] = None, page_kb: int = 64,
             more_datasets: Sequence[Sequence] = (), more_results: Optional[list] = None,
             batch_with: Optional[Sequence] = None, device_counts: Optional[list] = None,
-            more_ids: Sequence[Optional[IdState]] = ()) -> Tuple[List[np.ndarray], int, abi.ProgramInfo]:
+            more_ids: Sequence[Optional[IdState]] = (), xorwow: Optional[Sequence[int]] = None) -> Tuple[List[np.ndarray], int, abi.ProgramInfo]:
     """Same contract as run_oracle, through the C ABI of libvvm_hip.so with streams in device memory.
     batch_with: call frames of other emitters; the Exec then runs as the middle member of one vvm_exec_batch call with them.
     device_counts: a list; the Exec gets a buffer of eight ints (filled with -1) as vvm_exec_options.DeviceCounts, whose contents
@@ -161,6 +164,9 @@ def run_hip(script: BuiltScript, const_tables: Sequence[bytes], inputs: Sequence
         try:
             frame = abi.CallFrame(state, [ds] + more_ds, n, const_tables, ext_fns)
             opt = abi.ExecOptions(seed, exec_index_base, rand_instance_base, None, flags)
+            if xorwow is not None:
+                xorwow_words = (C.c_uint32 * 24)(*xorwow)      # (alive until the Exec has returned)
+                opt.RandXorwowState = xorwow_words
             if device_counts is not None:
                 p = L.vvm_device_alloc(32)
                 assert p, be.error_text()
