@@ -612,12 +612,6 @@ int stage_id_counters(vvm_state* st, const vvm_exec_context* ctx, const vvm::Lin
 	return VVM_OK;
 }
 
-// A script that acquires several datasets has one program per dataset (a pass).  When all passes run four instances per lane,
-// or all one, they go out as ONE launch of a FULL kernel that runs every pass on a tile before it moves to the next tile: one
-// launch instead of several, and the passes' look-back chains advance together.  Passes that would run eight instances per
-// lane are launched one after the other, on the faster eight-wide kernels (measured on 64 Mi instances, two datasets:
-// 1.48 ms against 1.86 ms fused; the later passes do not find the shared streams in the L2 either way, the tiles in flight
-// are several times its size).  `handled` stays false when the passes have to be launched one after the other.
 // One step of one of the reference generator's four lanes without the counter (VectorVMRuntime.cpp:470-479): the linear part,
 // from which the jump table is built.
 void xorwow_linear_step(uint32_t (&x)[5])
@@ -698,6 +692,12 @@ int enqueue_reference_random(vvm_state* st, const vvm_exec_context* ctx, const v
 	return VVM_OK;
 }
 
+// A script that acquires several datasets has one program per dataset (a pass).  When all passes run four instances per lane,
+// or all one, they go out as ONE launch of a FULL kernel that runs every pass on a tile before it moves to the next tile: one
+// launch instead of several, and the passes' look-back chains advance together.  Passes that would run eight instances per
+// lane are launched one after the other, on the faster eight-wide kernels (measured on 64 Mi instances, two datasets:
+// 1.48 ms against 1.86 ms fused; the later passes do not find the shared streams in the L2 either way, the tiles in flight
+// are several times its size).  `handled` stays false when the passes have to be launched one after the other.
 int enqueue_fused_passes(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, uint32_t K, hipStream_t stream, VvmLaunchState* d_launch, bool timed, bool& handled)
 {
 	handled = false;
