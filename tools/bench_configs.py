@@ -5,6 +5,7 @@
   kill_half        64 Mi particles, fountain with 50 % death                      (configs[3], one GPU's share scaled down)
   kill_half_250m   250 M particles, fountain with 50 % death                      (configs[3], one GPU's share of 2 G particles)
   one_million      1 Mi particles, fountain                                       (configs[0], the reference's CPU-runnable case)
+  reference_random 16 Mi particles, three random draws: the counter-based generator against the reference's xorwow
   batch            4096 emitters x 16 Ki particles, 64 distinct bytecode bodies, one launch per kernel shape  (configs[4])
 
 Prints one JSON object per configuration.  Times are wall-clock around synchronous calls (vvm_exec / vvm_exec_batch), so
@@ -96,6 +97,42 @@ def main():
             t_before = time.perf_counter()
             run_single("arithmetic %d ops, 4 streams in / 4 out, 64Mi" % n_ops, w, ins[:4], 4, n)
             print(json.dumps({"config": "arithmetic %d ops: interpreted instructions x instances per second = value of 'updates_per_s' x %d" % (n_ops, n_ops)}), flush=True)
+
+    if "reference_random" in which:
+        # 16 Mi particles, one stream in, three draws (random, random_2x) and three streams out: the counter-based generator
+        # against the reference's xorwow laid out ahead of the Exec (vvm_exec_options.RandXorwowState)
+        import ctypes as C
+        import struct
+        from renderer_amd.assembler import FLOAT, Script
+        s = Script()
+        x = s.input(0, FLOAT, 0)
+        s.acquireindex(s.const(0), 0)
+        r0, r1, r2 = s.temps(3)
+        s.op("random", x, r0); s.op("random_2x", x, r1, r2)
+        s.output_data(FLOAT, 0, [(r, s.output(0, FLOAT, i)) for i, r in enumerate((r0, r1, r2))])
+        built = s.build()
+        n = 16 * 1024 * 1024
+        xs = torch.rand(n + PAD, dtype=torch.float32, device=dev)
+        outs = [torch.zeros(n + PAD, dtype=torch.float32, device=dev) for _ in range(3)]
+        torch.cuda.synchronize()
+        words = (C.c_uint32 * 24)(*be.xorwow_seed(0x1234, 0x5678, 0x7F0000001000))
+        for name, use in (("counter-based generator", False), ("reference xorwow from an injected state", True)):
+            st = VectorVMState(built.blob, be)
+            frame = st.frame([abi.DataSet([xs.data_ptr()], [t.data_ptr() for t in outs], 0)], n, [struct.pack("<I", 0xFFFFFFFF) + bytes(12)])
+            o = abi.ExecOptions(7, 0, 0, None, 0)
+            if use:
+                o.RandXorwowState = words
+            for _ in range(3):
+                st.exec(frame, o)
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                st.exec_async(frame, o)
+            st.finish(frame)
+            el = time.perf_counter() - t0
+            width = st.last_exec_width()
+            st.close()
+            print(json.dumps({"config": "3 random draws, 1 stream in / 3 out, 16Mi: " + name, "ms_per_step": el / args.steps * 1e3,
+                              "updates_per_s": n * args.steps / el, "instances_per_lane": width}), flush=True)
 
     if "six_out" in which:
         # the fountain script with two of its eight outputs left out (eight streams in, six out): what the light eight-wide kernel,
