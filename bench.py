@@ -147,6 +147,8 @@ def main():
                     help="rehearsal on a one-GPU box: run the multi-rank step (count copy, all-gather on its own stream) with a single rank")
     ap.add_argument("--comm", default="c-abi", choices=["c-abi", "torch"],
                     help="who runs the count exchange at N > 1: the library's own RCCL communicator (vvm_exec_sharded_async) or torch.distributed")
+    ap.add_argument("--exchange-depth", type=int, default=2, choices=[1, 2, 3, 4],
+                    help="count exchanges that may be pending (c-abi communicator): the host collects step k - depth before it enqueues step k")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -261,8 +263,8 @@ def main():
         k = steps_done[0] & 1
         steps_done[0] += 1
         if comm:
-            # at most two exchanges in flight: the one of two steps ago is collected before the next is enqueued
-            if pending[0] == 2:
+            # at most `--exchange-depth` exchanges in flight: the oldest is collected before the next step is enqueued
+            if pending[0] == args.exchange_depth:
                 last_result[0] = be.exec_sharded_wait(comm)
                 pending[0] -= 1
             be.exec_sharded_async(frame, opt, comm)
