@@ -34,6 +34,8 @@ def gen(seed):
     r = random.Random(seed)
     s = Script()
     nf, ni, nh, nna = r.randint(1, 10), r.randint(0, 3), r.randint(0, 2), r.randint(0, 1)
+    if seed % 2 == 0 and seed % 5 != 0 and seed % 3 != 0:
+        nf, ni, nh = r.randint(1, 5), r.randint(0, 1), 0
     if seed % 5 == 0:
         nf = r.randint(17, 48)                  # every stream is in a register from the top of the tile: the big-register kernels
     fvals = [s.input(0, FLOAT, i) for i in range(nf)]
@@ -57,6 +59,10 @@ def gen(seed):
     def fsrc():
         return s.const(r.randint(1, 4)) if r.random() < 0.2 else r.choice(fvals)
     n_ops = r.randint(3, 60)
+    small = seed % 2 == 0 and seed % 5 != 0 and seed % 3 != 0      # short scripts over few streams: most of these fit the light eight-wide kernel
+    if small:
+        n_ops = r.randint(2, 9)
+    gen.small = small
     for k in range(n_ops):
         if k == pred_at:
             s.acquireindex(r.choice(masks) if masks and r.random() < 0.7 else s.const(0), 0)
@@ -211,9 +217,12 @@ def main():
                 got_ids = want_ids.copy()
             more = [dts1] if dts1 else []
             ref_more, got_more = [], []
-            ref = run_oracle(built, [consts], ins, dts, n, seed=seed, instance_offset=offset, more_datasets=more, more_results=ref_more, ext_fns=list(gen.ext), ids=want_ids)
-            got = run_hip(built, [consts], ins, dts, n, seed=seed, instance_offset=offset, flags=(0, abi.VVM_EXEC_FORCE_EIGHT_WIDE, abi.VVM_EXEC_SEPARATE_PASSES, abi.VVM_EXEC_FORCE_EIGHT_WIDE | abi.VVM_EXEC_NO_LIGHT_KERNEL)[seed % 4],
-                          more_datasets=more, more_results=got_more, ext_fns=list(gen.ext), ids=got_ids)
+            # every eleventh script draws from the reference's own generator (vvm_exec_options.RandXorwowState) instead of the counter-based
+            # one; scripts that acquire two datasets in one pass have no kernel for it and keep the counter-based generator
+            xorwow = [(seed * 2654435761 + 97 * k) & 0xFFFFFFFF for k in range(24)] if seed % 11 == 0 and not dts1 else None
+            ref = run_oracle(built, [consts], ins, dts, n, seed=seed, instance_offset=offset, more_datasets=more, more_results=ref_more, ext_fns=list(gen.ext), ids=want_ids, xorwow=xorwow)
+            got = run_hip(built, [consts], ins, dts, n, seed=seed, instance_offset=offset, flags=(0, abi.VVM_EXEC_FORCE_EIGHT_WIDE, abi.VVM_EXEC_SEPARATE_PASSES, abi.VVM_EXEC_FORCE_EIGHT_WIDE | abi.VVM_EXEC_NO_LIGHT_KERNEL)[(seed // 2) % 4 if gen.small else seed % 4],
+                          more_datasets=more, more_results=got_more, ext_fns=list(gen.ext), ids=got_ids, xorwow=xorwow)
         except abi.VVMError as e:
             if e.code == abi.VVM_E_TOO_LARGE:
                 skipped += 1
@@ -222,6 +231,13 @@ def main():
         info = got[2]
         key = (info.InstancesPerLane, info.NumVirtualRegisters > 16, info.LdsSpillRegisters > 0)
         shapes[key] = shapes.get(key, 0) + 1
+        if got[2].Flags & 0x20000 and ((seed // 2) % 4 if gen.small else seed % 4) == 1:
+            shapes["ran on the light kernel"] = shapes.get("ran on the light kernel", 0) + 1
+        for bit, name in ((0x20000, "fits the light kernel"), (0x40000, "two chains in one pass")):
+            if info.Flags & bit:
+                shapes[name] = shapes.get(name, 0) + 1
+        if xorwow is not None:
+            shapes["reference generator"] = shapes.get("reference generator", 0) + 1
         ok = got[1] == ref[1]
         for k in range(len(dts)):
             if not ok:
