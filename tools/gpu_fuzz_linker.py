@@ -2,8 +2,9 @@
 """usage: gpu_fuzz_linker.py <first seed> <last seed>   (on a GPU box)  random scripts written straight in the optimized format
 (renderer_amd.assembler), wider than the optimizer fuzz: up to 60 instructions over float / int32 / half / no-advance inputs, merged
 opcodes, two-output ops, the bit-exact transcendentals, exec_index, random, up to 24 outputs of three kinds (several staging groups),
-many values alive at once (the 32-register kernels, LDS register slots, the one-instance-per-lane kernel).  Each script runs on
-libvvm_hip.so and on the CPU oracle; results must agree bit for bit (NaN payloads aside)."""
+many values alive at once (the 32-register kernels, LDS register slots, the one-instance-per-lane kernel), short scripts that fit the
+light kernel, the reference's random generator, Execs inside a vvm_exec_batch call.  Each script runs on libvvm_hip.so and on the CPU
+oracle; results must agree bit for bit (NaN payloads aside)."""
 import os
 import random
 import sys
@@ -191,9 +192,39 @@ def gen(seed):
     return s.build(alias_outputs=r.random() < 0.5), nf + nna, ni, nh, dts
 
 
+class Neighbours:
+    """Four fountain emitters (one large enough to run on the light kernel inside a batch) that share a vvm_exec_batch call with every
+    thirteenth script; their own results are checked after each such call."""
+
+    def __init__(self):
+        from renderer_amd import scripts
+        from renderer_amd.runtime import VectorVMState
+        from test_gpu_more import _DeviceStreams
+        self.be = abi.load_hip_backend()
+        self.frames, self.states, self.streams, self.refs = [], [], [], []
+        for e, n in enumerate((3000, 9001, 4022, 1)):
+            w = scripts.fountain(variant=e)
+            ins = scripts.fountain_streams_np(e * 7777, n, kill_half=True)
+            self.refs.append(run_oracle(w.script, [w.constants], ins, [f32] * 8, n))
+            ds = _DeviceStreams(self.be, ins, 8, n)
+            st = VectorVMState(w.script.blob, self.be)
+            self.streams.append(ds); self.states.append(st)
+            self.frames.append(st.frame([abi.DataSet(ds.ins, ds.outs, 0)], n, [w.constants]))
+
+    def check(self):
+        for e, (ref, ref_n, _) in enumerate(self.refs):
+            if self.frames[e].survivors(0) != ref_n:
+                return False
+            for k in range(8):
+                if not np.array_equal(self.streams[e].download(k)[:ref_n].view(np.uint32), ref[k][:ref_n].view(np.uint32)):
+                    return False
+        return True
+
+
 def main():
     bad = skipped = 0
     shapes = {}
+    neighbours = Neighbours()
     for seed in range(int(sys.argv[1]), int(sys.argv[2])):
         try:
             built, nf, ni, nh, dts = gen(seed)
@@ -220,9 +251,11 @@ def main():
             # every eleventh script draws from the reference's own generator (vvm_exec_options.RandXorwowState) instead of the counter-based
             # one; scripts that acquire two datasets in one pass have no kernel for it and keep the counter-based generator
             xorwow = [(seed * 2654435761 + 97 * k) & 0xFFFFFFFF for k in range(24)] if seed % 11 == 0 and not dts1 else None
+            in_batch = seed % 13 == 0 and xorwow is None
             ref = run_oracle(built, [consts], ins, dts, n, seed=seed, instance_offset=offset, more_datasets=more, more_results=ref_more, ext_fns=list(gen.ext), ids=want_ids, xorwow=xorwow)
             got = run_hip(built, [consts], ins, dts, n, seed=seed, instance_offset=offset, flags=(0, abi.VVM_EXEC_FORCE_EIGHT_WIDE, abi.VVM_EXEC_SEPARATE_PASSES, abi.VVM_EXEC_FORCE_EIGHT_WIDE | abi.VVM_EXEC_NO_LIGHT_KERNEL)[(seed // 2) % 4 if gen.small else seed % 4],
-                          more_datasets=more, more_results=got_more, ext_fns=list(gen.ext), ids=got_ids, xorwow=xorwow)
+                          more_datasets=more, more_results=got_more, ext_fns=list(gen.ext), ids=got_ids, xorwow=xorwow,
+                          batch_with=neighbours.frames if in_batch else None)
         except abi.VVMError as e:
             if e.code == abi.VVM_E_TOO_LARGE:
                 skipped += 1
@@ -238,6 +271,8 @@ def main():
                 shapes[name] = shapes.get(name, 0) + 1
         if xorwow is not None:
             shapes["reference generator"] = shapes.get("reference generator", 0) + 1
+        if in_batch:
+            shapes["inside a batch"] = shapes.get("inside a batch", 0) + 1
         ok = got[1] == ref[1]
         for k in range(len(dts)):
             if not ok:
@@ -263,6 +298,9 @@ def main():
                 x, y = got_more[0][0][k][offset:offset + m].view(np.uint32), ref_more[0][0][k][offset:offset + m].view(np.uint32)
                 nan = np.isnan(x.view(f32)) & np.isnan(y.view(f32)) if dt == f32 else np.zeros(m, bool)
                 ok = np.array_equal(x[~nan], y[~nan])
+        if ok and in_batch and not neighbours.check():
+            ok = False
+            print("seed", seed, "the neighbours of the batch differ", flush=True)
         if not ok:
             bad += 1
             print("seed", seed, "MISMATCH (survivors %d / %d)" % (got[1], ref[1]), "vregs", info.NumVirtualRegisters, "width", info.InstancesPerLane, flush=True)
