@@ -937,7 +937,7 @@ static int exec_enqueue(vvm_exec_context* ctx, const vvm_exec_options* opt, bool
 		rc = ensure_status(st, pe.tiles * pe.lp->num_chains);      // (every chain has look-back words of its own)
 		if (rc != VVM_OK) return rc;
 	}
-	unsigned long long* const d_status = no_alloc ? (unsigned long long*)(scratch_ptr + VVM_NOALLOC_STATUS_OFF) : st->d_status;
+	unsigned long long* d_status = no_alloc ? (unsigned long long*)(scratch_ptr + VVM_NOALLOC_STATUS_OFF) : st->d_status;
 	st->cur_status = d_status;
 	st->cur_status_words = no_alloc ? (size_t)VVM_NOALLOC_MAX_TILES : (size_t)st->status_capacity;
 	const bool timed = st->timing && st->ev_used < 4096 && (!no_alloc || st->ev_used < st->ev_start.size());      // (no new events without allocating)
@@ -966,6 +966,20 @@ static int exec_enqueue(vvm_exec_context* ctx, const vvm_exec_options* opt, bool
 		if (pass != 0) {
 			rc = prepare(st, ctx, opt, pe, pass);
 			if (rc != VVM_OK) return rc;
+			// A later pass may run on a kernel with smaller tiles than the first (each pass is linked for what its own dataset needs:
+			// one may fit four instances per lane where another takes one), so it can have more tiles, and more look-back words.
+			if (no_alloc) {
+				if ((uint64_t)pe.tiles * pe.lp->num_chains > VVM_NOALLOC_MAX_TILES)
+					return fail(VVM_E_TOO_LARGE, "vvm_exec_noalloc: a pass of the script has more tiles than the scratch array holds look-back words for");
+			} else {
+				if ((uint64_t)pe.tiles * pe.lp->num_chains > 0xFFFFFFFFull) return fail(VVM_E_TOO_LARGE, "too many tiles");
+				rc = ensure_status(st, pe.tiles * pe.lp->num_chains);
+				if (rc != VVM_OK) return rc;
+				d_status = st->d_status;
+				st->last_width = pe.instances_per_lane;
+				st->cur_status = d_status;
+				st->cur_status_words = (size_t)st->status_capacity;
+			}
 		}
 		if (pe.lp->updates_ids) {      // (one update_id per pass, and the passes follow each other on the stream: they share one piece of the buffers)
 			rc = ensure_id_buffers(st, 1, pe.num_chunks, (uint32_t)ctx->NumInstances, stream);
@@ -988,7 +1002,7 @@ static int exec_enqueue(vvm_exec_context* ctx, const vvm_exec_options* opt, bool
 			if (rc != VVM_OK) return rc;
 			rc = st->ring.acquire(slot);
 			if (rc != VVM_OK) return rc;
-			rc = fill_params(st, ctx, opt, pe, st->ring.host[slot], st->ring.dev[slot], st->d_status, 0);
+			rc = fill_params(st, ctx, opt, pe, st->ring.host[slot], st->ring.dev[slot], d_status, 0);
 			if (rc != VVM_OK) return rc;
 			HIP_TRY(hipMemcpyAsync(st->ring.dev[slot], st->ring.host[slot], pe.bytes, hipMemcpyHostToDevice, stream));
 		}

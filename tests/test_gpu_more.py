@@ -476,6 +476,45 @@ def test_two_datasets_match_the_oracle(n, secondary_first, many, mode, monkeypat
     assert got_n == len(d0[0]) and m == len(d1[0])
 
 
+def test_a_later_pass_with_smaller_tiles_gets_its_own_look_back_words():
+    """Dataset 0 needs two values, dataset 1 fifty at once: the first program runs four instances per lane, the second one, so the
+    second pass has four times the tiles.  Its look-back words are sized for it (sized for the first pass they ended 148 words short
+    here, and the words past the end landed in whatever lay behind the array)."""
+    s = Script()
+    xs = [s.input(0, FLOAT, i) for i in range(50)]
+    k0, k1 = s.temps(2)
+    s.op("cmplt", xs[0], s.const(1), k0)
+    s.acquireindex(k0, 0)
+    s.output_data(FLOAT, 0, [(xs[1], s.output(0, FLOAT, 0))])
+    s.op("cmplt", xs[1], s.const(2), k1)
+    s.acquireindex(k1, 1)
+    prods = []
+    for x in xs:
+        t = s.temp()
+        s.op("mul", x, s.const(3), t)
+        prods.append(t)
+    acc = s.temp()
+    s.op("add", prods[0], prods[1], acc)
+    for t in prods[2:]:
+        s.op("add", acc, t, acc)
+    s.output_data(FLOAT, 1, [(acc, s.output(1, FLOAT, 0)), (prods[49], s.output(1, FLOAT, 1))])
+    built = s.build()
+    n = 300_000
+    rng = np.random.default_rng(5)
+    ins = [rng.random(n).astype(f32) for _ in range(50)]
+    consts = [ALL_ONES[:4] + np.array([0.5, 0.7, 1.25], f32).tobytes()]
+    for flags in (0, abi.VVM_EXEC_SEPARATE_PASSES):
+        ref_more, got_more, widths = [], [], []
+        ref, ref_n, _ = run_oracle(built, consts, ins, [f32], n, more_datasets=[[f32, f32]], more_results=ref_more)
+        got, got_n, info = run_hip(built, consts, ins, [f32], n, more_datasets=[[f32, f32]], more_results=got_more, flags=flags, last_width=widths)
+        assert info.InstancesPerLane == 4 and widths == [1]      # the first pass's program, the kernel of the last launch
+        assert got_n == ref_n and got_more[0][1] == ref_more[0][1] and 0 < got_n < n
+        assert np.array_equal(_bits(got[0][:got_n]), _bits(ref[0][:ref_n]))
+        m = got_more[0][1]
+        for a, b in zip(got_more[0][0], ref_more[0][0]):
+            assert np.array_equal(a[:m].view(np.uint32), b[:m].view(np.uint32))
+
+
 def test_internal_fields_follow_the_reference_chunking():
     """ctx->Internal.* is what the reference's chunking computes for the Exec (VectorVMRuntime.cpp:2210-2261), at any page size."""
     w = scripts.fountain(alias_outputs=False)

@@ -100,8 +100,10 @@ def run_hip(script: BuiltScript, const_tables: Sequence[bytes], inputs: Sequence
             out_fill: int = 0xCD, repeat: int = 1, ids: Optional[IdState] = None, page_kb: int = 64,
             more_datasets: Sequence[Sequence] = (), more_results: Optional[list] = None,
             batch_with: Optional[Sequence] = None, device_counts: Optional[list] = None,
-            more_ids: Sequence[Optional[IdState]] = (), xorwow: Optional[Sequence[int]] = None) -> Tuple[List[np.ndarray], int, abi.ProgramInfo]:
-    """Same contract as run_oracle, through the C ABI of libvvm_hip.so with streams in device memory.
+            more_ids: Sequence[Optional[IdState]] = (), xorwow: Optional[Sequence[int]] = None,
+            last_width: Optional[list] = None) -> Tuple[List[np.ndarray], int, abi.ProgramInfo]:
+    """last_width: a list; the instances per lane of the kernel the Exec's last launch ran on is appended to it.
+    Same contract as run_oracle, through the C ABI of libvvm_hip.so with streams in device memory.
     batch_with: call frames of other emitters; the Exec then runs as the middle member of one vvm_exec_batch call with them.
     device_counts: a list; the Exec gets a buffer of eight ints (filled with -1) as vvm_exec_options.DeviceCounts, whose contents
     after the Exec are appended to the list."""
@@ -183,6 +185,8 @@ def run_hip(script: BuiltScript, const_tables: Sequence[bytes], inputs: Sequence
                     be.exec_batch(others[:half] + [frame] + others[half:], [plain] * half + [opt] + [plain] * (len(others) - half))
             surv = frame.survivors(0)
             info = be.info(state)
+            if last_width is not None:
+                last_width.append(int(L.vvm_state_last_exec_width(state)))
             if device_counts is not None:
                 h = np.empty(8, dtype=np.int32)
                 be._check(L.vvm_device_download(h.ctypes.data, opt.DeviceCounts, h.nbytes), "download")
