@@ -25,6 +25,8 @@ def main():
     n = (seed // 7) % 10 if seed % 7 == 0 else 2048 + 1 + (seed * 37) % 3000
     if g.LARGE and seed % 17 == 0 and seed % 7 != 0:
         n = 200_000 + (seed * 7919) % 400_000
+    if g.LARGE and seed % 97 == 0 and seed % 7 != 0:
+        n = 1_200_000 + (seed * 7919) % 2_000_000
     offset = 1 + seed % 9 if seed % 3 == 0 else 0
     rng = np.random.default_rng(seed)
     ins = [rng.uniform(-3, 3, max(n, 1)).astype(f32) for _ in range(nf)] + [rng.integers(-20, 20, max(n, 1)).astype(np.int32) for _ in range(ni)] + \

@@ -242,6 +242,8 @@ def main():
         n = (seed // 7) % 10 if seed % 7 == 0 else 2048 + 1 + (seed * 37) % 3000          # (some tiny Execs, empty ones included)
         if LARGE and seed % 17 == 0 and seed % 7 != 0:
             n = 200_000 + (seed * 7919) % 400_000         # hundreds to thousands of tiles: the eight-wide kernels by the library's own choice, several tiles per workgroup
+        if LARGE and seed % 97 == 0 and seed % 7 != 0:
+            n = 1_200_000 + (seed * 7919) % 2_000_000     # more tiles than resident workgroups on every kernel
         offset = 1 + seed % 9 if seed % 3 == 0 else 0                                        # InstanceOffset
         rng = np.random.default_rng(seed)
         ins = [rng.uniform(-3, 3, max(n, 1)).astype(f32) for _ in range(nf)] + [rng.integers(-20, 20, max(n, 1)).astype(np.int32) for _ in range(ni)] + \
