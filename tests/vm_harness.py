@@ -101,8 +101,9 @@ def run_hip(script: BuiltScript, const_tables: Sequence[bytes], inputs: Sequence
             more_datasets: Sequence[Sequence] = (), more_results: Optional[list] = None,
             batch_with: Optional[Sequence] = None, device_counts: Optional[list] = None,
             more_ids: Sequence[Optional[IdState]] = (), xorwow: Optional[Sequence[int]] = None,
-            last_width: Optional[list] = None) -> Tuple[List[np.ndarray], int, abi.ProgramInfo]:
-    """last_width: a list; the instances per lane of the kernel the Exec's last launch ran on is appended to it.
+            last_width: Optional[list] = None, no_alloc: bool = False) -> Tuple[List[np.ndarray], int, abi.ProgramInfo]:
+    """no_alloc: the Exec goes through vvm_exec_noalloc (a refusal raises VVMError like any other).
+    last_width: a list; the instances per lane of the kernel the Exec's last launch ran on is appended to it.
     Same contract as run_oracle, through the C ABI of libvvm_hip.so with streams in device memory.
     batch_with: call frames of other emitters; the Exec then runs as the middle member of one vvm_exec_batch call with them.
     device_counts: a list; the Exec gets a buffer of eight ints (filled with -1) as vvm_exec_options.DeviceCounts, whose contents
@@ -176,7 +177,9 @@ def run_hip(script: BuiltScript, const_tables: Sequence[bytes], inputs: Sequence
                 be._check(L.vvm_device_memset(p, 0xFF, 32), "memset")
                 opt.DeviceCounts = p
             for _ in range(repeat):
-                if batch_with is None:
+                if no_alloc:
+                    be.exec_noalloc(frame, opt)
+                elif batch_with is None:
                     be.exec_ex(frame, opt)
                 else:
                     others = list(batch_with)

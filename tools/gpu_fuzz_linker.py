@@ -264,10 +264,25 @@ def main():
             # one; scripts that acquire two datasets in one pass have no kernel for it and keep the counter-based generator
             xorwow = [(seed * 2654435761 + 97 * k) & 0xFFFFFFFF for k in range(24)] if seed % 11 == 0 and not dts1 else None
             in_batch = seed % 13 == 0 and xorwow is None
+            # every nineteenth script goes through vvm_exec_noalloc where that entry point takes it (no ID instructions, a parameter
+            # block of at most 1 KB, no injected generator state); a refusal for one of those reasons sends it through vvm_exec_ex
+            no_alloc = seed % 19 == 0 and not in_batch and xorwow is None and not gen.with_ids
             ref = run_oracle(built, [consts], ins, dts, n, seed=seed, instance_offset=offset, more_datasets=more, more_results=ref_more, ext_fns=list(gen.ext), ids=want_ids, xorwow=xorwow)
-            got = run_hip(built, [consts], ins, dts, n, seed=seed, instance_offset=offset, flags=(0, abi.VVM_EXEC_FORCE_EIGHT_WIDE, abi.VVM_EXEC_SEPARATE_PASSES, abi.VVM_EXEC_FORCE_EIGHT_WIDE | abi.VVM_EXEC_NO_LIGHT_KERNEL)[(seed // 2) % 4 if gen.small else seed % 4],
-                          more_datasets=more, more_results=got_more, ext_fns=list(gen.ext), ids=got_ids, xorwow=xorwow,
-                          batch_with=neighbours.frames if in_batch else None)
+            hip_flags = (0, abi.VVM_EXEC_FORCE_EIGHT_WIDE, abi.VVM_EXEC_SEPARATE_PASSES, abi.VVM_EXEC_FORCE_EIGHT_WIDE | abi.VVM_EXEC_NO_LIGHT_KERNEL)[(seed // 2) % 4 if gen.small else seed % 4]
+            if seed % 23 == 0:
+                hip_flags |= abi.VVM_EXEC_PARAMS_IN_MEMORY
+            if no_alloc:
+                try:
+                    got = run_hip(built, [consts], ins, dts, n, seed=seed, instance_offset=offset, flags=hip_flags, more_datasets=more, more_results=got_more,
+                                  ext_fns=list(gen.ext), no_alloc=True)
+                except abi.VVMError as e:
+                    if e.code not in (abi.VVM_E_TOO_LARGE, abi.VVM_E_UNSUPPORTED_OP):
+                        raise
+                    no_alloc = False
+                    got_more.clear()
+            if not no_alloc:
+                got = run_hip(built, [consts], ins, dts, n, seed=seed, instance_offset=offset, flags=hip_flags, more_datasets=more, more_results=got_more,
+                              ext_fns=list(gen.ext), ids=got_ids, xorwow=xorwow, batch_with=neighbours.frames if in_batch else None)
         except abi.VVMError as e:
             if e.code == abi.VVM_E_TOO_LARGE:
                 skipped += 1
@@ -285,6 +300,8 @@ def main():
             shapes["reference generator"] = shapes.get("reference generator", 0) + 1
         if in_batch:
             shapes["inside a batch"] = shapes.get("inside a batch", 0) + 1
+        if no_alloc:
+            shapes["through vvm_exec_noalloc"] = shapes.get("through vvm_exec_noalloc", 0) + 1
         if n >= 200_000:
             shapes["200 K instances or more"] = shapes.get("200 K instances or more", 0) + 1
         ok = got[1] == ref[1]
