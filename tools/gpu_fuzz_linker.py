@@ -211,6 +211,12 @@ class Neighbours:
             self.streams.append(ds); self.states.append(st)
             self.frames.append(st.frame([abi.DataSet(ds.ins, ds.outs, 0)], n, [w.constants]))
 
+    def close(self):
+        for st in self.states:
+            st.close()
+        for ds in self.streams:
+            ds.free()
+
     def check(self):
         for e, (ref, ref_n, _) in enumerate(self.refs):
             if self.frames[e].survivors(0) != ref_n:
@@ -229,11 +235,12 @@ if LARGE:
     sys.argv.remove("--large")
 
 
-def main():
+def run(first_seed, last_seed, report_every=100):
+    """Seeds [first_seed, last_seed): returns (scripts that differed from the oracle, scripts skipped as too large, counts per kind)."""
     bad = skipped = 0
     shapes = {}
     neighbours = Neighbours()
-    for seed in range(int(sys.argv[1]), int(sys.argv[2])):
+    for seed in range(first_seed, last_seed):
         try:
             built, nf, ni, nh, dts = gen(seed)
         except AssertionError:
@@ -337,8 +344,14 @@ def main():
         if not ok:
             bad += 1
             print("seed", seed, "MISMATCH (survivors %d / %d)" % (got[1], ref[1]), "vregs", info.NumVirtualRegisters, "width", info.InstancesPerLane, flush=True)
-        if seed % 100 == 0:
+        if report_every and seed % report_every == 0:
             print("seed", seed, "failures so far", bad, "skipped", skipped, "kernel shapes", shapes, flush=True)
+    neighbours.close()
+    return bad, skipped, shapes
+
+
+def main():
+    bad, skipped, shapes = run(int(sys.argv[1]), int(sys.argv[2]))
     print("done: failures", bad, "skipped", skipped, "kernel shapes (instances per lane, more than 16 registers, LDS registers):", shapes)
     sys.exit(1 if bad else 0)
 
