@@ -101,8 +101,9 @@ def run_hip(script: BuiltScript, const_tables: Sequence[bytes], inputs: Sequence
             more_datasets: Sequence[Sequence] = (), more_results: Optional[list] = None,
             batch_with: Optional[Sequence] = None, device_counts: Optional[list] = None,
             more_ids: Sequence[Optional[IdState]] = (), xorwow: Optional[Sequence[int]] = None,
-            last_width: Optional[list] = None, no_alloc: bool = False) -> Tuple[List[np.ndarray], int, abi.ProgramInfo]:
-    """no_alloc: the Exec goes through vvm_exec_noalloc (a refusal raises VVMError like any other).
+            last_width: Optional[list] = None, no_alloc: bool = False, batch_handle: bool = False) -> Tuple[List[np.ndarray], int, abi.ProgramInfo]:
+    """batch_handle (with batch_with): the batch runs through a vvm_batch handle, twice (the second call finds everything in place).
+    no_alloc: the Exec goes through vvm_exec_noalloc (a refusal raises VVMError like any other).
     last_width: a list; the instances per lane of the kernel the Exec's last launch ran on is appended to it.
     Same contract as run_oracle, through the C ABI of libvvm_hip.so with streams in device memory.
     batch_with: call frames of other emitters; the Exec then runs as the middle member of one vvm_exec_batch call with them.
@@ -185,7 +186,17 @@ def run_hip(script: BuiltScript, const_tables: Sequence[bytes], inputs: Sequence
                     others = list(batch_with)
                     half = len(others) // 2
                     plain = abi.ExecOptions(0, 0, 0, None, 0)
-                    be.exec_batch(others[:half] + [frame] + others[half:], [plain] * half + [opt] + [plain] * (len(others) - half))
+                    members, their_opts = others[:half] + [frame] + others[half:], [plain] * half + [opt] + [plain] * (len(others) - half)
+                    if batch_handle:
+                        arr, oarr = be.pack_batch(members, their_opts)
+                        handle = be.batch_create(arr, oarr)
+                        try:
+                            be.batch_exec(handle, 0)
+                            be.batch_exec(handle, 0)
+                        finally:
+                            be.batch_destroy(handle)
+                    else:
+                        be.exec_batch(members, their_opts)
             surv = frame.survivors(0)
             info = be.info(state)
             if last_width is not None:

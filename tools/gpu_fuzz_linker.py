@@ -289,7 +289,8 @@ def run(first_seed, last_seed, report_every=100):
                     got_more.clear()
             if not no_alloc:
                 got = run_hip(built, [consts], ins, dts, n, seed=seed, instance_offset=offset, flags=hip_flags, more_datasets=more, more_results=got_more,
-                              ext_fns=list(gen.ext), ids=got_ids, xorwow=xorwow, batch_with=neighbours.frames if in_batch else None)
+                              ext_fns=list(gen.ext), ids=got_ids, xorwow=xorwow, batch_with=neighbours.frames if in_batch else None,
+                              batch_handle=in_batch and seed % 26 == 0 and not gen.with_ids)      # (an ID script's tables take one Exec: the handle runs two)
         except abi.VVMError as e:
             if e.code == abi.VVM_E_TOO_LARGE:
                 skipped += 1
@@ -307,6 +308,8 @@ def run(first_seed, last_seed, report_every=100):
             shapes["reference generator"] = shapes.get("reference generator", 0) + 1
         if in_batch:
             shapes["inside a batch"] = shapes.get("inside a batch", 0) + 1
+            if seed % 26 == 0 and not gen.with_ids:
+                shapes["... kept in a vvm_batch handle"] = shapes.get("... kept in a vvm_batch handle", 0) + 1
         if no_alloc:
             shapes["through vvm_exec_noalloc"] = shapes.get("through vvm_exec_noalloc", 0) + 1
         if n >= 200_000:
