@@ -1329,3 +1329,10 @@ ORACLE_API void     vvm_oracle_curl_noise3(float x, float y, float z, float* o) 
 ORACLE_API uint32_t vvm_oracle_rand_u32(uint64_t seed, uint32_t instance, uint32_t ordinal) { return rand_u32(seed, instance, ordinal); }
 ORACLE_API uint16_t vvm_oracle_store_half(float f) { return store_half(f); }
 ORACLE_API float    vvm_oracle_load_half(uint16_t h) { return load_half(h); }
+/* the compaction tables the output instructions shuffle by, for the test that compares them with the reference's own
+ * (VVM_PSHUFB_OUTPUT_TABLE, _TABLE16 and the two advance tables, VectorVMRuntime.cpp:132-186): 256 + 256 + 16 + 16 bytes */
+ORACLE_API void     vvm_oracle_compaction_tables(uint8_t* shuf32, uint8_t* shuf16, uint8_t* adv32, uint8_t* adv16)
+{
+	build_tables();
+	memcpy(shuf32, g_shuf32, 256); memcpy(shuf16, g_shuf16, 256); memcpy(adv32, g_adv32, 16); memcpy(adv16, g_adv16, 16);
+}
