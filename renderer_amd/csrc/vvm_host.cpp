@@ -151,6 +151,14 @@ struct vvm_state {
 	std::vector<vvm::LinkedProgram> wide_more, narrow_more;
 	std::vector<VvmIns*> d_code_wide_more, d_code_narrow_more;
 
+	// A script whose record is too wide for the register file of the eight-wide kernels, but whose extra width is streams that it
+	// hands through unchanged, also has this form: programs for the light eight-wide kernel that each write a part of the outputs
+	// (the first everything the script computes, the others up to six handed-through streams each; every one repeats the
+	// acquireindex and what it depends on).  A large Exec runs them one after the other over the same instances.
+	std::vector<vvm::LinkedProgram> slices;
+	std::vector<VvmIns*> d_code_slices;
+	bool slices_ready = false;
+
 	VvmIns* d_code_wide = nullptr;
 	VvmIns* d_code_narrow = nullptr;
 	uint8_t* d_perlin = nullptr;
@@ -261,6 +269,8 @@ struct PreparedExec {
 	uint32_t instances_per_lane = 4;                   // of the kernel this Exec runs on (8, 4 or 1)
 	bool light = false;                                // ... the light eight-wide kernel
 	bool in_batch = false;                             // set by the caller: the Exec is a member of a batch (decides the kernel of small Execs, see prepare)
+	bool whole_only = false;                           // set by the caller: never the sliced form of the script (vvm_exec_noalloc)
+	uint32_t sliced = 0;                               // not 0: the Exec runs the state's sliced form, this many programs one after the other
 	uint32_t id_buffers = 0;                           // which piece of the state's update_id buffers this pass works in (fused passes run together)
 	bool reference_random = false;                     // the Exec's random ops read the reference generator's words (then it runs on a FULL kernel)
 	bool full() const { return lp->full_kernel || reference_random; }
@@ -317,6 +327,57 @@ int link_more_passes(const vvm::ThawedScript& s, bool narrow, const vvm::LinkedP
 	return VVM_OK;
 }
 
+// The sliced form of a script (vvm_state::slices), where it pays: the whole script needs more than the sixteen per-lane registers
+// of the eight-wide kernels (every stream it reads sits in one from the top of a tile), at least two of its outputs hand a 32-bit
+// input stream through unchanged, and without those the script fits the light eight-wide kernel.  The handed-through outputs then
+// go into programs of their own, as many per program as the light kernel takes beside the streams the acquireindex depends on
+// (at most six: the outputs it stages), and the state keeps the form when all programs together move at most 25 % more stream
+// bytes than the script as a whole (every program reads the acquireindex's streams again).  Not built is not an error.
+int plan_slices(vvm_state* st)
+{
+	const vvm::LinkedProgram& w = st->wide;
+	if (getenv("VVM_NO_SLICES")) return VVM_OK;
+	if (st->light_ready || w.num_passes != 1 || w.num_chains != 1 || w.uses_ids || w.full_kernel || w.acquire_order.size() != 1) return VVM_OK;
+	if (!(w.many_registers || w.instances_per_lane == 1)) return VVM_OK;
+	const size_t O = w.through_input.size();
+	std::vector<uint32_t> through;
+	for (size_t o = 0; o < O; ++o) {
+		if (w.through_input[o] == -2) return VVM_OK;
+		if (w.through_input[o] >= 0) through.push_back((uint32_t)o);
+	}
+	// (measured on the fountain update with 10 / 12 / 16 / 24 / 32 handed-through attributes, 32 Mi instances: the sliced form takes
+	// 0.98 / 1.20 / 1.33 / 1.89 / 2.28 ms, the whole script 1.29 / 1.33 / 1.44 / 1.78 / 2.17 ms: every further program costs a launch
+	// and another reading of the acquireindex's streams, so the form is kept up to four programs)
+	if (through.size() < 2 || through.size() > 18) return VVM_OK;
+	std::string why;
+	for (size_t per = 6; per >= 3; --per) {
+		std::vector<vvm::LinkedProgram> progs(1 + (through.size() + per - 1) / per);
+		std::vector<uint8_t> select(O, 0);
+		for (size_t o = 0; o < O; ++o) select[o] = w.through_input[o] < 0;
+		bool ok = vvm::link_program(st->script, false, progs[0], why, 0, true, &select) == VVM_OK;
+		size_t bytes_in = ok ? progs[0].bytes_in_per_instance : 0;
+		for (size_t k = 1; ok && k < progs.size(); ++k) {
+			std::fill(select.begin(), select.end(), 0);
+			for (size_t j = (k - 1) * per; j < std::min(through.size(), k * per); ++j) select[through[j]] = 1;
+			ok = vvm::link_program(st->script, false, progs[k], why, 0, true, &select) == VVM_OK;
+			// (a program that stages more than six outputs would let two of them wait in registers: not for plain copies)
+			if (ok) for (size_t q = VVM_LIGHT_GROUP_SLOTS; q < progs[k].out_list.size(); ++q) ok = ok && progs[k].out_list[q] == -1;
+			if (ok) bytes_in += progs[k].bytes_in_per_instance;
+		}
+		if (!ok) continue;
+		if ((bytes_in + w.bytes_out_per_instance) * 4 > ((size_t)w.bytes_in_per_instance + w.bytes_out_per_instance) * 5) return VVM_OK;
+		st->d_code_slices.assign(progs.size(), nullptr);
+		for (size_t k = 0; k < progs.size(); ++k) {
+			const int rc = upload_code(progs[k], &st->d_code_slices[k]);
+			if (rc != VVM_OK) return rc;
+		}
+		st->slices = std::move(progs);
+		st->slices_ready = true;
+		return VVM_OK;
+	}
+	return VVM_OK;
+}
+
 int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, PreparedExec& pe, uint32_t pass = 0)
 {
 	const vvm::ThawedScript& s = st->script;
@@ -329,6 +390,7 @@ int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, P
 	if (ctx->ConstantTableCount < 0 || (ctx->ConstantTableCount > 0 && (!ctx->ConstantTableNumBytes || !ctx->ConstantTableData)))
 		return fail(VVM_E_INVALID_ARG, "ConstantTableData / ConstantTableNumBytes is null");
 	const bool narrow = opt && (opt->Flags & VVM_EXEC_NO_VGPR_WIDE);
+	pe.light = false;
 	if (narrow && st->wide.instances_per_lane != 1) {
 		if (!st->narrow_ready) {
 			std::string err;
@@ -340,9 +402,13 @@ int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, P
 			if (rc != VVM_OK) return rc;
 			st->narrow_ready = true;
 		}
+		if (pass > st->narrow_more.size()) return fail(VVM_E_INVALID_ARG, "internal: pass index out of range");
 		pe.lp = pass ? &st->narrow_more[pass - 1] : &st->narrow; pe.d_code = pass ? st->d_code_narrow_more[pass - 1] : st->d_code_narrow;
 	} else {
-		pe.lp = pass ? &st->wide_more[pass - 1] : &st->wide; pe.d_code = pass ? st->d_code_wide_more[pass - 1] : st->d_code_wide;
+		// (passes 1.. of the sliced form of a script with one dataset have no program here: chosen further down)
+		const bool have = pass <= st->wide_more.size();
+		if (!have && !(st->slices_ready && pass < st->slices.size())) return fail(VVM_E_INVALID_ARG, "internal: pass index out of range");
+		pe.lp = !have ? &st->wide : pass ? &st->wide_more[pass - 1] : &st->wide; pe.d_code = !have ? st->d_code_wide : pass ? st->d_code_wide_more[pass - 1] : st->d_code_wide;
 	}
 	for (uint32_t i = 0; i < s.num_ext_fns; ++i) {
 		const vvm_ext_function* f = ctx->ExtFunctionTable.data[i];
@@ -356,6 +422,20 @@ int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, P
 	}
 	pe.instances_per_lane = pe.lp->instances_per_lane;
 	pe.reference_random = opt && opt->RandXorwowState && !st->wide.rand_draws.empty();
+	pe.sliced = 0;
+	{
+		// the sliced form: for a single Exec large enough that a launch per program pays (VVM_SLICES_MIN_INSTANCES)
+		const uint32_t flags = opt ? opt->Flags : 0;
+		const bool big = ctx->NumInstances >= VVM_SLICES_MIN_INSTANCES || (flags & VVM_EXEC_FORCE_EIGHT_WIDE);
+		if (st->slices_ready && !narrow && !pe.in_batch && !pe.whole_only && !pe.reference_random && big &&
+		    !(flags & (VVM_EXEC_NO_EIGHT_WIDE | VVM_EXEC_NO_LIGHT_KERNEL | VVM_EXEC_NO_SLICES)) && pass < st->slices.size()) {
+			pe.sliced = (uint32_t)st->slices.size();
+			pe.lp = &st->slices[pass];
+			pe.d_code = st->d_code_slices[pass];
+			pe.instances_per_lane = 8;
+			pe.light = true;
+		}
+	}
 	if (pe.reference_random) {
 		if (pe.in_batch) return fail(VVM_E_UNSUPPORTED_OP, "RandXorwowState: not available to the members of a batch");
 		if (pe.lp->num_chains > 1) return fail(VVM_E_UNSUPPORTED_OP, "RandXorwowState: not available to a script that acquires two datasets in one pass (set VVM_NO_CHAINS)");
@@ -367,7 +447,7 @@ int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, P
 		// eight instances per lane: the same program, twice the work per interpreted instruction; only worth it when there are
 		// enough tiles left to keep every CU busy for several rounds
 		const uint32_t flags = opt ? opt->Flags : 0;
-		const bool can = pe.lp->instances_per_lane == 4 && !pe.full() && !pe.lp->many_registers && !(flags & VVM_EXEC_NO_EIGHT_WIDE);
+		const bool can = !pe.sliced && pe.lp->instances_per_lane == 4 && !pe.full() && !pe.lp->many_registers && !(flags & VVM_EXEC_NO_EIGHT_WIDE);
 		// (the size of the Exec itself decides, also inside a batch: many small Execs measured faster four wide, 0.88 ms against
 		// 0.92 ms for 4096 Execs of 16 Ki instances)
 		// scripts that get by with eight registers have a program for the light eight-wide kernel (three workgroups per CU)
@@ -818,6 +898,7 @@ VVM_API vvm_state* vvm_alloc_state(const uint8_t* blob, size_t num_bytes)
 			st->light_ready = true;
 		}
 	}
+	if (plan_slices(st) != VVM_OK) { vvm_free_state(st); return nullptr; }
 	hipError_t e;
 	st->any_ids = st->wide.uses_ids;
 	st->const_table.reserve(st->script.num_consts);      // (filled by the first Exec; reserved here so that no Exec allocates for them)
@@ -861,6 +942,7 @@ VVM_API void vvm_free_state(vvm_state* st)
 	if (st->d_code_wide) (void)hipFree(st->d_code_wide);
 	if (st->d_code_narrow) (void)hipFree(st->d_code_narrow);
 	if (st->d_code_light) (void)hipFree(st->d_code_light);
+	for (VvmIns* p : st->d_code_slices) if (p) (void)hipFree(p);
 	for (VvmIns* p : st->d_code_wide_more) if (p) (void)hipFree(p);
 	for (VvmIns* p : st->d_code_narrow_more) if (p) (void)hipFree(p);
 	if (st->d_perlin) (void)hipFree(st->d_perlin);
@@ -898,6 +980,7 @@ static int exec_enqueue(vvm_exec_context* ctx, const vvm_exec_options* opt, bool
 			return fail(VVM_E_TOO_LARGE, "vvm_exec_noalloc: too many output datasets for the scratch array's count words");
 	}
 	PreparedExec pe;
+	pe.whole_only = no_alloc;
 	int rc = prepare(st, ctx, opt, pe);
 	if (rc != VVM_OK) return rc;
 	if (no_alloc && pe.reference_random) return fail(VVM_E_UNSUPPORTED_OP, "vvm_exec_noalloc: RandXorwowState needs a buffer sized per Exec");
@@ -953,8 +1036,8 @@ static int exec_enqueue(vvm_exec_context* ctx, const vvm_exec_options* opt, bool
 		rc = enqueue_reference_random(st, ctx, opt, pe, stream);
 		if (rc != VVM_OK) return rc;
 	}
-	const uint32_t num_passes = pe.lp->num_passes;
-	if (num_passes > 1 && !no_alloc && !(opt && (opt->Flags & VVM_EXEC_SEPARATE_PASSES))) {
+	const uint32_t num_passes = pe.sliced ? pe.sliced : pe.lp->num_passes;      // (the slices of a wide record run like the passes of several datasets)
+	if (num_passes > 1 && !pe.sliced && !no_alloc && !(opt && (opt->Flags & VVM_EXEC_SEPARATE_PASSES))) {
 		bool handled = false;
 		rc = enqueue_fused_passes(st, ctx, opt, num_passes, stream, d_launch, timed, handled);
 		if (rc != VVM_OK) return rc;
@@ -1642,6 +1725,7 @@ VVM_API int vvm_state_info(const vvm_state* st, vvm_program_info* out)
 	if (!st || !out) return fail(VVM_E_INVALID_ARG, "null argument");
 	fill_info(st->script, st->wide, out);
 	if (st->light_ready) out->Flags |= 0x20000u;
+	if (st->slices_ready) out->Flags |= 0x80000u | ((uint32_t)st->slices.size() << 24);
 	return VVM_OK;
 }
 

@@ -327,24 +327,26 @@ template <typename F> static void fold_compares_into_acquires(std::vector<Decode
 	}
 }
 
-static int link_program_as(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, std::string& err, uint32_t pass, bool light, bool allow_chains, bool& chains_failed);
+static int link_program_as(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, std::string& err, uint32_t pass, bool light, bool allow_chains, bool& chains_failed,
+                           const std::vector<uint8_t>* out_select);
 
-int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, std::string& err, uint32_t pass, bool light)
+int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, std::string& err, uint32_t pass, bool light, const std::vector<uint8_t>* out_select)
 {
 	// first as one pass with two chains, where the script has two acquired datasets; if the program then needs a kernel that
 	// has no second chain, as one pass per dataset
 	const bool try_chains = !light && !force_narrow && pass == 0 && !getenv("VVM_NO_CHAINS");
 	bool chains_failed = false;
-	int rc = link_program_as(s, force_narrow, lp, err, pass, light, try_chains, chains_failed);
+	int rc = link_program_as(s, force_narrow, lp, err, pass, light, try_chains, chains_failed, out_select);
 	if (chains_failed) {
 		lp = LinkedProgram();
 		err.clear();
-		rc = link_program_as(s, force_narrow, lp, err, pass, light, false, chains_failed);
+		rc = link_program_as(s, force_narrow, lp, err, pass, light, false, chains_failed, out_select);
 	}
 	return rc;
 }
 
-static int link_program_as(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, std::string& err, uint32_t pass, bool light, bool allow_chains, bool& chains_failed)
+static int link_program_as(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, std::string& err, uint32_t pass, bool light, bool allow_chains, bool& chains_failed,
+                           const std::vector<uint8_t>* out_select)
 {
 	chains_failed = false;
 	std::vector<Decoded> ins;
@@ -431,6 +433,38 @@ static int link_program_as(const ThawedScript& s, bool force_narrow, LinkedProgr
 		for (uint16_t r : d.out) {
 			if (r != VVM_INVALID_REG && r >= T && r < out0) { err = "an op writes a constant or input register"; return VVM_E_BAD_BLOB; }
 			touch(r);
+		}
+	}
+	// Outputs that hand an input stream through unchanged (see LinkedProgram::through_input), then the selection of outputs this
+	// program writes (out_select): the pairs that are not selected leave the decoded script here, so that everything below (what
+	// is computed, what is loaded, the output list) follows from the ones that stay.
+	lp.through_input.assign(O, -1);
+	{
+		std::vector<uint8_t> writers(O, 0);
+		std::vector<uint8_t> acquired(lp.acquires_dataset.size(), 0);
+		for (const Decoded& d : ins) {
+			if (d.kind == K_ACQUIRE) acquired[d.dataset] = 1;
+			if (d.kind != K_OUTPUT) continue;
+			for (auto& p : d.pairs) {
+				const uint32_t serial = p.second - out0;
+				if (writers[serial]++) { lp.through_input[serial] = -2; continue; }
+				const bool word_copy = d.op == VVM_OP_outputdata_float || d.op == VVM_OP_outputdata_int32;
+				const bool behind_acquire = d.dataset < acquired.size() && acquired[d.dataset];
+				if (word_copy && behind_acquire && p.first >= T + C && p.first < T + C + I) {
+					const uint32_t i = p.first - (T + C);
+					if (!lp.inputs[i].noadvance && lp.inputs[i].type != 2) lp.through_input[serial] = (int32_t)i;
+				}
+			}
+		}
+		for (uint32_t o = 0; o < O; ++o) if (writers[o] > 1) lp.through_input[o] = -2;
+	}
+	if (out_select) {
+		if (out_select->size() != O) { err = "internal: output selection of the wrong size"; return VVM_E_INVALID_ARG; }
+		for (size_t k = 0; k < ins.size(); ++k) {
+			Decoded& d = ins[k];
+			if (d.kind != K_OUTPUT) continue;
+			d.pairs.erase(std::remove_if(d.pairs.begin(), d.pairs.end(), [&](const std::pair<uint16_t, uint16_t>& p) { return !(*out_select)[p.second - out0]; }), d.pairs.end());
+			if (d.pairs.empty()) { ins.erase(ins.begin() + (ptrdiff_t)k); --k; }
 		}
 	}
 	// Derived constants (see LinkedProgram::derived): registers [out0 + O, ...) stand for them in the decoded instructions from

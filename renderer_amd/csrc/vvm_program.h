@@ -81,12 +81,21 @@ struct LinkedProgram {
 	std::vector<int32_t> out_list;     // output serial index per output-list entry (staging order), -1 = nothing is written,
 	                                   // -2 = the ID register of update_id
 	std::vector<uint8_t> out_is16;     // per entry: the destination stream has 16-bit elements
+	// Per output serial index (the output's register minus the first output register): the remapped input whose value an output
+	// instruction hands through to it unchanged (an advancing 32-bit stream, written by outputdata_float / _int32 behind the
+	// dataset's acquireindex), or -1.  -2: the serial index is written by more than one pair.  See `out_select` of link_program.
+	std::vector<int32_t> through_input;
 };
 
 // Returns VVM_OK or an error code with `err` filled.
 int thaw_blob(const uint8_t* blob, size_t n, ThawedScript& out, std::string& err);
 // `pass` selects the dataset of a script with several acquireindex datasets (0 .. out.num_passes - 1 of a first link).
 // light: link for the light eight-wide kernel; fails with VVM_E_UNSUPPORTED_OP when the script does not fit it.
-int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& out, std::string& err, uint32_t pass = 0, bool light = false);
+// out_select: null, or one flag per output serial index: the program writes only the outputs whose flag is set (and computes and
+// loads only what those and the acquireindex need).  A script whose record is wider than the register file of the fast kernels is
+// run as several such programs over the same instances, one after the other: each repeats the acquireindex and its inputs, so
+// every one of them places its survivors alike.
+int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& out, std::string& err, uint32_t pass = 0, bool light = false,
+                 const std::vector<uint8_t>* out_select = nullptr);
 
 }  // namespace vvm

@@ -1,0 +1,52 @@
+"""A particle update on a wide record: the fountain update (VectorVMRuntime.cpp semantics as in scripts.fountain) on particles that
+carry more attributes, float and int32, which the script hands through unchanged.  Shared by the oracle-side and the GPU tests."""
+import struct
+
+import numpy as np
+
+from renderer_amd.assembler import FLOAT, INT32, Script
+
+
+def wide_record_script(extra_float: int, extra_int: int, touch_one: bool = False):
+    """8 float streams of the fountain + extra_float + extra_int handed-through streams.  touch_one: one of the extra float
+    streams is also read by the arithmetic (so it is loaded by two programs of the sliced form)."""
+    s = Script()
+    dt, drag = s.const(0), s.const(4)
+    pos = [s.input(0, FLOAT, k) for k in range(3)]
+    vel = [s.input(0, FLOAT, 3 + k) for k in range(3)]
+    age, life = s.input(0, FLOAT, 6), s.input(0, FLOAT, 7)
+    more_f = [s.input(0, FLOAT, 8 + k) for k in range(extra_float)]
+    more_i = [s.input(0, INT32, k) for k in range(extra_int)]
+    age1 = s.temp(); s.op("add", age, dt, age1)
+    alive = s.temp(); s.op("cmplt", age1, life, alive)
+    s.acquireindex(alive, 0)
+    v1, p1 = s.temps(3), s.temps(3)
+    for c in range(3):
+        s.op("mad_mul", s.const(1 + c), dt, vel[c], drag, v1[c])
+        # (touch_one: the first extra stream stands in for pos.x, which is then not read at all, so that the computed part still
+        # reads eight streams)
+        s.op("mad", v1[c], dt, more_f[0] if (touch_one and more_f and c == 0) else pos[c], p1[c])
+    s.output_data(FLOAT, 0, [(p1[c], s.output(0, FLOAT, c)) for c in range(3)] + [(v1[c], s.output(0, FLOAT, 3 + c)) for c in range(3)] +
+                  [(age1, s.output(0, FLOAT, 6)), (life, s.output(0, FLOAT, 7))] + [(more_f[k], s.output(0, FLOAT, 8 + k)) for k in range(extra_float)])
+    if extra_int:
+        s.output_data(INT32, 0, [(more_i[k], s.output(0, INT32, k)) for k in range(extra_int)])
+    return s.build(alias_outputs=True)
+
+
+CONSTANTS = struct.pack("<6f", 1.0 / 60.0, 0.0, 0.0, -980.0, 0.98, 1.0) + bytes(8)
+
+
+def streams(n: int, extra_float: int, extra_int: int, death: float, seed: int = 3):
+    rng = np.random.default_rng(seed)
+    f32 = np.float32
+    fl = [rng.uniform(-100, 100, n).astype(f32) for _ in range(6)]
+    life = rng.uniform(1, 5, n).astype(f32)
+    age = np.where(rng.random(n) < death, life, life * f32(0.25)).astype(f32)
+    fl += [age, life]
+    fl += [rng.uniform(-1, 1, n).astype(f32) for _ in range(extra_float)]
+    il = [rng.integers(-2 ** 31, 2 ** 31 - 1, n, dtype=np.int64).astype(np.int32) for _ in range(extra_int)]
+    return fl + il
+
+
+def out_dtypes(extra_float: int, extra_int: int):
+    return [np.float32] * (8 + extra_float) + [np.int32] * extra_int

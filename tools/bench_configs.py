@@ -26,6 +26,9 @@ def main():
     ap.add_argument("--which", default="transcendental,kill_half,batch")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--no-light", action="store_true", help="keep eight-wide Execs on the general kernel")
+    ap.add_argument("--no-slices", action="store_true", help="wide_record: run the script whole instead of in its sliced form")
+    ap.add_argument("--extras", default="16,8", help="wide_record: numbers of handed-through attributes to run")
+    ap.add_argument("--wide-particles", type=int, default=32 * 1024 * 1024, help="wide_record: instances")
     ap.add_argument("--separate-passes", action="store_true", help="two_datasets: one launch per dataset instead of one launch for both")
     ap.add_argument("--batch-variants", type=int, default=64, help="bytecode variants of the batch (the first 16 all fit the light kernel)")
     ap.add_argument("--batch-flags", type=int, default=0, help="vvm_exec_options.Flags of every member of the batch (4: force eight instances per lane)")
@@ -43,7 +46,7 @@ def main():
         torch.cuda.synchronize()
         st = VectorVMState(w.script.blob, be)
         frame = st.frame([abi.DataSet([t.data_ptr() for t in ins], [t.data_ptr() for t in outs], 0)], n, [w.constants], list(ext))
-        o = abi.ExecOptions(0, 0, 0, None, abi.VVM_EXEC_NO_LIGHT_KERNEL if args.no_light else 0)
+        o = abi.ExecOptions(0, 0, 0, None, (abi.VVM_EXEC_NO_LIGHT_KERNEL if args.no_light else 0) | (abi.VVM_EXEC_NO_SLICES if args.no_slices else 0))
         for _ in range(3):
             surv = st.exec(frame, o)
         st.enable_timing(True)
@@ -60,7 +63,8 @@ def main():
         alg = info.BytesInPerInstance * n + info.BytesOutPerInstance * surv
         print(json.dumps({"config": name, "particles": n, "survivors": surv, "steps": args.steps, "ms_per_step": el / args.steps * 1e3,
                           "kernel_ms": kernel_ms, "updates_per_s": n * args.steps / el, "algorithmic_GBps": alg / kernel_ms / 1e6,
-                          "frac_of_8TBps": alg / kernel_ms / 1e6 / 8000.0, "instances_per_lane": width}), flush=True)
+                          "frac_of_8TBps": alg / kernel_ms / 1e6 / 8000.0, "instances_per_lane": width,
+                          "programs_of_the_sliced_form": (info.Flags >> 24) if (info.Flags & 0x80000 and not args.no_slices) else 0}), flush=True)
 
     def arith_script(n_ops):
         """4 streams in, 4 out, n_ops dependent mad / mul / add instructions spread over the streams: interpreter throughput."""
@@ -161,6 +165,39 @@ def main():
         n = 64 * 1024 * 1024
         run_single("fountain with six outputs, 64Mi", w, scripts.fountain_streams_torch(0, n, dev, pad=PAD), 6, n)
         run_single("fountain with six outputs, 64Mi, 50% death", w, scripts.fountain_streams_torch(0, n, dev, kill_half=True, pad=PAD), 6, n)
+    if "wide_record" in which:
+        # the fountain update on particles that carry sixteen more attributes (colour, size, rotation, ...) which the script hands
+        # through unchanged, as a Niagara update script does with every attribute it does not touch (the buffers are double-buffered,
+        # so they are still read and written): 24 streams in, 24 out.  Every input is in a per-lane register from the top of the
+        # tile, so this script runs on the 32-register four-wide kernel.
+        from renderer_amd.assembler import FLOAT, Script
+        import struct
+        for extra in [int(x) for x in args.extras.split(",")]:
+            s = Script()
+            dt, drag = s.const(0), s.const(4)
+            pos = [s.input(0, FLOAT, k) for k in range(3)]
+            vel = [s.input(0, FLOAT, 3 + k) for k in range(3)]
+            age, life = s.input(0, FLOAT, 6), s.input(0, FLOAT, 7)
+            rest = [s.input(0, FLOAT, 8 + k) for k in range(extra)]
+            age1 = s.temp(); s.op("add", age, dt, age1)
+            alive = s.temp(); s.op("cmplt", age1, life, alive)
+            s.acquireindex(alive, 0)
+            v1, p1 = s.temps(3), s.temps(3)
+            for c in range(3):
+                s.op("mad_mul", s.const(1 + c), dt, vel[c], drag, v1[c])
+                s.op("mad", v1[c], dt, pos[c], p1[c])
+            s.output_data(FLOAT, 0, [(p1[c], s.output(0, FLOAT, c)) for c in range(3)] + [(v1[c], s.output(0, FLOAT, 3 + c)) for c in range(3)] +
+                          [(age1, s.output(0, FLOAT, 6)), (life, s.output(0, FLOAT, 7))] + [(rest[k], s.output(0, FLOAT, 8 + k)) for k in range(extra)])
+            class WR:
+                pass
+            w = WR()
+            w.script = s.build(alias_outputs=True)
+            w.constants = struct.pack("<6f", 1.0 / 60.0, 0.0, 0.0, -980.0, 0.98, 1.0) + bytes(8)
+            n = args.wide_particles
+            base = scripts.fountain_streams_torch(0, n, dev, pad=PAD)
+            more = [torch.rand(n + PAD, dtype=torch.float32, device=dev) for _ in range(extra)]
+            run_single("fountain with %d attributes handed through (%d streams in / %d out), %d instances" % (extra, 8 + extra, 8 + extra, n), w, base + more, 8 + extra, n)
+            del more
     if "two_datasets" in which:
         # the fountain update with a second dataset that receives the particles that die this tick (position and age): both
         # datasets' programs read all eight streams
