@@ -237,17 +237,18 @@ enum {
 	VVM_EXEC_SEPARATE_PASSES = 1u << 5,
 	/* A script whose particle record is wider than the register file of the eight-wide kernels (every stream it reads is in a
 	 * per-lane register from the top of a tile), and whose extra width is attributes it hands through unchanged, is kept in a
-	 * sliced form as well: programs for the light eight-wide kernel that each write a part of the outputs, every one repeating
-	 * the acquireindex.  A single Exec of at least VVM_SLICES_MIN_INSTANCES instances runs them one after the other (bit
-	 * 0x80000 of vvm_state_info's Flags: the state has the form; the top byte holds the number of programs).  This flag runs
-	 * the script whole instead (tests / comparison; so does VVM_NO_SLICES=1 in the environment at vvm_alloc_state).  The
-	 * results are the same either way. */
-	VVM_EXEC_NO_SLICES = 1u << 6
+	 * lean form as well: a program for the light eight-wide kernel with everything the script computes, and the list of the
+	 * handed-through streams, which a copy kernel moves behind that program's launch (it takes every survivor's place from what
+	 * the program's acquireindex left).  A single Exec of at least VVM_THROUGH_MIN_INSTANCES instances runs that way (bit
+	 * 0x80000 of vvm_state_info's Flags: the state has the form; the top byte holds the number of handed-through streams).
+	 * This flag runs the script whole instead (tests / comparison; so does VVM_NO_THROUGH=1 in the environment at
+	 * vvm_alloc_state).  The results are the same either way. */
+	VVM_EXEC_NO_THROUGH_KERNEL = 1u << 6
 };
 #define VVM_EIGHT_WIDE_MIN_INSTANCES (256 * 1024)
-/* the sliced form of a wide-record script (VVM_EXEC_NO_SLICES) runs from this size on: every program of the form is a launch of
- * its own, which measured slower than the whole script up to 4 Mi instances and faster from 8 Mi on */
-#define VVM_SLICES_MIN_INSTANCES (8 * 1024 * 1024)
+/* the lean form of a wide-record script (VVM_EXEC_NO_THROUGH_KERNEL) runs from this size on: it is two launches, which measured
+ * faster than the whole script from 64 Ki instances on (24 streams each way: 23 against 29 us per Exec) */
+#define VVM_THROUGH_MIN_INSTANCES (64 * 1024)
 /* ... and inside vvm_exec_batch / vvm_batch_exec, where the launch is shared, a member whose script fits the light eight-wide
  * kernel (eight per-lane registers; bit 0x20000 of vvm_state_info's Flags) runs eight-wide from this size on */
 #define VVM_BATCH_LIGHT_MIN_INSTANCES (8 * 1024)

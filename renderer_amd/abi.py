@@ -21,7 +21,7 @@ VVM_EXEC_FORCE_EIGHT_WIDE = 4
 VVM_EXEC_PARAMS_IN_MEMORY = 8
 VVM_EXEC_NO_LIGHT_KERNEL = 16
 VVM_EXEC_SEPARATE_PASSES = 32
-VVM_EXEC_NO_SLICES = 64
+VVM_EXEC_NO_THROUGH_KERNEL = 64
 VVM_BATCH_CHANGED_INSTANCES, VVM_BATCH_CHANGED_CONSTANTS, VVM_BATCH_CHANGED_STREAMS = 1, 2, 4
 
 STATUS_NAMES = {0: "VVM_OK", 1: "VVM_E_INVALID_ARG", 2: "VVM_E_EXTFN_MISMATCH", 3: "VVM_E_NO_BYTECODE",

@@ -166,6 +166,22 @@ struct VvmXorwowFill {
 	uint8_t  width[256];         // ... and its draws per loop (1, or 2 for random_2x)
 };
 
+// Streams that a script hands through unchanged can stay out of its program (see vvm_host.cpp, plan_through): the program that
+// runs on the light eight-wide kernel then leaves, per tile and lane, the word the kernel keeps of the lane's acquireindex result
+// (keep bits [0:8) of the lane's eight instances, rank within the tile of its first survivor of the first half [8:20) and of the
+// second half [20:32)) at ride[tile * VVM_BLOCK_THREADS + lane] (the entry three before the Exec's output list holds the
+// address, 0 = none), and vvm_through_kernel moves the streams behind it: from the look-back words, which all hold inclusive
+// counts once the Exec's kernel has ended, it takes where a tile's survivors start, from the ride words where each goes.
+#define VVM_THROUGH_MAX_PAIRS 56u
+#define VVM_THROUGH_PAIRS_PER_BLOCK 4u
+struct VvmThroughArgs {
+	const unsigned long long* status;   // the Exec's look-back words
+	const uint32_t* ride;
+	uint32_t num_instances, num_tiles, num_pairs, pad;
+	uint64_t src[VVM_THROUGH_MAX_PAIRS];   // byte address of element [InstanceOffset] of the input stream
+	uint64_t dst[VVM_THROUGH_MAX_PAIRS];   // ... of the output stream
+};
+
 // Launch-wide words in device memory; the last block to leave a launch re-arms them for the next one.
 //
 // Tiles are handed out in index order by ticket counters.  A device-scope atomic on ONE address completes about every 13 ns

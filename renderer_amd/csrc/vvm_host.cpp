@@ -152,12 +152,15 @@ struct vvm_state {
 	std::vector<VvmIns*> d_code_wide_more, d_code_narrow_more;
 
 	// A script whose record is too wide for the register file of the eight-wide kernels, but whose extra width is streams that it
-	// hands through unchanged, also has this form: programs for the light eight-wide kernel that each write a part of the outputs
-	// (the first everything the script computes, the others up to six handed-through streams each; every one repeats the
-	// acquireindex and what it depends on).  A large Exec runs them one after the other over the same instances.
-	std::vector<vvm::LinkedProgram> slices;
-	std::vector<VvmIns*> d_code_slices;
-	bool slices_ready = false;
+	// hands through unchanged, also has this form: a program for the light eight-wide kernel with everything the script computes
+	// (`lean`), and the list of handed-through outputs, which vvm_through_kernel moves behind that program's launch from the
+	// acquireindex results the program leaves per tile and lane (`d_ride`).  A large Exec runs that way.
+	vvm::LinkedProgram lean;
+	VvmIns* d_code_lean = nullptr;
+	bool lean_ready = false;
+	std::vector<uint32_t> through;         // output serial indices that are handed through
+	uint32_t* d_ride = nullptr;
+	uint32_t ride_capacity = 0;            // tiles
 
 	VvmIns* d_code_wide = nullptr;
 	VvmIns* d_code_narrow = nullptr;
@@ -269,8 +272,9 @@ struct PreparedExec {
 	uint32_t instances_per_lane = 4;                   // of the kernel this Exec runs on (8, 4 or 1)
 	bool light = false;                                // ... the light eight-wide kernel
 	bool in_batch = false;                             // set by the caller: the Exec is a member of a batch (decides the kernel of small Execs, see prepare)
-	bool whole_only = false;                           // set by the caller: never the sliced form of the script (vvm_exec_noalloc)
-	uint32_t sliced = 0;                               // not 0: the Exec runs the state's sliced form, this many programs one after the other
+	bool whole_only = false;                           // set by the caller: never the lean form of the script (vvm_exec_noalloc)
+	bool lean = false;                                 // the Exec runs the state's lean program; vvm_through_kernel follows it
+	uint64_t ride_addr = 0;                            // where the program leaves its per-lane acquireindex results for that kernel (0: nowhere)
 	uint32_t id_buffers = 0;                           // which piece of the state's update_id buffers this pass works in (fused passes run together)
 	bool reference_random = false;                     // the Exec's random ops read the reference generator's words (then it runs on a FULL kernel)
 	bool full() const { return lp->full_kernel || reference_random; }
@@ -327,16 +331,13 @@ int link_more_passes(const vvm::ThawedScript& s, bool narrow, const vvm::LinkedP
 	return VVM_OK;
 }
 
-// The sliced form of a script (vvm_state::slices), where it pays: the whole script needs more than the sixteen per-lane registers
-// of the eight-wide kernels (every stream it reads sits in one from the top of a tile), at least two of its outputs hand a 32-bit
-// input stream through unchanged, and without those the script fits the light eight-wide kernel.  The handed-through outputs then
-// go into programs of their own, as many per program as the light kernel takes beside the streams the acquireindex depends on
-// (at most six: the outputs it stages), and the state keeps the form when all programs together move at most 25 % more stream
-// bytes than the script as a whole (every program reads the acquireindex's streams again).  Not built is not an error.
-int plan_slices(vvm_state* st)
+// The lean form of a script (vvm_state::lean), where it pays: the whole script needs more than the sixteen per-lane registers of
+// the eight-wide kernels (every stream it reads sits in one from the top of a tile), at least two of its outputs hand a 32-bit
+// input stream through unchanged, and without those the script fits the light eight-wide kernel.  Not built is not an error.
+int plan_through(vvm_state* st)
 {
 	const vvm::LinkedProgram& w = st->wide;
-	if (getenv("VVM_NO_SLICES")) return VVM_OK;
+	if (getenv("VVM_NO_THROUGH")) return VVM_OK;
 	if (st->light_ready || w.num_passes != 1 || w.num_chains != 1 || w.uses_ids || w.full_kernel || w.acquire_order.size() != 1) return VVM_OK;
 	if (!(w.many_registers || w.instances_per_lane == 1)) return VVM_OK;
 	const size_t O = w.through_input.size();
@@ -345,36 +346,52 @@ int plan_slices(vvm_state* st)
 		if (w.through_input[o] == -2) return VVM_OK;
 		if (w.through_input[o] >= 0) through.push_back((uint32_t)o);
 	}
-	// (measured on the fountain update with 10 / 12 / 16 / 24 / 32 handed-through attributes, 32 Mi instances: the sliced form takes
-	// 0.98 / 1.20 / 1.33 / 1.89 / 2.28 ms, the whole script 1.29 / 1.33 / 1.44 / 1.78 / 2.17 ms: every further program costs a launch
-	// and another reading of the acquireindex's streams, so the form is kept up to four programs)
-	if (through.size() < 2 || through.size() > 18) return VVM_OK;
+	if (through.size() < 2 || through.size() > VVM_THROUGH_MAX_PAIRS) return VVM_OK;
 	std::string why;
-	for (size_t per = 6; per >= 3; --per) {
-		std::vector<vvm::LinkedProgram> progs(1 + (through.size() + per - 1) / per);
-		std::vector<uint8_t> select(O, 0);
-		for (size_t o = 0; o < O; ++o) select[o] = w.through_input[o] < 0;
-		bool ok = vvm::link_program(st->script, false, progs[0], why, 0, true, &select) == VVM_OK;
-		size_t bytes_in = ok ? progs[0].bytes_in_per_instance : 0;
-		for (size_t k = 1; ok && k < progs.size(); ++k) {
-			std::fill(select.begin(), select.end(), 0);
-			for (size_t j = (k - 1) * per; j < std::min(through.size(), k * per); ++j) select[through[j]] = 1;
-			ok = vvm::link_program(st->script, false, progs[k], why, 0, true, &select) == VVM_OK;
-			// (a program that stages more than six outputs would let two of them wait in registers: not for plain copies)
-			if (ok) for (size_t q = VVM_LIGHT_GROUP_SLOTS; q < progs[k].out_list.size(); ++q) ok = ok && progs[k].out_list[q] == -1;
-			if (ok) bytes_in += progs[k].bytes_in_per_instance;
-		}
-		if (!ok) continue;
-		if ((bytes_in + w.bytes_out_per_instance) * 4 > ((size_t)w.bytes_in_per_instance + w.bytes_out_per_instance) * 5) return VVM_OK;
-		st->d_code_slices.assign(progs.size(), nullptr);
-		for (size_t k = 0; k < progs.size(); ++k) {
-			const int rc = upload_code(progs[k], &st->d_code_slices[k]);
-			if (rc != VVM_OK) return rc;
-		}
-		st->slices = std::move(progs);
-		st->slices_ready = true;
-		return VVM_OK;
+	std::vector<uint8_t> select(O, 0);
+	for (size_t o = 0; o < O; ++o) select[o] = w.through_input[o] < 0;
+	if (vvm::link_program(st->script, false, st->lean, why, 0, true, &select) != VVM_OK) return VVM_OK;
+	const int rc = upload_code(st->lean, &st->d_code_lean);
+	if (rc != VVM_OK) return rc;
+	st->through = std::move(through);
+	st->lean_ready = true;
+	return VVM_OK;
+}
+
+// The stream addresses of the handed-through pairs of an Exec, as fill_params forms them (element [InstanceOffset] of each stream).
+int fill_through(vvm_state* st, const vvm_exec_context* ctx, VvmThroughArgs& a)
+{
+	const vvm::ThawedScript& s = st->script;
+	a.num_pairs = 0;
+	for (uint32_t o : st->through) {
+		const vvm::InputInfo& in = st->wide.inputs[(size_t)st->wide.through_input[o]];
+		if (o >= s.num_outputs_remapped || s.out_dst[o] == 0xFFFF) continue;
+		const uint8_t dso = s.out_dataset[o];
+		const uint16_t ty = s.out_type[o];
+		if ((int)in.dataset >= ctx->DataSets.num || (int)dso >= ctx->DataSets.num || ty > 1) return fail(VVM_E_INVALID_ARG, "script reads or writes a dataset the context does not provide");
+		const vvm_dataset_meta& dsi = ctx->DataSets.data[in.dataset];
+		const vvm_dataset_meta& dsw = ctx->DataSets.data[dso];
+		const uint32_t ii = dsi.InputRegisterTypeOffsets[in.type] + in.reg, oi = dsw.OutputRegisterTypeOffsets[ty] + s.out_dst[o];
+		if ((int)ii >= dsi.InputRegisters.num || !dsi.InputRegisters.data) return fail(VVM_E_INVALID_ARG, "input register index past InputRegisters.num");
+		if ((int)oi >= dsw.OutputRegisters.num || !dsw.OutputRegisters.data) return fail(VVM_E_INVALID_ARG, "output register index past OutputRegisters.num");
+		if (!dsw.OutputRegisters.data[oi]) continue;      // (no destination: nothing is written, as for any output)
+		if (!dsi.InputRegisters.data[ii]) return fail(VVM_E_INVALID_ARG, "an input stream the script reads is a null pointer");
+		a.src[a.num_pairs] = (uint64_t)(uintptr_t)dsi.InputRegisters.data[ii] + (uint64_t)(int64_t)dsi.InstanceOffset * 4u;
+		a.dst[a.num_pairs] = (uint64_t)(uintptr_t)dsw.OutputRegisters.data[oi] + (uint64_t)(int64_t)dsw.InstanceOffset * 4u;
+		++a.num_pairs;
 	}
+	return VVM_OK;
+}
+
+int ensure_ride(vvm_state* st, uint32_t tiles, hipStream_t stream)
+{
+	if (tiles <= st->ride_capacity) return VVM_OK;
+	HIP_TRY(hipStreamSynchronize(stream));
+	if (st->last_stream && st->last_stream != stream) HIP_TRY(hipStreamSynchronize(st->last_stream));
+	if (st->d_ride) { HIP_TRY(hipFree(st->d_ride)); st->d_ride = nullptr; st->ride_capacity = 0; }
+	const uint32_t cap = std::max<uint32_t>(1024, tiles + tiles / 4);
+	HIP_TRY(hipMalloc((void**)&st->d_ride, (size_t)cap * VVM_BLOCK_THREADS * 4u));
+	st->ride_capacity = cap;
 	return VVM_OK;
 }
 
@@ -405,10 +422,8 @@ int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, P
 		if (pass > st->narrow_more.size()) return fail(VVM_E_INVALID_ARG, "internal: pass index out of range");
 		pe.lp = pass ? &st->narrow_more[pass - 1] : &st->narrow; pe.d_code = pass ? st->d_code_narrow_more[pass - 1] : st->d_code_narrow;
 	} else {
-		// (passes 1.. of the sliced form of a script with one dataset have no program here: chosen further down)
-		const bool have = pass <= st->wide_more.size();
-		if (!have && !(st->slices_ready && pass < st->slices.size())) return fail(VVM_E_INVALID_ARG, "internal: pass index out of range");
-		pe.lp = !have ? &st->wide : pass ? &st->wide_more[pass - 1] : &st->wide; pe.d_code = !have ? st->d_code_wide : pass ? st->d_code_wide_more[pass - 1] : st->d_code_wide;
+		if (pass > st->wide_more.size()) return fail(VVM_E_INVALID_ARG, "internal: pass index out of range");
+		pe.lp = pass ? &st->wide_more[pass - 1] : &st->wide; pe.d_code = pass ? st->d_code_wide_more[pass - 1] : st->d_code_wide;
 	}
 	for (uint32_t i = 0; i < s.num_ext_fns; ++i) {
 		const vvm_ext_function* f = ctx->ExtFunctionTable.data[i];
@@ -422,16 +437,16 @@ int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, P
 	}
 	pe.instances_per_lane = pe.lp->instances_per_lane;
 	pe.reference_random = opt && opt->RandXorwowState && !st->wide.rand_draws.empty();
-	pe.sliced = 0;
+	pe.lean = false;
 	{
-		// the sliced form: for a single Exec large enough that a launch per program pays (VVM_SLICES_MIN_INSTANCES)
+		// the lean form: for a single Exec large enough that a second launch pays (VVM_THROUGH_MIN_INSTANCES)
 		const uint32_t flags = opt ? opt->Flags : 0;
-		const bool big = ctx->NumInstances >= VVM_SLICES_MIN_INSTANCES || (flags & VVM_EXEC_FORCE_EIGHT_WIDE);
-		if (st->slices_ready && !narrow && !pe.in_batch && !pe.whole_only && !pe.reference_random && big &&
-		    !(flags & (VVM_EXEC_NO_EIGHT_WIDE | VVM_EXEC_NO_LIGHT_KERNEL | VVM_EXEC_NO_SLICES)) && pass < st->slices.size()) {
-			pe.sliced = (uint32_t)st->slices.size();
-			pe.lp = &st->slices[pass];
-			pe.d_code = st->d_code_slices[pass];
+		const bool big = ctx->NumInstances >= VVM_THROUGH_MIN_INSTANCES || (flags & VVM_EXEC_FORCE_EIGHT_WIDE);
+		if (st->lean_ready && pass == 0 && !narrow && !pe.in_batch && !pe.whole_only && !pe.reference_random && big &&
+		    !(flags & (VVM_EXEC_NO_EIGHT_WIDE | VVM_EXEC_NO_LIGHT_KERNEL | VVM_EXEC_NO_THROUGH_KERNEL))) {
+			pe.lean = true;
+			pe.lp = &st->lean;
+			pe.d_code = st->d_code_lean;
 			pe.instances_per_lane = 8;
 			pe.light = true;
 		}
@@ -447,7 +462,7 @@ int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, P
 		// eight instances per lane: the same program, twice the work per interpreted instruction; only worth it when there are
 		// enough tiles left to keep every CU busy for several rounds
 		const uint32_t flags = opt ? opt->Flags : 0;
-		const bool can = !pe.sliced && pe.lp->instances_per_lane == 4 && !pe.full() && !pe.lp->many_registers && !(flags & VVM_EXEC_NO_EIGHT_WIDE);
+		const bool can = !pe.lean && pe.lp->instances_per_lane == 4 && !pe.full() && !pe.lp->many_registers && !(flags & VVM_EXEC_NO_EIGHT_WIDE);
 		// (the size of the Exec itself decides, also inside a batch: many small Execs measured faster four wide, 0.88 ms against
 		// 0.92 ms for 4096 Execs of 16 Ki instances)
 		// scripts that get by with eight registers have a program for the light eight-wide kernel (three workgroups per CU)
@@ -589,6 +604,7 @@ int fill_params(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* op
 	memset(out_list, 0, pe.bytes - pe.off_out);
 	{   // the entry before the list: where the Exec's last tile writes the survivor count of the acquired dataset
 		out_list[-1] = (uint64_t)(uintptr_t)(d->counts + lp.pass_dataset);
+		out_list[-3] = pe.ride_addr;      // (the light kernel reads it on every tile: 0 unless vvm_through_kernel follows)
 		if (lp.num_chains > 1) out_list[-2] = (uint64_t)(uintptr_t)(d->counts + lp.chain_dataset[1]);      // (the second chain's)
 	}
 	for (size_t k = 0; k < lp.out_list.size(); ++k) {
@@ -898,7 +914,7 @@ VVM_API vvm_state* vvm_alloc_state(const uint8_t* blob, size_t num_bytes)
 			st->light_ready = true;
 		}
 	}
-	if (plan_slices(st) != VVM_OK) { vvm_free_state(st); return nullptr; }
+	if (plan_through(st) != VVM_OK) { vvm_free_state(st); return nullptr; }
 	hipError_t e;
 	st->any_ids = st->wide.uses_ids;
 	st->const_table.reserve(st->script.num_consts);      // (filled by the first Exec; reserved here so that no Exec allocates for them)
@@ -942,7 +958,8 @@ VVM_API void vvm_free_state(vvm_state* st)
 	if (st->d_code_wide) (void)hipFree(st->d_code_wide);
 	if (st->d_code_narrow) (void)hipFree(st->d_code_narrow);
 	if (st->d_code_light) (void)hipFree(st->d_code_light);
-	for (VvmIns* p : st->d_code_slices) if (p) (void)hipFree(p);
+	if (st->d_code_lean) (void)hipFree(st->d_code_lean);
+	if (st->d_ride) (void)hipFree(st->d_ride);
 	for (VvmIns* p : st->d_code_wide_more) if (p) (void)hipFree(p);
 	for (VvmIns* p : st->d_code_narrow_more) if (p) (void)hipFree(p);
 	if (st->d_perlin) (void)hipFree(st->d_perlin);
@@ -1036,8 +1053,8 @@ static int exec_enqueue(vvm_exec_context* ctx, const vvm_exec_options* opt, bool
 		rc = enqueue_reference_random(st, ctx, opt, pe, stream);
 		if (rc != VVM_OK) return rc;
 	}
-	const uint32_t num_passes = pe.sliced ? pe.sliced : pe.lp->num_passes;      // (the slices of a wide record run like the passes of several datasets)
-	if (num_passes > 1 && !pe.sliced && !no_alloc && !(opt && (opt->Flags & VVM_EXEC_SEPARATE_PASSES))) {
+	const uint32_t num_passes = pe.lp->num_passes;
+	if (num_passes > 1 && !no_alloc && !(opt && (opt->Flags & VVM_EXEC_SEPARATE_PASSES))) {
 		bool handled = false;
 		rc = enqueue_fused_passes(st, ctx, opt, num_passes, stream, d_launch, timed, handled);
 		if (rc != VVM_OK) return rc;
@@ -1063,6 +1080,16 @@ static int exec_enqueue(vvm_exec_context* ctx, const vvm_exec_options* opt, bool
 				st->cur_status = d_status;
 				st->cur_status_words = (size_t)st->status_capacity;
 			}
+		}
+		VvmThroughArgs through;
+		if (pe.lean) {
+			rc = ensure_ride(st, pe.tiles, stream);
+			if (rc != VVM_OK) return rc;
+			pe.ride_addr = (uint64_t)(uintptr_t)st->d_ride;
+			through.status = d_status; through.ride = st->d_ride;
+			through.num_instances = (uint32_t)ctx->NumInstances; through.num_tiles = pe.tiles; through.pad = 0;
+			rc = fill_through(st, ctx, through);
+			if (rc != VVM_OK) return rc;
 		}
 		if (pe.lp->updates_ids) {      // (one update_id per pass, and the passes follow each other on the stream: they share one piece of the buffers)
 			rc = ensure_id_buffers(st, 1, pe.num_chunks, (uint32_t)ctx->NumInstances, stream);
@@ -1095,6 +1122,10 @@ static int exec_enqueue(vvm_exec_context* ctx, const vvm_exec_options* opt, bool
 		                                       grid_for(pe.tiles, pe.instances_per_lane, pe.full(), pe.launch_many()), stream,
 		                                       inline_block ? local_block : nullptr, inline_block ? (uint32_t)pe.bytes : 0u, 0u, 0);
 		if (lrc != 0) return hip_fail((hipError_t)lrc, "kernel launch");
+		if (pe.lean) {
+			const int trc = vvm_launch_through_kernel(&through, stream);
+			if (trc != 0) return hip_fail((hipError_t)trc, "kernel launch (handed-through streams)");
+		}
 		if (timed && pass + 1 == num_passes) { HIP_TRY(hipEventRecord(st->ev_stop[st->ev_used], stream)); st->ev_used++; }
 		for (size_t u = 0; u < pe.lp->id_uses.size(); ++u) {
 			if (!pe.lp->id_uses[u].updates) continue;
@@ -1725,7 +1756,7 @@ VVM_API int vvm_state_info(const vvm_state* st, vvm_program_info* out)
 	if (!st || !out) return fail(VVM_E_INVALID_ARG, "null argument");
 	fill_info(st->script, st->wide, out);
 	if (st->light_ready) out->Flags |= 0x20000u;
-	if (st->slices_ready) out->Flags |= 0x80000u | ((uint32_t)st->slices.size() << 24);
+	if (st->lean_ready) out->Flags |= 0x80000u | ((uint32_t)st->through.size() << 24);
 	return VVM_OK;
 }
 

@@ -22,6 +22,8 @@ int vvm_launch_max_id_kernel(const VvmIdDesc* ids, uint32_t num_chunks, hipStrea
 // The reference's random generator for one Exec: fills words[draw * stride + instance] (device memory, stride a multiple of 4 and
 // at least 4 * total_loops) with the 32 bits of every draw; jump = the VVM_XORWOW_JUMP_WORDS words of the jump table in device memory.
 int vvm_launch_xorwow_fill(const VvmXorwowFill* params, const uint32_t* jump, uint32_t* words, hipStream_t stream);
+// The handed-through streams of an Exec whose program has run on the light eight-wide kernel and left its ride words (same stream).
+int vvm_launch_through_kernel(const VvmThroughArgs* args, hipStream_t stream);
 int vvm_kernel_max_dynamic_lds(void);
 uint32_t vvm_kernel_resident_registers(int instances_per_lane, int many_registers);
 uint32_t vvm_kernel_lds_fixed_bytes(int instances_per_lane, int full);

@@ -972,6 +972,14 @@ template <int V, bool FULL, bool LIGHT, bool TWO, typename VEC> DEV void store_t
                                                                        VEC R0, VEC R1, VEC R2, VEC R3, VEC R4, VEC R5, VEC R6, VEC R7)
 {
 	static_assert(VVM_STAGE_SLOTS == 8, "store_slots is written for eight slots");
+	if constexpr (LIGHT) {
+		// for vvm_through_kernel, when the Exec has streams that stay out of its program: the lane's acquireindex result of this tile
+		const uint64_t ride_base = sload64(p.out_list - 3, 0);
+		if (ride_base != 0) {
+			const rsrc_t rr = make_rsrc(ride_base + (uint64_t)p.tile_local * (VVM_BLOCK_THREADS * 4u), VVM_BLOCK_THREADS * 4u);
+			__builtin_amdgcn_raw_buffer_store_b32(p.ride, rr, (int)(c.tid * 4u), 0, 0);
+		}
+	}
 	const uint32_t n_staged = STAGED_COUNT(p.stage_end);
 	if (n_staged != 0 && !(dbg & 8u)) {
 		// slot s holds the values for entry first + s of the Exec's output list: all eight entries arrive with one scalar load
@@ -1759,6 +1767,73 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (IS_LIGHT(V, SPILL) ? 3 : V
 				__hip_atomic_store((gu32*)&env.ls->tickets[x * (VVM_TICKET_STRIDE_BYTES / 4u)], 0u, RLX_AGENT);
 		}
 	}
+}
+
+// The streams a script hands through unchanged, moved behind the Exec's own kernel (see VvmThroughArgs): workgroup (tile, b) moves
+// pairs [4 b, 4 b + 4) of one tile of eight instances per lane.  A tile whose instances all survive is copied as it lies, 128 bits
+// per lane and half; otherwise every survivor's value goes to its rank in LDS (dead ones to the thread's sink word) and the tile's
+// survivors leave from there, 128 bits per lane, cut at the tile's count by the descriptor's bound.  Survivors keep instance order
+// (VectorVMRuntime.cpp:786-804) because the ranks are the acquireindex's own.
+__global__ void __launch_bounds__(VVM_BLOCK_THREADS) vvm_through_kernel(const VvmThroughArgs a)
+{
+	constexpr uint32_t TILE = VVM_BLOCK_THREADS * 8u, PPB = VVM_THROUGH_PAIRS_PER_BLOCK;
+	__shared__ __attribute__((aligned(16))) uint32_t packed[PPB][TILE + VVM_BLOCK_THREADS];
+	const uint32_t tile = blockIdx.x, tid = threadIdx.x;
+	const uint32_t inclusive = (uint32_t)sload64(a.status, tile);
+	const uint32_t base = tile ? (uint32_t)sload64(a.status, tile - 1u) : 0u;
+	const uint32_t total = inclusive - base;
+	if (total == 0) return;
+	const uint32_t first = tile * TILE;
+	const uint32_t valid = min(a.num_instances - first, TILE);
+	const uint32_t p0 = blockIdx.y * PPB;
+	u32x4 lo[PPB], hi[PPB];
+#pragma unroll
+	for (uint32_t j = 0; j < PPB; ++j) {
+		const bool used = p0 + j < a.num_pairs;
+		const rsrc_t rs = make_rsrc(a.src[used ? p0 + j : p0] + 4ull * first, used ? 4u * valid : 0u);
+		lo[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(tid * 16u), 0, AUX_STREAM_LOAD);
+		hi[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(VVM_HALF_TILE * 4u + tid * 16u), 0, AUX_STREAM_LOAD);
+	}
+	if (total == TILE) {
+#pragma unroll
+		for (uint32_t j = 0; j < PPB; ++j) {
+			const bool used = p0 + j < a.num_pairs;
+			const rsrc_t rd = make_rsrc(a.dst[used ? p0 + j : p0] + 4ull * base, used ? 4u * TILE : 0u);
+			__builtin_amdgcn_raw_buffer_store_b128(lo[j], rd, (int)(tid * 16u), 0, AUX_STREAM_STORE);
+			__builtin_amdgcn_raw_buffer_store_b128(hi[j], rd, (int)(VVM_HALF_TILE * 4u + tid * 16u), 0, AUX_STREAM_STORE);
+		}
+		return;
+	}
+	const uint32_t ride = a.ride[(size_t)tile * VVM_BLOCK_THREADS + tid];
+#pragma unroll
+	for (uint32_t j = 0; j < PPB; ++j) {
+		const uint32_t v[8] = {lo[j].x, lo[j].y, lo[j].z, lo[j].w, hi[j].x, hi[j].y, hi[j].z, hi[j].w};
+		uint32_t r = (ride >> 8) & 0xFFFu;
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			if (k == 4) r = ride >> 20;
+			const bool keep = (ride >> k) & 1u;
+			packed[j][keep ? r : TILE + tid] = v[k];
+			r += keep ? 1u : 0u;
+		}
+	}
+	__syncthreads();
+#pragma unroll
+	for (uint32_t j = 0; j < PPB; ++j) {
+		const bool used = p0 + j < a.num_pairs;
+		const rsrc_t rd = make_rsrc(a.dst[used ? p0 + j : p0] + 4ull * base, used ? 4u * total : 0u);
+		const u32x4 x = *(const u32x4*)&packed[j][tid * 4u];
+		const u32x4 y = *(const u32x4*)&packed[j][VVM_HALF_TILE + tid * 4u];
+		__builtin_amdgcn_raw_buffer_store_b128(x, rd, (int)(tid * 16u), 0, AUX_STREAM_STORE);
+		__builtin_amdgcn_raw_buffer_store_b128(y, rd, (int)(VVM_HALF_TILE * 4u + tid * 16u), 0, AUX_STREAM_STORE);
+	}
+}
+extern "C" int vvm_launch_through_kernel(const VvmThroughArgs* args, hipStream_t stream)
+{
+	if (args->num_pairs == 0 || args->num_tiles == 0) return 0;
+	const dim3 grid(args->num_tiles, (args->num_pairs + VVM_THROUGH_PAIRS_PER_BLOCK - 1u) / VVM_THROUGH_PAIRS_PER_BLOCK);
+	hipLaunchKernelGGL(vvm_through_kernel, grid, dim3(VVM_BLOCK_THREADS), 0, stream, *args);
+	return (int)hipGetLastError();
 }
 
 // update_id's MaxUsedID (VectorVMRuntime.cpp:1141-1174, 1383-1399), run after the Exec: per chunk of the reference's chunking,

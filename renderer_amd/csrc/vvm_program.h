@@ -93,8 +93,7 @@ int thaw_blob(const uint8_t* blob, size_t n, ThawedScript& out, std::string& err
 // light: link for the light eight-wide kernel; fails with VVM_E_UNSUPPORTED_OP when the script does not fit it.
 // out_select: null, or one flag per output serial index: the program writes only the outputs whose flag is set (and computes and
 // loads only what those and the acquireindex need).  A script whose record is wider than the register file of the fast kernels is
-// run as several such programs over the same instances, one after the other: each repeats the acquireindex and its inputs, so
-// every one of them places its survivors alike.
+// linked a second time without the outputs that hand an input stream through (through_input); a copy kernel moves those.
 int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& out, std::string& err, uint32_t pass = 0, bool light = false,
                  const std::vector<uint8_t>* out_select = nullptr);
 

@@ -9,7 +9,7 @@ from renderer_amd.assembler import FLOAT, INT32, Script
 
 def wide_record_script(extra_float: int, extra_int: int, touch_one: bool = False):
     """8 float streams of the fountain + extra_float + extra_int handed-through streams.  touch_one: one of the extra float
-    streams is also read by the arithmetic (so it is loaded by two programs of the sliced form)."""
+    streams is also read by the arithmetic (so the program loads it and the copy kernel reads it again)."""
     s = Script()
     dt, drag = s.const(0), s.const(4)
     pos = [s.input(0, FLOAT, k) for k in range(3)]

@@ -26,7 +26,8 @@ def main():
     ap.add_argument("--which", default="transcendental,kill_half,batch")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--no-light", action="store_true", help="keep eight-wide Execs on the general kernel")
-    ap.add_argument("--no-slices", action="store_true", help="wide_record: run the script whole instead of in its sliced form")
+    ap.add_argument("--no-through", action="store_true", help="wide_record: run the script whole instead of in its lean form (copy kernel for the handed-through streams)")
+    ap.add_argument("--force-eight", action="store_true", help="single Execs: eight instances per lane whatever the size (and with it the lean form of a wide-record script)")
     ap.add_argument("--extras", default="16,8", help="wide_record: numbers of handed-through attributes to run")
     ap.add_argument("--wide-particles", type=int, default=32 * 1024 * 1024, help="wide_record: instances")
     ap.add_argument("--separate-passes", action="store_true", help="two_datasets: one launch per dataset instead of one launch for both")
@@ -46,7 +47,8 @@ def main():
         torch.cuda.synchronize()
         st = VectorVMState(w.script.blob, be)
         frame = st.frame([abi.DataSet([t.data_ptr() for t in ins], [t.data_ptr() for t in outs], 0)], n, [w.constants], list(ext))
-        o = abi.ExecOptions(0, 0, 0, None, (abi.VVM_EXEC_NO_LIGHT_KERNEL if args.no_light else 0) | (abi.VVM_EXEC_NO_SLICES if args.no_slices else 0))
+        o = abi.ExecOptions(0, 0, 0, None, (abi.VVM_EXEC_NO_LIGHT_KERNEL if args.no_light else 0) | (abi.VVM_EXEC_NO_THROUGH_KERNEL if args.no_through else 0) |
+                             (abi.VVM_EXEC_FORCE_EIGHT_WIDE if args.force_eight else 0))
         for _ in range(3):
             surv = st.exec(frame, o)
         st.enable_timing(True)
@@ -64,7 +66,7 @@ def main():
         print(json.dumps({"config": name, "particles": n, "survivors": surv, "steps": args.steps, "ms_per_step": el / args.steps * 1e3,
                           "kernel_ms": kernel_ms, "updates_per_s": n * args.steps / el, "algorithmic_GBps": alg / kernel_ms / 1e6,
                           "frac_of_8TBps": alg / kernel_ms / 1e6 / 8000.0, "instances_per_lane": width,
-                          "programs_of_the_sliced_form": (info.Flags >> 24) if (info.Flags & 0x80000 and not args.no_slices) else 0}), flush=True)
+                          "streams_left_to_the_copy_kernel": (info.Flags >> 24) if (info.Flags & 0x80000 and not args.no_through and width == 8) else 0}), flush=True)
 
     def arith_script(n_ops):
         """4 streams in, 4 out, n_ops dependent mad / mul / add instructions spread over the streams: interpreter throughput."""
@@ -168,8 +170,9 @@ def main():
     if "wide_record" in which:
         # the fountain update on particles that carry sixteen more attributes (colour, size, rotation, ...) which the script hands
         # through unchanged, as a Niagara update script does with every attribute it does not touch (the buffers are double-buffered,
-        # so they are still read and written): 24 streams in, 24 out.  Every input is in a per-lane register from the top of the
-        # tile, so this script runs on the 32-register four-wide kernel.
+        # so they are still read and written): 24 streams in, 24 out.  Every input of the whole script is in a per-lane register from
+        # the top of the tile (the 32-register four-wide kernel); in its lean form the light kernel runs what the script computes and
+        # a copy kernel moves the rest.
         from renderer_amd.assembler import FLOAT, Script
         import struct
         for extra in [int(x) for x in args.extras.split(",")]:

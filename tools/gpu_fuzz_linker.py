@@ -3,7 +3,7 @@
 (renderer_amd.assembler), wider than the optimizer fuzz: up to 60 instructions over float / int32 / half / no-advance inputs, merged
 opcodes, two-output ops, the bit-exact transcendentals, exec_index, random, up to 24 outputs of three kinds (several staging groups),
 many values alive at once (the 32-register kernels, LDS register slots, the one-instance-per-lane kernel), short scripts that fit the
-light kernel, wide records whose extra streams are handed through (the sliced form), the reference's random generator, Execs inside a vvm_exec_batch call.  Each script runs on libvvm_hip.so and on the CPU
+light kernel, wide records whose extra streams are handed through (the lean form and its copy kernel), the reference's random generator, Execs inside a vvm_exec_batch call.  Each script runs on libvvm_hip.so and on the CPU
 oracle; results must agree bit for bit (NaN payloads aside)."""
 import os
 import random
@@ -160,7 +160,7 @@ def gen(seed):
     dts, fo, io, ho = [], 0, 0, 0
     outs = []
     # a wide record: one short script in eight also hands nine to eighteen more float streams through unchanged; where what it
-    # computes fits the light kernel the library keeps a sliced form of it, and these seeds run with eight instances per lane forced
+    # computes fits the light kernel the library keeps a lean form of it, and these seeds run with eight instances per lane forced
     wide = []
     if small and seed % 16 == 2:
         wide = [s.input(0, FLOAT, nf + nna + i) for i in range(r.randint(9, 18))]
@@ -309,7 +309,7 @@ def run(first_seed, last_seed, report_every=100):
         shapes[key] = shapes.get(key, 0) + 1
         if got[2].Flags & 0x20000 and ((seed // 2) % 4 if gen.small else seed % 4) == 1:
             shapes["ran on the light kernel"] = shapes.get("ran on the light kernel", 0) + 1
-        for bit, name in ((0x20000, "fits the light kernel"), (0x40000, "two chains in one pass"), (0x80000, "has a sliced form (runs when eight-wide is forced)")):
+        for bit, name in ((0x20000, "fits the light kernel"), (0x40000, "two chains in one pass"), (0x80000, "has a lean form (runs when eight-wide is forced)")):
             if info.Flags & bit:
                 shapes[name] = shapes.get(name, 0) + 1
         if xorwow is not None:
