@@ -235,11 +235,12 @@ enum {
 	 * runs all of them on a tile of instances before it moves on.  This flag launches the passes one after the other instead
 	 * (tests / comparison).  The results are the same. */
 	VVM_EXEC_SEPARATE_PASSES = 1u << 5,
-	/* A script whose particle record is wider than the register file of the eight-wide kernels (every stream it reads is in a
+	/* A script whose particle record is wider than the register file of the light eight-wide kernel (every stream it reads is in a
 	 * per-lane register from the top of a tile), and whose extra width is attributes it hands through unchanged, is kept in a
 	 * lean form as well: a program for the light eight-wide kernel with everything the script computes, and the list of the
 	 * handed-through streams, which a copy kernel moves behind that program's launch (it takes every survivor's place from what
-	 * the program's acquireindex left).  A single Exec of at least VVM_THROUGH_MIN_INSTANCES instances runs that way (bit
+	 * the program's acquireindex left).  A single Exec of at least VVM_THROUGH_MIN_INSTANCES instances (VVM_THROUGH_MIN_INSTANCES_EIGHT_WIDE
+	 * where the whole script still fits the general eight-wide kernel) runs that way (bit
 	 * 0x80000 of vvm_state_info's Flags: the state has the form; the top byte holds the number of handed-through streams).
 	 * This flag runs the script whole instead (tests / comparison; so does VVM_NO_THROUGH=1 in the environment at
 	 * vvm_alloc_state).  The results are the same either way. */
@@ -249,6 +250,9 @@ enum {
 /* the lean form of a wide-record script (VVM_EXEC_NO_THROUGH_KERNEL) runs from this size on: it is two launches, which measured
  * faster than the whole script from 64 Ki instances on (24 streams each way: 23 against 29 us per Exec) */
 #define VVM_THROUGH_MIN_INSTANCES (64 * 1024)
+/* ... and from this size on where the whole script fits the general eight-wide kernel (nine to sixteen per-lane registers): 12 to
+ * 16 streams each way measured 1 to 3 % faster lean at 2 Mi instances, 8 to 12 % at 4 Mi, 7 to 17 % at 32 Mi, slower at 1 Mi */
+#define VVM_THROUGH_MIN_INSTANCES_EIGHT_WIDE (4 * 1024 * 1024)
 /* ... and inside vvm_exec_batch / vvm_batch_exec, where the launch is shared, a member whose script fits the light eight-wide
  * kernel (eight per-lane registers; bit 0x20000 of vvm_state_info's Flags) runs eight-wide from this size on */
 #define VVM_BATCH_LIGHT_MIN_INSTANCES (8 * 1024)

@@ -331,15 +331,14 @@ int link_more_passes(const vvm::ThawedScript& s, bool narrow, const vvm::LinkedP
 	return VVM_OK;
 }
 
-// The lean form of a script (vvm_state::lean), where it pays: the whole script needs more than the sixteen per-lane registers of
-// the eight-wide kernels (every stream it reads sits in one from the top of a tile), at least two of its outputs hand a 32-bit
-// input stream through unchanged, and without those the script fits the light eight-wide kernel.  Not built is not an error.
+// The lean form of a script (vvm_state::lean), where it can pay: the whole script does not fit the light eight-wide kernel (every
+// stream it reads sits in a per-lane register from the top of a tile), at least two of its outputs hand a 32-bit input stream
+// through unchanged, and without those it does fit.  From which size on an Exec takes the form: prepare().  Not built is not an error.
 int plan_through(vvm_state* st)
 {
 	const vvm::LinkedProgram& w = st->wide;
 	if (getenv("VVM_NO_THROUGH")) return VVM_OK;
 	if (st->light_ready || w.num_passes != 1 || w.num_chains != 1 || w.uses_ids || w.full_kernel || w.acquire_order.size() != 1) return VVM_OK;
-	if (!(w.many_registers || w.instances_per_lane == 1)) return VVM_OK;
 	const size_t O = w.through_input.size();
 	std::vector<uint32_t> through;
 	for (size_t o = 0; o < O; ++o) {
@@ -441,7 +440,10 @@ int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, P
 	{
 		// the lean form: for a single Exec large enough that a second launch pays (VVM_THROUGH_MIN_INSTANCES)
 		const uint32_t flags = opt ? opt->Flags : 0;
-		const bool big = ctx->NumInstances >= VVM_THROUGH_MIN_INSTANCES || (flags & VVM_EXEC_FORCE_EIGHT_WIDE);
+		// (two launches instead of one: against the four-wide kernels with 32 registers that pays from 64 Ki instances on, against the
+		// general eight-wide kernel, which a script of nine to sixteen registers runs on whole, from about 2 Mi)
+		const bool whole_is_slow = st->wide.many_registers || st->wide.instances_per_lane == 1;
+		const bool big = ctx->NumInstances >= (whole_is_slow ? VVM_THROUGH_MIN_INSTANCES : VVM_THROUGH_MIN_INSTANCES_EIGHT_WIDE) || (flags & VVM_EXEC_FORCE_EIGHT_WIDE);
 		if (st->lean_ready && pass == 0 && !narrow && !pe.in_batch && !pe.whole_only && !pe.reference_random && big &&
 		    !(flags & (VVM_EXEC_NO_EIGHT_WIDE | VVM_EXEC_NO_LIGHT_KERNEL | VVM_EXEC_NO_THROUGH_KERNEL))) {
 			pe.lean = true;

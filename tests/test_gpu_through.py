@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 EIGHT = abi.VVM_EXEC_FORCE_EIGHT_WIDE
 
 
-def _compare(n, extra_float, extra_int, death, flags=EIGHT, touch_one=False, instance_offset=0, expect_lean=True):
+def _compare(n, extra_float, extra_int, death, flags=EIGHT, touch_one=False, instance_offset=0, expect_lean=True, lean_from=64 * 1024):
     script = sc.wide_record_script(extra_float, extra_int, touch_one)
     ins = sc.streams(n, extra_float, extra_int, death)
     dts = sc.out_dtypes(extra_float, extra_int)
@@ -19,9 +19,10 @@ def _compare(n, extra_float, extra_int, death, flags=EIGHT, touch_one=False, ins
     width = []
     got, got_n, info = run_hip(script, [sc.CONSTANTS], ins, dts, n, instance_offset=instance_offset, flags=flags, last_width=width)
     assert bool(info.Flags & 0x80000) == expect_lean
-    runs_lean = expect_lean and not (flags & abi.VVM_EXEC_NO_THROUGH_KERNEL) and ((flags & EIGHT) or n >= 64 * 1024)
+    runs_lean = expect_lean and not (flags & abi.VVM_EXEC_NO_THROUGH_KERNEL) and ((flags & EIGHT) or n >= lean_from)
     if n > 0:
-        assert width == [8 if runs_lean or (flags & EIGHT and not expect_lean) else 4]
+        whole_width = 8 if (extra_float + extra_int <= 8 and ((flags & EIGHT) or n >= 256 * 1024)) else 4      # (up to sixteen streams: the general eight-wide kernel)
+        assert width == [8 if runs_lean else whole_width]
     assert got_n == want_n
     for g, w in zip(got, want):
         np.testing.assert_array_equal(g[instance_offset:instance_offset + got_n].view(np.uint32), w[instance_offset:instance_offset + want_n].view(np.uint32))
@@ -54,4 +55,10 @@ def test_large_and_by_its_own_choice():
 
 def test_scripts_that_stay_whole():
     _compare(5000, 0, 0, 0.5, expect_lean=False)      # fits the light kernel as it is
-    _compare(5000, 6, 0, 0.5, expect_lean=False)      # fourteen registers: the general eight-wide kernel
+
+
+def test_a_script_that_fits_the_general_eight_wide_kernel_goes_lean_later():
+    """Fourteen streams: the whole script runs eight-wide on the general kernel, and the lean form takes over from 4 Mi instances."""
+    _compare(5000, 6, 0, 0.5)                                        # forced
+    _compare(300000, 6, 0, 0.5, flags=0, lean_from=4 * 1024 * 1024)   # whole, eight-wide by the library's choice
+    _compare(4 * 1024 * 1024 + 3, 6, 0, 0.5, flags=0, lean_from=4 * 1024 * 1024)
