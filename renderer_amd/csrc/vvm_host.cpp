@@ -349,7 +349,15 @@ int plan_through(vvm_state* st)
 	std::string why;
 	std::vector<uint8_t> select(O, 0);
 	for (size_t o = 0; o < O; ++o) select[o] = w.through_input[o] < 0;
-	if (vvm::link_program(st->script, false, st->lean, why, 0, true, &select) != VVM_OK) return VVM_OK;
+	if (vvm::link_program(st->script, false, st->lean, why, 0, true, &select) != VVM_OK) {
+		// what the script computes does not fit the light kernel: the general eight-wide kernel leaves the ride words too, when the
+		// whole script is beyond it (more than sixteen registers) and the rest is not
+		st->lean = vvm::LinkedProgram();
+		if (!(w.many_registers || w.instances_per_lane == 1)) return VVM_OK;
+		if (vvm::link_program(st->script, false, st->lean, why, 0, false, &select) != VVM_OK) return VVM_OK;
+		const vvm::LinkedProgram& l = st->lean;
+		if (l.instances_per_lane != 4 || l.many_registers || l.full_kernel || l.num_passes != 1 || l.num_chains != 1) { st->lean = vvm::LinkedProgram(); return VVM_OK; }
+	}
 	const int rc = upload_code(st->lean, &st->d_code_lean);
 	if (rc != VVM_OK) return rc;
 	st->through = std::move(through);
@@ -445,12 +453,12 @@ int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, P
 		const bool whole_is_slow = st->wide.many_registers || st->wide.instances_per_lane == 1;
 		const bool big = ctx->NumInstances >= (whole_is_slow ? VVM_THROUGH_MIN_INSTANCES : VVM_THROUGH_MIN_INSTANCES_EIGHT_WIDE) || (flags & VVM_EXEC_FORCE_EIGHT_WIDE);
 		if (st->lean_ready && pass == 0 && !narrow && !pe.in_batch && !pe.whole_only && !pe.reference_random && big &&
-		    !(flags & (VVM_EXEC_NO_EIGHT_WIDE | VVM_EXEC_NO_LIGHT_KERNEL | VVM_EXEC_NO_THROUGH_KERNEL))) {
+		    !(flags & (VVM_EXEC_NO_EIGHT_WIDE | VVM_EXEC_NO_THROUGH_KERNEL)) && !(st->lean.light && (flags & VVM_EXEC_NO_LIGHT_KERNEL))) {
 			pe.lean = true;
 			pe.lp = &st->lean;
 			pe.d_code = st->d_code_lean;
 			pe.instances_per_lane = 8;
-			pe.light = true;
+			pe.light = st->lean.light;
 		}
 	}
 	if (pe.reference_random) {

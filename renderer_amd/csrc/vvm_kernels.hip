@@ -805,8 +805,9 @@ struct Pending {
 	// first chain's, `tiles` words on
 	bool     unresolved1;
 	uint32_t total1, base1, tiles;
-	uint32_t ride;                 // per lane, light kernel: the lane's acquireindex result for the outputs that wait in registers:
-	                               // keep bits [0:8), rank of the lane's first survivor [8:20), of its first one in the second half [20:32)
+	uint32_t ride;                 // per lane, eight instances per lane: the lane's acquireindex result (for the light kernel's outputs that wait in
+	                               // registers, and for vvm_through_kernel): keep bits [0:8), rank of the lane's first survivor [8:20), of its first
+	                               // one in the second half [20:32)
 };
 #define STAGED_COUNT(end) ((end) ? (((end) - 1u) & (VVM_STAGE_SLOTS - 1u)) + 1u : 0u)
 #define STAGED_FIRST(end) ((end) ? ((end) - 1u) & ~(VVM_STAGE_SLOTS - 1u) : 0u)
@@ -974,6 +975,7 @@ template <int V, bool FULL, bool LIGHT, bool TWO, typename VEC> DEV void store_t
 	static_assert(VVM_STAGE_SLOTS == 8, "store_slots is written for eight slots");
 	if constexpr (LIGHT) {
 		// for vvm_through_kernel, when the Exec has streams that stay out of its program: the lane's acquireindex result of this tile
+		// (the light kernel keeps the word for its riding outputs anyway; the general eight-wide kernel stores it at the end of run_tile)
 		const uint64_t ride_base = sload64(p.out_list - 3, 0);
 		if (ride_base != 0) {
 			const rsrc_t rr = make_rsrc(ride_base + (uint64_t)p.tile_local * (VVM_BLOCK_THREADS * 4u), VVM_BLOCK_THREADS * 4u);
@@ -1616,6 +1618,14 @@ leave_run:
 	pend.unresolved = t_pending; pend.total = t_total; pend.base = t_base; pend.stage_end = stage_end; pend.last = last_tile;
 	pend.tile_local = tile_local; pend.status = status; pend.out_list = c.out_list;
 	pend.ride = t_keep | (t_rank << 8) | (t_rank_b << 20);
+	if constexpr (V == 8 && !IS_LIGHT(V, SPILL)) {
+		// the same word for vvm_through_kernel from the general eight-wide kernel, straight from the tile that made it (see store_tile)
+		const uint64_t ride_base = sload64(c.out_list - 3, 0);
+		if (ride_base != 0) {
+			const rsrc_t rr = make_rsrc(ride_base + (uint64_t)tile_local * (VVM_BLOCK_THREADS * 4u), VVM_BLOCK_THREADS * 4u);
+			__builtin_amdgcn_raw_buffer_store_b32(t_keep | (t_rank << 8) | (t_rank_b << 20), rr, (int)(c.tid * 4u), 0, 0);
+		}
+	}
 	if constexpr (IS_LIGHT(V, SPILL)) { K0 = R0; K1 = R1; K2 = R2; K3 = R3; K4 = R4; K5 = R5; K6 = R6; K7 = R7; }
 }
 

@@ -11,8 +11,8 @@ pytestmark = pytest.mark.gpu
 EIGHT = abi.VVM_EXEC_FORCE_EIGHT_WIDE
 
 
-def _compare(n, extra_float, extra_int, death, flags=EIGHT, touch_one=False, instance_offset=0, expect_lean=True, lean_from=64 * 1024):
-    script = sc.wide_record_script(extra_float, extra_int, touch_one)
+def _compare(n, extra_float, extra_int, death, flags=EIGHT, touch_one=False, instance_offset=0, expect_lean=True, lean_from=64 * 1024, more_math=0):
+    script = sc.wide_record_script(extra_float, extra_int, touch_one, more_math)
     ins = sc.streams(n, extra_float, extra_int, death)
     dts = sc.out_dtypes(extra_float, extra_int)
     want, want_n, _ = run_oracle(script, [sc.CONSTANTS], ins, dts, n, instance_offset=instance_offset)
@@ -62,3 +62,16 @@ def test_a_script_that_fits_the_general_eight_wide_kernel_goes_lean_later():
     _compare(5000, 6, 0, 0.5)                                        # forced
     _compare(300000, 6, 0, 0.5, flags=0, lean_from=4 * 1024 * 1024)   # whole, eight-wide by the library's choice
     _compare(4 * 1024 * 1024 + 3, 6, 0, 0.5, flags=0, lean_from=4 * 1024 * 1024)
+
+
+@pytest.mark.parametrize("n,death", [(1, 0.0), (2049, 0.5), (70001, 0.3), (70001, 1.0), (600001, 0.5)])
+def test_what_the_script_computes_needs_the_general_eight_wide_kernel(n, death):
+    """Six of the extra streams are computed with: fourteen streams in the lean program, which then runs on the general eight-wide
+    kernel (which leaves the ride words as the light one does); twelve more handed through."""
+    info = _compare(n, 18, 1, death, more_math=6)
+    assert (info.Flags >> 24) == 14
+
+
+def test_more_than_eight_computed_outputs_flush_in_the_middle_of_a_tile():
+    """Eight fountain outputs and six computed ones: two groups of staging slots in the lean program, twelve streams handed through."""
+    _compare(70001, 18, 0, 0.5, more_math=6, instance_offset=3)

@@ -7,9 +7,11 @@ import numpy as np
 from renderer_amd.assembler import FLOAT, INT32, Script
 
 
-def wide_record_script(extra_float: int, extra_int: int, touch_one: bool = False):
+def wide_record_script(extra_float: int, extra_int: int, touch_one: bool = False, more_math: int = 0):
     """8 float streams of the fountain + extra_float + extra_int handed-through streams.  touch_one: one of the extra float
-    streams is also read by the arithmetic (so the program loads it and the copy kernel reads it again)."""
+    streams is also read by the arithmetic (so the program loads it and the copy kernel reads it again).  more_math: that many of
+    the extra float streams are not handed through but scaled and offset (what the script computes then needs more registers than
+    the light kernel has)."""
     s = Script()
     dt, drag = s.const(0), s.const(4)
     pos = [s.input(0, FLOAT, k) for k in range(3)]
@@ -26,8 +28,13 @@ def wide_record_script(extra_float: int, extra_int: int, touch_one: bool = False
         # (touch_one: the first extra stream stands in for pos.x, which is then not read at all, so that the computed part still
         # reads eight streams)
         s.op("mad", v1[c], dt, more_f[0] if (touch_one and more_f and c == 0) else pos[c], p1[c])
+    changed = []
+    for k in range(min(more_math, extra_float)):
+        t = s.temp(); s.op("mad", more_f[k], drag, age1, t)
+        changed.append(t)
     s.output_data(FLOAT, 0, [(p1[c], s.output(0, FLOAT, c)) for c in range(3)] + [(v1[c], s.output(0, FLOAT, 3 + c)) for c in range(3)] +
-                  [(age1, s.output(0, FLOAT, 6)), (life, s.output(0, FLOAT, 7))] + [(more_f[k], s.output(0, FLOAT, 8 + k)) for k in range(extra_float)])
+                  [(age1, s.output(0, FLOAT, 6)), (life, s.output(0, FLOAT, 7))] +
+                  [(changed[k] if k < len(changed) else more_f[k], s.output(0, FLOAT, 8 + k)) for k in range(extra_float)])
     if extra_int:
         s.output_data(INT32, 0, [(more_i[k], s.output(0, INT32, k)) for k in range(extra_int)])
     return s.build(alias_outputs=True)

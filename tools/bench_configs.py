@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--force-eight", action="store_true", help="single Execs: eight instances per lane whatever the size (and with it the lean form of a wide-record script)")
     ap.add_argument("--extras", default="16,8", help="wide_record: numbers of handed-through attributes to run")
     ap.add_argument("--wide-particles", type=int, default=32 * 1024 * 1024, help="wide_record: instances")
+    ap.add_argument("--more-math", type=int, default=0, help="wide_record: that many of the extra attributes are scaled and offset instead of handed through")
     ap.add_argument("--separate-passes", action="store_true", help="two_datasets: one launch per dataset instead of one launch for both")
     ap.add_argument("--batch-variants", type=int, default=64, help="bytecode variants of the batch (the first 16 all fit the light kernel)")
     ap.add_argument("--batch-flags", type=int, default=0, help="vvm_exec_options.Flags of every member of the batch (4: force eight instances per lane)")
@@ -189,8 +190,13 @@ def main():
             for c in range(3):
                 s.op("mad_mul", s.const(1 + c), dt, vel[c], drag, v1[c])
                 s.op("mad", v1[c], dt, pos[c], p1[c])
+            changed = []
+            for k in range(min(args.more_math, extra)):
+                t = s.temp(); s.op("mad", rest[k], drag, age1, t)
+                changed.append(t)
             s.output_data(FLOAT, 0, [(p1[c], s.output(0, FLOAT, c)) for c in range(3)] + [(v1[c], s.output(0, FLOAT, 3 + c)) for c in range(3)] +
-                          [(age1, s.output(0, FLOAT, 6)), (life, s.output(0, FLOAT, 7))] + [(rest[k], s.output(0, FLOAT, 8 + k)) for k in range(extra)])
+                          [(age1, s.output(0, FLOAT, 6)), (life, s.output(0, FLOAT, 7))] +
+                          [(changed[k] if k < len(changed) else rest[k], s.output(0, FLOAT, 8 + k)) for k in range(extra)])
             class WR:
                 pass
             w = WR()
@@ -199,7 +205,7 @@ def main():
             n = args.wide_particles
             base = scripts.fountain_streams_torch(0, n, dev, pad=PAD)
             more = [torch.rand(n + PAD, dtype=torch.float32, device=dev) for _ in range(extra)]
-            run_single("fountain with %d attributes handed through (%d streams in / %d out), %d instances" % (extra, 8 + extra, 8 + extra, n), w, base + more, 8 + extra, n)
+            run_single("fountain with %d more attributes, %d of them computed with, the others handed through (%d streams in / %d out), %d instances" % (extra, min(args.more_math, extra), 8 + extra, 8 + extra, n), w, base + more, 8 + extra, n)
             del more
     if "two_datasets" in which:
         # the fountain update with a second dataset that receives the particles that die this tick (position and age): both
