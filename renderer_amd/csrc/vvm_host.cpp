@@ -334,33 +334,37 @@ int link_more_passes(const vvm::ThawedScript& s, bool narrow, const vvm::LinkedP
 // The lean form of a script (vvm_state::lean), where it can pay: the whole script does not fit the light eight-wide kernel (every
 // stream it reads sits in a per-lane register from the top of a tile), at least two of its outputs hand a 32-bit input stream
 // through unchanged, and without those it does fit.  From which size on an Exec takes the form: prepare().  Not built is not an error.
-int plan_through(vvm_state* st)
+// (host only: vvm_inspect_blob plans the same way without a device)
+bool plan_through_programs(const vvm::ThawedScript& script, const vvm::LinkedProgram& w, bool fits_light, vvm::LinkedProgram& lean, std::vector<uint32_t>& through)
 {
-	const vvm::LinkedProgram& w = st->wide;
-	if (getenv("VVM_NO_THROUGH")) return VVM_OK;
-	if (st->light_ready || w.num_passes != 1 || w.num_chains != 1 || w.uses_ids || w.full_kernel || w.acquire_order.size() != 1) return VVM_OK;
+	through.clear();
+	if (getenv("VVM_NO_THROUGH")) return false;
+	if (fits_light || w.num_passes != 1 || w.num_chains != 1 || w.uses_ids || w.full_kernel || w.acquire_order.size() != 1) return false;
 	const size_t O = w.through_input.size();
-	std::vector<uint32_t> through;
 	for (size_t o = 0; o < O; ++o) {
-		if (w.through_input[o] == -2) return VVM_OK;
+		if (w.through_input[o] == -2) { through.clear(); return false; }
 		if (w.through_input[o] >= 0) through.push_back((uint32_t)o);
 	}
-	if (through.size() < 2 || through.size() > VVM_THROUGH_MAX_PAIRS) return VVM_OK;
+	if (through.size() < 2 || through.size() > VVM_THROUGH_MAX_PAIRS) { through.clear(); return false; }
 	std::string why;
 	std::vector<uint8_t> select(O, 0);
 	for (size_t o = 0; o < O; ++o) select[o] = w.through_input[o] < 0;
-	if (vvm::link_program(st->script, false, st->lean, why, 0, true, &select) != VVM_OK) {
-		// what the script computes does not fit the light kernel: the general eight-wide kernel leaves the ride words too, when the
-		// whole script is beyond it (more than sixteen registers) and the rest is not
-		st->lean = vvm::LinkedProgram();
-		if (!(w.many_registers || w.instances_per_lane == 1)) return VVM_OK;
-		if (vvm::link_program(st->script, false, st->lean, why, 0, false, &select) != VVM_OK) return VVM_OK;
-		const vvm::LinkedProgram& l = st->lean;
-		if (l.instances_per_lane != 4 || l.many_registers || l.full_kernel || l.num_passes != 1 || l.num_chains != 1) { st->lean = vvm::LinkedProgram(); return VVM_OK; }
-	}
+	lean = vvm::LinkedProgram();
+	if (vvm::link_program(script, false, lean, why, 0, true, &select) == VVM_OK) return true;
+	// what the script computes does not fit the light kernel: the general eight-wide kernel leaves the ride words too, when the
+	// whole script is beyond it (more than sixteen registers) and the rest is not
+	lean = vvm::LinkedProgram();
+	bool ok = (w.many_registers || w.instances_per_lane == 1) && vvm::link_program(script, false, lean, why, 0, false, &select) == VVM_OK;
+	ok = ok && lean.instances_per_lane == 4 && !lean.many_registers && !lean.full_kernel && lean.num_passes == 1 && lean.num_chains == 1;
+	if (!ok) { lean = vvm::LinkedProgram(); through.clear(); }
+	return ok;
+}
+
+int plan_through(vvm_state* st)
+{
+	if (!plan_through_programs(st->script, st->wide, st->light_ready, st->lean, st->through)) return VVM_OK;
 	const int rc = upload_code(st->lean, &st->d_code_lean);
 	if (rc != VVM_OK) return rc;
-	st->through = std::move(through);
 	st->lean_ready = true;
 	return VVM_OK;
 }
@@ -1780,6 +1784,14 @@ VVM_API int vvm_inspect_blob(const uint8_t* blob, size_t num_bytes, vvm_program_
 	if (rc == VVM_OK) rc = vvm::link_program(s, false, lp, err);
 	if (rc != VVM_OK) return fail(rc, err);
 	fill_info(s, lp, out);
+	// (the flags vvm_state_info adds for the state's other programs)
+	vvm::LinkedProgram other;
+	std::string why;
+	const bool fits_light = lp.instances_per_lane == 4 && !lp.full_kernel && !lp.many_registers && lp.num_passes == 1 &&
+	                        vvm::link_program(s, false, other, why, 0, true) == VVM_OK;
+	if (fits_light) out->Flags |= 0x20000u;
+	std::vector<uint32_t> through;
+	if (plan_through_programs(s, lp, fits_light, other, through)) out->Flags |= 0x80000u | ((uint32_t)through.size() << 24);
 	return VVM_OK;
 }
 

@@ -1,0 +1,76 @@
+"""Which scripts get a lean form (what they compute as a program for an eight-wide kernel, the streams they hand through left to
+the copy kernel): the planning that vvm_alloc_state does, seen through vvm_inspect_blob, which needs no device."""
+import struct
+
+import pytest
+
+import through_cases as tc
+from renderer_amd import abi
+from renderer_amd.assembler import FLOAT, INT32, Script
+
+LIGHT, LEAN = 0x20000, 0x80000
+
+
+def be():
+    return abi.load_hip_backend()
+
+
+def flags(script):
+    return be().inspect_blob(script.blob).Flags
+
+
+def test_the_fountain_fits_the_light_kernel_as_it_is():
+    f = flags(tc.wide_record_script(0, 0))
+    assert f & LIGHT and not f & LEAN
+
+
+@pytest.mark.parametrize("extra_float,extra_int", [(2, 0), (6, 0), (8, 1), (14, 2), (30, 0), (40, 7)])
+def test_wide_records_get_a_lean_form(extra_float, extra_int):
+    f = flags(tc.wide_record_script(extra_float, extra_int))
+    assert f & LEAN and not f & LIGHT
+    assert (f >> 24) == extra_float + extra_int + 1      # and the lifetime, which the fountain hands through as well
+
+
+def test_one_handed_through_stream_is_not_worth_a_second_launch():
+    # the fountain with seven computed outputs and the lifetime handed through, plus one more stream computed with: nine registers
+    s = tc.wide_record_script(1, 0, more_math=1)
+    f = flags(s)
+    assert not f & LEAN and not f & LIGHT
+
+
+def test_more_streams_than_the_copy_kernel_takes_pairs():
+    assert not flags(tc.wide_record_script(60, 0)) & LEAN
+
+
+def test_what_the_script_computes_may_need_the_general_eight_wide_kernel():
+    f = flags(tc.wide_record_script(18, 1, more_math=6))      # fourteen streams computed with: beyond the light kernel
+    assert f & LEAN and (f >> 24) == 14
+    # ... but when the whole script still fits that kernel, a lean program that does not fit the light one gains nothing
+    assert not flags(tc.wide_record_script(8, 0, more_math=6)) & LEAN
+    # and what is computed must fit it: twenty streams computed with do not
+    assert not flags(tc.wide_record_script(30, 0, more_math=12)) & LEAN
+
+
+def test_an_output_written_twice_keeps_the_script_whole():
+    s = Script()
+    x = [s.input(0, FLOAT, k) for k in range(20)]
+    s.acquireindex(s.const(0), 0)
+    t = s.temp(); s.op("add", x[0], x[1], t)
+    s.output_data(FLOAT, 0, [(t, s.output(0, FLOAT, 0))] + [(x[k], s.output(0, FLOAT, k)) for k in range(1, 20)])
+    s.output_data(FLOAT, 0, [(x[3], s.output(0, FLOAT, 2))])      # output 2 a second time
+    assert not flags(s.build()) & LEAN
+
+
+def test_streams_that_are_not_plain_32_bit_copies_stay_in_the_program():
+    """Half streams, no-advance inputs and outputs ahead of the acquireindex are not handed to the copy kernel."""
+    from renderer_amd.assembler import HALF
+    s = Script()
+    x = [s.input(0, FLOAT, k) for k in range(18)]
+    h = s.input(0, HALF, 0)
+    na = s.input(0, FLOAT, 18, noadvance=True)
+    s.acquireindex(s.const(0), 0)
+    t = s.temp(); s.op("add", x[0], x[1], t)
+    s.output_data(FLOAT, 0, [(t, s.output(0, FLOAT, 0))] + [(x[k], s.output(0, FLOAT, k)) for k in range(1, 18)] + [(na, s.output(0, FLOAT, 18))])
+    s.output_data(HALF, 0, [(h, s.output(0, HALF, 0))], from_half=True)
+    f = flags(s.build())
+    assert f & LEAN and (f >> 24) == 17

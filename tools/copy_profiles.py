@@ -15,14 +15,15 @@ for src, dst in (("prof_%s/" % RUN + "bench_kernel_stats.csv", PRE + "_bench_ker
                  ("configs_%s.jsonl" % RUN, PRE + "_other_configs.jsonl"), ("ulp_%s.json" % RUN, PRE + "_ulp_report.json"),
                  ("prof_%s_configs/" % RUN + "configs_kernel_stats.csv", PRE + "_configs_kernel_stats.csv")):
     shutil.copy(os.path.join(G, src), os.path.join(P, dst))
-rows = [r for r in csv.DictReader(open(os.path.join(G, "prof_%s_configs/" % RUN + "configs_kernel_trace.csv"))) if "vvm_exec" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(os.path.join(G, "prof_%s_configs/" % RUN + "configs_kernel_trace.csv"))) if "vvm_exec" in r["Kernel_Name"] or "vvm_through" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 groups = []
 for r in rows:
     o = {"kernel": r["Kernel_Name"].split("(")[0].replace("void ", ""), "grid": int(r["Grid_Size_X"]),
          "us": round((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, 2)}
-    g = groups[-1] if groups else None
-    if g and g["kernel"] == o["kernel"] and g["grid"] == o["grid"] and 0.25 < o["us"] / g["us"][0] < 4:
+    # (an Exec may be two kernels, the program and the copy kernel for handed-through streams: look a few groups back)
+    g = next((c for c in groups[-3:][::-1] if c["kernel"] == o["kernel"] and c["grid"] == o["grid"] and 0.25 < o["us"] / c["us"][0] < 4), None)
+    if g:
         g["us"].append(o["us"])
     else:
         o["us"] = [o["us"]]
