@@ -22,7 +22,7 @@ for r in rows:
     o = {"kernel": r["Kernel_Name"].split("(")[0].replace("void ", ""), "grid": int(r["Grid_Size_X"]),
          "us": round((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, 2)}
     # (an Exec may be two kernels, the program and the copy kernel for handed-through streams: look a few groups back)
-    g = next((c for c in groups[-3:][::-1] if c["kernel"] == o["kernel"] and c["grid"] == o["grid"] and 0.25 < o["us"] / c["us"][0] < 4), None)
+    g = next((c for c in groups[-3:][::-1] if c["kernel"] == o["kernel"] and c["grid"] == o["grid"] and 0.7 < o["us"] / c["us"][0] < 1.4), None)
     if g:
         g["us"].append(o["us"])
     else:
