@@ -40,6 +40,8 @@ def main():
             blobs.append(gpu_fuzz_linker.gen(seed)[0].blob)
         except AssertionError:
             pass
+    import through_cases
+    blobs += [through_cases.wide_record_script(f, i, t, m).blob for f, i, t, m in ((16, 0, False, 0), (14, 2, False, 0), (12, 0, True, 0), (18, 1, False, 6), (40, 7, False, 0), (60, 0, False, 0), (2, 0, False, 0))]
     originals.append(original_cases.fountain()[0])
     for i, b in enumerate(blobs):
         with open(os.path.join(out, "b%05d.bin" % i), "wb") as f:

@@ -18,6 +18,16 @@ int main(int argc, char** argv)
 			int rc = vvm::link_program(s, mode == 1, lp, err, 0, mode == 2);
 			if (rc == 0)
 				for (uint32_t k = 1; k < lp.num_passes; ++k) { vvm::LinkedProgram more; vvm::link_program(s, mode == 1, more, err, k, false); }
+			// the program without the outputs that hand a stream through (the lean form), and one with every other output only
+			if (rc == 0 && mode != 1 && !lp.through_input.empty()) {
+				std::vector<uint8_t> select(lp.through_input.size());
+				for (size_t o = 0; o < select.size(); ++o) select[o] = lp.through_input[o] < 0;
+				vvm::LinkedProgram lean;
+				vvm::link_program(s, false, lean, err, 0, mode == 2, &select);
+				for (size_t o = 0; o < select.size(); ++o) select[o] = (o & 1u) != 0;
+				vvm::LinkedProgram some;
+				vvm::link_program(s, false, some, err, 0, mode == 2, &select);
+			}
 		}
 	}
 	printf("done, %d blobs did not thaw\n", bad);
