@@ -240,7 +240,9 @@ enum {
 	 * lean form as well: a program for the light eight-wide kernel with everything the script computes, and the list of the
 	 * handed-through streams, which a copy kernel moves behind that program's launch (it takes every survivor's place from what
 	 * the program's acquireindex left).  A single Exec of at least VVM_THROUGH_MIN_INSTANCES instances (VVM_THROUGH_MIN_INSTANCES_EIGHT_WIDE
-	 * where the whole script still fits the general eight-wide kernel) runs that way (bit
+	 * where the whole script still fits the general eight-wide kernel) runs that way, and so does a member of a batch of at least
+	 * VVM_BATCH_LIGHT_MIN_INSTANCES instances whose whole script needs more than sixteen registers (one copy-kernel launch serves
+	 * all such members of a slice) (bit
 	 * 0x80000 of vvm_state_info's Flags: the state has the form; the top byte holds the number of handed-through streams).
 	 * This flag runs the script whole instead (tests / comparison; so does VVM_NO_THROUGH=1 in the environment at
 	 * vvm_alloc_state).  The results are the same either way. */

@@ -177,7 +177,8 @@ struct VvmXorwowFill {
 struct VvmThroughArgs {
 	const unsigned long long* status;   // the Exec's look-back words
 	const uint32_t* ride;
-	uint32_t num_instances, num_tiles, num_pairs, pad;
+	uint32_t num_instances, num_tiles, num_pairs;
+	uint32_t pad;                       // vvm_through_batch_kernel: the number of the Exec's first tile within the launch
 	uint64_t src[VVM_THROUGH_MAX_PAIRS];   // byte address of element [InstanceOffset] of the input stream
 	uint64_t dst[VVM_THROUGH_MAX_PAIRS];   // ... of the output stream
 };

@@ -455,8 +455,13 @@ int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, P
 		// (two launches instead of one: against the four-wide kernels with 32 registers that pays from 64 Ki instances on, against the
 		// general eight-wide kernel, which a script of nine to sixteen registers runs on whole, from about 2 Mi)
 		const bool whole_is_slow = st->wide.many_registers || st->wide.instances_per_lane == 1;
-		const bool big = ctx->NumInstances >= (whole_is_slow ? VVM_THROUGH_MIN_INSTANCES : VVM_THROUGH_MIN_INSTANCES_EIGHT_WIDE) || (flags & VVM_EXEC_FORCE_EIGHT_WIDE);
-		if (st->lean_ready && pass == 0 && !narrow && !pe.in_batch && !pe.whole_only && !pe.reference_random && big &&
+		// (a member of a batch shares its launches with the others: there the form pays from the size on from which the light kernel
+		// does, for scripts that would otherwise run on the kernels with 32 registers and whose lean program fits the light kernel;
+		// 4096 emitters of 16 Ki instances, 24 streams each way: 3.11 ms whole)
+		const bool big = (pe.in_batch ? (whole_is_slow && st->lean.light && ctx->NumInstances >= VVM_BATCH_LIGHT_MIN_INSTANCES)
+		                              : ctx->NumInstances >= (whole_is_slow ? VVM_THROUGH_MIN_INSTANCES : VVM_THROUGH_MIN_INSTANCES_EIGHT_WIDE)) ||
+		                 ((flags & VVM_EXEC_FORCE_EIGHT_WIDE) && (!pe.in_batch || st->lean.light));
+		if (st->lean_ready && pass == 0 && !narrow && ctx->NumInstances > 0 && !pe.whole_only && !pe.reference_random && big &&
 		    !(flags & (VVM_EXEC_NO_EIGHT_WIDE | VVM_EXEC_NO_THROUGH_KERNEL)) && !(st->lean.light && (flags & VVM_EXEC_NO_LIGHT_KERNEL))) {
 			pe.lean = true;
 			pe.lp = &st->lean;
@@ -1246,6 +1251,7 @@ struct BatchWorkspace {
 	int32_t* d_counts = nullptr; int32_t* h_counts = nullptr; size_t counts_capacity = 0;   // survivor counts of all Execs of a batch
 	VvmLaunchState* d_launch[8] = {};
 	VvmLaunchState* h_launch = nullptr;
+	uint32_t* d_ride = nullptr; uint32_t ride_capacity = 0;      // one word per lane and tile for the lean members (see vvm_state::lean), same tile numbering as d_status
 	// Every launch of a batch tags its look-back words with a number drawn from this counter.  The launches share d_status, at
 	// offsets that move from call to call, through one set of launch words per kernel shape: with each set counting its own
 	// epochs, a word written through one set could carry the tag another set reaches later, and a tile that polls before its
@@ -1267,6 +1273,7 @@ struct BatchWorkspace {
 		if (host) (void)hipHostFree(host);
 		if (dev) (void)hipFree(dev);
 		if (d_status) (void)hipFree(d_status);
+		if (d_ride) (void)hipFree(d_ride);
 		if (d_counts) (void)hipFree(d_counts);
 		if (h_counts) (void)hipHostFree(h_counts);
 		if (h_launch) (void)hipHostFree(h_launch);
@@ -1278,8 +1285,8 @@ struct BatchWorkspace {
 		}
 		if (upload_stream) (void)hipStreamDestroy(upload_stream);
 		if (stream) (void)hipStreamDestroy(stream);
-		host = dev = nullptr; d_status = nullptr; d_counts = h_counts = nullptr; h_launch = nullptr; stream = upload_stream = nullptr;
-		bytes = 0; status_capacity = 0; counts_capacity = 0;
+		host = dev = nullptr; d_status = nullptr; d_counts = h_counts = nullptr; h_launch = nullptr; stream = upload_stream = nullptr; d_ride = nullptr;
+		bytes = 0; status_capacity = 0; counts_capacity = 0; ride_capacity = 0;
 	}
 };
 BatchWorkspace g_batch;      // the workspace of vvm_exec_batch; a vvm_batch handle owns one of its own
@@ -1290,7 +1297,12 @@ std::mutex g_batch_stamp_mutex;
 // register tier, full), one launch per group.  Everything here is decided from the contexts' sizes and the states' programs;
 // a vvm_batch handle keeps it from call to call.
 struct BatchGroup { int key = 0; std::vector<int> members; uint32_t tiles = 0, spill = 0; size_t desc_off = 0; };
-struct BatchSlice { int first = 0, count = 0; std::vector<BatchGroup> groups; size_t region_off = 0, desc_bytes = 0, head_bytes = 0, used_bytes = 0; };
+struct BatchSlice {
+	int first = 0, count = 0; std::vector<BatchGroup> groups; size_t region_off = 0, desc_bytes = 0, head_bytes = 0, used_bytes = 0;
+	// the lean members of the slice (vvm_state::lean): their VvmThroughArgs blocks lie side by side at through_off of the parameter
+	// buffer, in the order of `through_members`, and one launch of vvm_through_batch_kernel behind the slice's kernels serves them all
+	std::vector<int> through_members; size_t through_off = 0; uint32_t through_tiles = 0, through_max_pairs = 0;
+};
 struct BatchPlan {
 	int n = 0;
 	std::vector<PreparedExec> pes;
@@ -1299,6 +1311,9 @@ struct BatchPlan {
 	std::vector<size_t> counts_off;         // [i] first word of Exec i in the batch's counts array
 	std::vector<size_t> desc_off, const_off, table_off;   // [i] where Exec i's descriptor, constants and other tables lie in the parameter buffer
 	std::vector<uint32_t> status_off, first_tile;   // [i] first look-back word; ticket number of the Exec's first tile within its launch
+	std::vector<size_t> through_off;                // [i] lean members: where the Exec's VvmThroughArgs block lies in the parameter buffer
+	std::vector<uint32_t> through_first_tile;       // [i] ... and the number of its first tile within the slice's copy-kernel launch
+	bool any_lean = false;
 	size_t total_counts = 0, total_bytes = 0;
 	uint32_t total_tiles = 0;
 };
@@ -1310,6 +1325,7 @@ void batch_layout(BatchPlan& plan, const vvm_exec_context* ctxs)
 {
 	plan.total_tiles = 0;
 	plan.total_counts = 0;
+	plan.any_lean = false;
 	size_t needed = 0;
 	for (int i = 0; i < plan.n; ++i) {
 		plan.counts_off[(size_t)i] = plan.total_counts;
@@ -1347,6 +1363,20 @@ void batch_layout(BatchPlan& plan, const vvm_exec_context* ctxs)
 			}
 			grp.tiles = first_tile;
 		}
+		slice.through_members.clear();
+		slice.through_tiles = 0; slice.through_max_pairs = 0;
+		slice.through_off = align_up(table_off, 256);
+		for (const BatchGroup& grp : slice.groups)
+			for (int i : grp.members) {
+				if (!plan.pes[(size_t)i].lean) continue;
+				plan.through_off[(size_t)i] = slice.through_off + slice.through_members.size() * sizeof(VvmThroughArgs);
+				plan.through_first_tile[(size_t)i] = slice.through_tiles;
+				slice.through_members.push_back(i);
+				slice.through_tiles += plan.pes[(size_t)i].tiles;
+				slice.through_max_pairs = std::max<uint32_t>(slice.through_max_pairs, (uint32_t)ctxs[i].VVMState->through.size());
+				plan.any_lean = true;
+			}
+		if (!slice.through_members.empty()) table_off = slice.through_off + slice.through_members.size() * sizeof(VvmThroughArgs);
 		slice.used_bytes = table_off - slice.region_off;
 		needed += align_up(slice.used_bytes, 256);
 	}
@@ -1364,6 +1394,7 @@ int batch_plan(BatchWorkspace& ws, vvm_exec_context* ctxs, int n, const vvm_exec
 	plan.single.assign((size_t)n, 0);
 	plan.counts_off.assign((size_t)n, 0); plan.desc_off.assign((size_t)n, 0); plan.const_off.assign((size_t)n, 0); plan.table_off.assign((size_t)n, 0);
 	plan.status_off.assign((size_t)n, 0); plan.first_tile.assign((size_t)n, 0);
+	plan.through_off.assign((size_t)n, 0); plan.through_first_tile.assign((size_t)n, 0);
 	plan.slices.assign((size_t)num_slices, BatchSlice());
 	// The first slice is the smallest (the GPU idles while it is filled), and each later one is as large as all before it together:
 	// filling an Exec's block takes the host about half the time the GPU needs for the Exec, so the fill stays ahead.
@@ -1413,6 +1444,11 @@ int batch_ensure_buffers(BatchWorkspace& ws, const BatchPlan& plan)
 		HIP_TRY(hipMalloc((void**)&ws.d_status, (size_t)ws.status_capacity * 8));
 		HIP_TRY(memset_and_wait(ws.d_status, 0, (size_t)ws.status_capacity * 8));      // tag 0 is never valid
 	}
+	if (plan.any_lean && plan.total_tiles > ws.ride_capacity) {
+		if (ws.d_ride) (void)hipFree(ws.d_ride);
+		ws.ride_capacity = plan.total_tiles + plan.total_tiles / 4 + 1024;
+		HIP_TRY(hipMalloc((void**)&ws.d_ride, (size_t)ws.ride_capacity * VVM_BLOCK_THREADS * 4u));
+	}
 	const size_t launch_slots = 4 * 8;      // (slices x groups)
 	if (!ws.h_launch) HIP_TRY(hipHostMalloc((void**)&ws.h_launch, launch_slots * sizeof(VvmLaunchState), hipHostMallocDefault));
 	for (const BatchSlice& slice : plan.slices)
@@ -1444,8 +1480,20 @@ int batch_ensure_buffers(BatchWorkspace& ws, const BatchPlan& plan)
 // measured slower: 0.58 ms against 0.42 ms for 4096 Execs).
 int batch_fill_exec(BatchWorkspace& ws, const BatchPlan& plan, vvm_exec_context* ctxs, const vvm_exec_options* opts, int i, std::vector<uint8_t>& scratch)
 {
-	const PreparedExec& pe = plan.pes[(size_t)i];
+	PreparedExec pe = plan.pes[(size_t)i];
 	vvm_state* st = ctxs[i].VVMState;
+	if (pe.lean) {
+		// the program leaves its ride words in the batch's array, at the tiles its look-back words have; the Exec's block for the
+		// copy kernel goes into the slice's row of such blocks
+		uint32_t* ride = ws.d_ride + (size_t)plan.status_off[(size_t)i] * VVM_BLOCK_THREADS;
+		pe.ride_addr = (uint64_t)(uintptr_t)ride;
+		VvmThroughArgs* t = (VvmThroughArgs*)(ws.host + plan.through_off[(size_t)i]);
+		memset(t, 0, sizeof(*t));
+		t->status = ws.d_status + plan.status_off[(size_t)i]; t->ride = ride;
+		t->num_instances = (uint32_t)ctxs[i].NumInstances; t->num_tiles = pe.tiles; t->pad = plan.through_first_tile[(size_t)i];
+		const int trc = fill_through(st, &ctxs[i], *t);
+		if (trc != VVM_OK) return trc;
+	}
 	// tables live at table_off in the device buffer; fill_params computes table addresses as dev + pe.off_*
 	uint8_t* dev_block = ws.dev + plan.table_off[(size_t)i];
 	scratch.resize(pe.bytes);
@@ -1486,6 +1534,11 @@ int batch_launch_slice(BatchWorkspace& ws, const BatchPlan& plan, int sl, size_t
 		                                       grid_for(grp.tiles, pe0.instances_per_lane, lp.full_kernel, pe0.launch_many()), ws.stream, nullptr, 0, launch_tag, 0);
 		if (lrc != 0) { (void)hipStreamSynchronize(ws.stream); return hip_fail((hipError_t)lrc, "batched kernel launch"); }
 		HIP_TRY(hipMemcpyAsync(&ws.h_launch[(size_t)sl * 8 + g], ws.d_launch[g], 80, hipMemcpyDeviceToHost, ws.stream));
+	}
+	if (!slice.through_members.empty()) {
+		const int trc = vvm_launch_through_batch_kernel((const VvmThroughArgs*)(ws.dev + slice.through_off), (uint32_t)slice.through_members.size(), slice.through_tiles,
+		                                                slice.through_max_pairs, ws.stream);
+		if (trc != 0) { (void)hipStreamSynchronize(ws.stream); return hip_fail((hipError_t)trc, "batched kernel launch (handed-through streams)"); }
 	}
 	// the slice's counts come back behind its kernels, so that the host can hand them to the contexts while later slices run
 	const size_t c0 = plan.counts_off[(size_t)slice.first];
@@ -1718,6 +1771,20 @@ VVM_API int vvm_batch_exec(vvm_batch* b, uint32_t changed)
 				d->status = ws.d_status + plan.status_off[(size_t)i];
 			}
 			upload = std::max(upload, plan.slices[0].desc_bytes);
+			if (plan.any_lean) {
+				// the lean members' ride words and copy-kernel blocks move with the look-back words: those Execs are filled again
+				if (ws.ride_capacity < plan.total_tiles) {
+					HIP_TRY(hipStreamSynchronize(ws.stream));
+					rc = batch_ensure_buffers(ws, plan);
+					if (rc != VVM_OK) return rc;
+				}
+				std::vector<uint8_t> scratch;
+				for (int i : plan.slices[0].through_members) {
+					rc = batch_fill_exec(ws, plan, b->ctxs, opts, i, scratch);
+					if (rc != VVM_OK) return rc;
+				}
+				upload = plan.slices[0].used_bytes;
+			}
 		}
 	}
 	if (changed & VVM_BATCH_CHANGED_STREAMS) {

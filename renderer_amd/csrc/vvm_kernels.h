@@ -24,6 +24,9 @@ int vvm_launch_max_id_kernel(const VvmIdDesc* ids, uint32_t num_chunks, hipStrea
 int vvm_launch_xorwow_fill(const VvmXorwowFill* params, const uint32_t* jump, uint32_t* words, hipStream_t stream);
 // The handed-through streams of an Exec whose program has run on the light eight-wide kernel and left its ride words (same stream).
 int vvm_launch_through_kernel(const VvmThroughArgs* args, hipStream_t stream);
+// The same for the lean members of a batch: `num_execs` blocks in device memory, each with the number of its first tile within
+// this launch in `pad` (increasing), `total_tiles` tiles in all, no Exec with more than `max_pairs` pairs.
+int vvm_launch_through_batch_kernel(const VvmThroughArgs* device_execs, uint32_t num_execs, uint32_t total_tiles, uint32_t max_pairs, hipStream_t stream);
 int vvm_kernel_max_dynamic_lds(void);
 uint32_t vvm_kernel_resident_registers(int instances_per_lane, int many_registers);
 uint32_t vvm_kernel_lds_fixed_bytes(int instances_per_lane, int full);

@@ -1784,37 +1784,39 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (IS_LIGHT(V, SPILL) ? 3 : V
 // per lane and half; otherwise every survivor's value goes to its rank in LDS (dead ones to the thread's sink word) and the tile's
 // survivors leave from there, 128 bits per lane, cut at the tile's count by the descriptor's bound.  Survivors keep instance order
 // (VectorVMRuntime.cpp:786-804) because the ranks are the acquireindex's own.
-__global__ void __launch_bounds__(VVM_BLOCK_THREADS) vvm_through_kernel(const VvmThroughArgs a)
+// SRC / DST: where pair i's stream addresses come from (the kernel's own arguments, or an Exec's block in device memory: scalar
+// loads either way, the index is uniform).
+template <typename SRC, typename DST>
+DEV void through_tile(const unsigned long long* status, const uint32_t* ride_words, uint32_t num_instances, uint32_t num_pairs, uint32_t tile, uint32_t p0,
+                      uint32_t (&packed)[VVM_THROUGH_PAIRS_PER_BLOCK][VVM_BLOCK_THREADS * 8u + VVM_BLOCK_THREADS], SRC src, DST dst)
 {
 	constexpr uint32_t TILE = VVM_BLOCK_THREADS * 8u, PPB = VVM_THROUGH_PAIRS_PER_BLOCK;
-	__shared__ __attribute__((aligned(16))) uint32_t packed[PPB][TILE + VVM_BLOCK_THREADS];
-	const uint32_t tile = blockIdx.x, tid = threadIdx.x;
-	const uint32_t inclusive = (uint32_t)sload64(a.status, tile);
-	const uint32_t base = tile ? (uint32_t)sload64(a.status, tile - 1u) : 0u;
+	const uint32_t tid = threadIdx.x;
+	const uint32_t inclusive = (uint32_t)sload64(status, tile);
+	const uint32_t base = tile ? (uint32_t)sload64(status, tile - 1u) : 0u;
 	const uint32_t total = inclusive - base;
-	if (total == 0) return;
+	if (total == 0 || p0 >= num_pairs) return;      // (uniform)
 	const uint32_t first = tile * TILE;
-	const uint32_t valid = min(a.num_instances - first, TILE);
-	const uint32_t p0 = blockIdx.y * PPB;
+	const uint32_t valid = min(num_instances - first, TILE);
 	u32x4 lo[PPB], hi[PPB];
 #pragma unroll
 	for (uint32_t j = 0; j < PPB; ++j) {
-		const bool used = p0 + j < a.num_pairs;
-		const rsrc_t rs = make_rsrc(a.src[used ? p0 + j : p0] + 4ull * first, used ? 4u * valid : 0u);
+		const bool used = p0 + j < num_pairs;
+		const rsrc_t rs = make_rsrc(src(used ? p0 + j : p0) + 4ull * first, used ? 4u * valid : 0u);
 		lo[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(tid * 16u), 0, AUX_STREAM_LOAD);
 		hi[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(VVM_HALF_TILE * 4u + tid * 16u), 0, AUX_STREAM_LOAD);
 	}
 	if (total == TILE) {
 #pragma unroll
 		for (uint32_t j = 0; j < PPB; ++j) {
-			const bool used = p0 + j < a.num_pairs;
-			const rsrc_t rd = make_rsrc(a.dst[used ? p0 + j : p0] + 4ull * base, used ? 4u * TILE : 0u);
+			const bool used = p0 + j < num_pairs;
+			const rsrc_t rd = make_rsrc(dst(used ? p0 + j : p0) + 4ull * base, used ? 4u * TILE : 0u);
 			__builtin_amdgcn_raw_buffer_store_b128(lo[j], rd, (int)(tid * 16u), 0, AUX_STREAM_STORE);
 			__builtin_amdgcn_raw_buffer_store_b128(hi[j], rd, (int)(VVM_HALF_TILE * 4u + tid * 16u), 0, AUX_STREAM_STORE);
 		}
 		return;
 	}
-	const uint32_t ride = a.ride[(size_t)tile * VVM_BLOCK_THREADS + tid];
+	const uint32_t ride = ride_words[(size_t)tile * VVM_BLOCK_THREADS + tid];
 #pragma unroll
 	for (uint32_t j = 0; j < PPB; ++j) {
 		const uint32_t v[8] = {lo[j].x, lo[j].y, lo[j].z, lo[j].w, hi[j].x, hi[j].y, hi[j].z, hi[j].w};
@@ -1830,19 +1832,49 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS) vvm_through_kernel(const Vv
 	__syncthreads();
 #pragma unroll
 	for (uint32_t j = 0; j < PPB; ++j) {
-		const bool used = p0 + j < a.num_pairs;
-		const rsrc_t rd = make_rsrc(a.dst[used ? p0 + j : p0] + 4ull * base, used ? 4u * total : 0u);
+		const bool used = p0 + j < num_pairs;
+		const rsrc_t rd = make_rsrc(dst(used ? p0 + j : p0) + 4ull * base, used ? 4u * total : 0u);
 		const u32x4 x = *(const u32x4*)&packed[j][tid * 4u];
 		const u32x4 y = *(const u32x4*)&packed[j][VVM_HALF_TILE + tid * 4u];
 		__builtin_amdgcn_raw_buffer_store_b128(x, rd, (int)(tid * 16u), 0, AUX_STREAM_STORE);
 		__builtin_amdgcn_raw_buffer_store_b128(y, rd, (int)(VVM_HALF_TILE * 4u + tid * 16u), 0, AUX_STREAM_STORE);
 	}
 }
+__global__ void __launch_bounds__(VVM_BLOCK_THREADS) vvm_through_kernel(const VvmThroughArgs a)
+{
+	__shared__ __attribute__((aligned(16))) uint32_t packed[VVM_THROUGH_PAIRS_PER_BLOCK][VVM_BLOCK_THREADS * 8u + VVM_BLOCK_THREADS];
+	through_tile(a.status, a.ride, a.num_instances, a.num_pairs, blockIdx.x, blockIdx.y * VVM_THROUGH_PAIRS_PER_BLOCK, packed,
+	             [&](uint32_t i) { return a.src[i]; }, [&](uint32_t i) { return a.dst[i]; });
+}
+// The same for the members of a batch: one block of VvmThroughArgs per Exec in device memory (pad = the number of its first tile
+// within this launch), workgroup x takes tile x of the launch: the last Exec whose first tile is not beyond it.
+__global__ void __launch_bounds__(VVM_BLOCK_THREADS) vvm_through_batch_kernel(const VvmThroughArgs* execs, uint32_t num_execs)
+{
+	__shared__ __attribute__((aligned(16))) uint32_t packed[VVM_THROUGH_PAIRS_PER_BLOCK][VVM_BLOCK_THREADS * 8u + VVM_BLOCK_THREADS];
+	uint32_t lo = 0, hi = num_execs;
+	while (hi - lo > 1) {
+		const uint32_t mid = (lo + hi) >> 1;
+		if (sload32(execs + mid, offsetof(VvmThroughArgs, pad) / 4) <= blockIdx.x) lo = mid; else hi = mid;
+	}
+	const VvmThroughArgs* e = execs + lo;
+	const uint32_t tile = blockIdx.x - sload32(e, offsetof(VvmThroughArgs, pad) / 4);
+	if (tile >= sload32(e, offsetof(VvmThroughArgs, num_tiles) / 4)) return;
+	through_tile((const unsigned long long*)sload64(e, offsetof(VvmThroughArgs, status) / 8), (const uint32_t*)sload64(e, offsetof(VvmThroughArgs, ride) / 8),
+	             sload32(e, offsetof(VvmThroughArgs, num_instances) / 4), sload32(e, offsetof(VvmThroughArgs, num_pairs) / 4), tile, blockIdx.y * VVM_THROUGH_PAIRS_PER_BLOCK, packed,
+	             [&](uint32_t i) { return sload64(e, offsetof(VvmThroughArgs, src) / 8 + i); }, [&](uint32_t i) { return sload64(e, offsetof(VvmThroughArgs, dst) / 8 + i); });
+}
 extern "C" int vvm_launch_through_kernel(const VvmThroughArgs* args, hipStream_t stream)
 {
 	if (args->num_pairs == 0 || args->num_tiles == 0) return 0;
 	const dim3 grid(args->num_tiles, (args->num_pairs + VVM_THROUGH_PAIRS_PER_BLOCK - 1u) / VVM_THROUGH_PAIRS_PER_BLOCK);
 	hipLaunchKernelGGL(vvm_through_kernel, grid, dim3(VVM_BLOCK_THREADS), 0, stream, *args);
+	return (int)hipGetLastError();
+}
+extern "C" int vvm_launch_through_batch_kernel(const VvmThroughArgs* device_execs, uint32_t num_execs, uint32_t total_tiles, uint32_t max_pairs, hipStream_t stream)
+{
+	if (num_execs == 0 || total_tiles == 0 || max_pairs == 0) return 0;
+	const dim3 grid(total_tiles, (max_pairs + VVM_THROUGH_PAIRS_PER_BLOCK - 1u) / VVM_THROUGH_PAIRS_PER_BLOCK);
+	hipLaunchKernelGGL(vvm_through_batch_kernel, grid, dim3(VVM_BLOCK_THREADS), 0, stream, device_execs, num_execs);
 	return (int)hipGetLastError();
 }
 

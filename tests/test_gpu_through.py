@@ -75,3 +75,114 @@ def test_what_the_script_computes_needs_the_general_eight_wide_kernel(n, death):
 def test_more_than_eight_computed_outputs_flush_in_the_middle_of_a_tile():
     """Eight fountain outputs and six computed ones: two groups of staging slots in the lean program, twelve streams handed through."""
     _compare(70001, 18, 0, 0.5, more_math=6, instance_offset=3)
+
+
+# ---- lean members of a batch: one launch of the light kernel for all programs, one launch of the copy kernel for all handed-through streams
+
+
+class _WideEmitter:
+    """An emitter with a wide record (through_cases.wide_record_script) with the interface of test_gpu_batch_handle._Emitter."""
+    CAP = 90_000
+
+    def __init__(self, be, e, n, extra_float, extra_int):
+        from renderer_amd.runtime import VectorVMState
+        from vm_harness import PAD
+        self.be, self.n, self.PAD = be, n, PAD
+        self.script = sc.wide_record_script(extra_float, extra_int)
+        self.dts = sc.out_dtypes(extra_float, extra_int)
+        self.consts = bytearray(sc.CONSTANTS)
+        self.host_in = sc.streams(self.CAP, extra_float, extra_int, death=(0.0, 0.5, 0.9)[e % 3], seed=100 + e)
+        self.ins = [self._upload(a) for a in self.host_in]
+        self.outs = [self._fresh() for _ in self.dts]
+        self.state = VectorVMState(self.script.blob, be)
+        nf = 8 + extra_float
+        self.ds = abi.DataSet(self.ins, self.outs, 0, [0, nf, nf + extra_int], [0, nf, nf + extra_int])
+        self.frame = self.state.frame([self.ds], n, [bytes(self.consts)])
+
+    def _upload(self, a):
+        buf = np.zeros(self.CAP + self.PAD, a.dtype)
+        buf[:self.CAP] = a
+        p = self.be.lib.vvm_device_alloc(buf.nbytes)
+        assert p
+        self.be._check(self.be.lib.vvm_device_upload(p, buf.ctypes.data, buf.nbytes), "upload")
+        return p
+
+    def _fresh(self):
+        p = self.be.lib.vvm_device_alloc((self.CAP + self.PAD) * 4)
+        assert p
+        self.be._check(self.be.lib.vvm_device_memset(p, 0xCD, (self.CAP + self.PAD) * 4), "memset")
+        return p
+
+    def swap_outputs(self):
+        self.old_outs = getattr(self, "old_outs", []) + self.outs
+        self.outs = [self._fresh() for _ in self.dts]
+        for k, p in enumerate(self.outs):
+            self.ds._out[k] = p
+
+    def check(self, tag, fresh=False):
+        """fresh: the output streams have not been written before this Exec, so nothing may lie behind the survivors."""
+        ref, ref_n, _ = run_oracle(self.script, [bytes(self.consts)], [a[:max(self.n, 1)] for a in self.host_in], self.dts, self.n)
+        assert self.frame.survivors(0) == ref_n, tag
+        for k in range(len(self.dts)):
+            h = np.empty(self.CAP + self.PAD, np.uint32)
+            self.be._check(self.be.lib.vvm_device_download(h.ctypes.data, self.outs[k], h.nbytes), "download")
+            assert np.array_equal(h[:ref_n], ref[k][:ref_n].view(np.uint32)), (tag, k)
+            assert not fresh or (h[ref_n:self.CAP] == 0xCDCDCDCD).all(), (tag, k, "past the survivors")
+
+    def free(self):
+        self.state.close()
+        for p in self.ins + self.outs + getattr(self, "old_outs", []):
+            self.be.lib.vvm_device_free(p)
+
+
+def test_lean_members_of_a_batch():
+    """Wide-record emitters beside fountain emitters in vvm_exec_batch and in a vvm_batch handle over ticks: from 8 Ki instances on a
+    wide-record member runs lean (its program in the light kernel's launch, its handed-through streams in the batch's one
+    copy-kernel launch), below it whole on the four-wide kernel.  Sizes cross that line between ticks, outputs are swapped."""
+    from test_gpu_batch_handle import _Emitter
+    be = abi.load_hip_backend()
+    wide_sizes = [20_000, 8_192, 8_191, 70_001, 1, 33_333, 2_049, 50_000, 9_000]
+    ems = []
+    for e, n in enumerate(wide_sizes):
+        ems.append(_WideEmitter(be, e, n, 10 + (e % 3) * 4, e % 3))
+        ems.append(_Emitter(be, e, 3000 + 4000 * e))
+    handle = None
+    try:
+        opts = [abi.ExecOptions(0, 0, 0, None, 0) for _ in ems]
+        arr, oarr = be.pack_batch([em.frame for em in ems], opts)
+        be.exec_batch_packed(arr, oarr)
+        for i, em in enumerate(ems):
+            em.check("plain batch, emitter %d" % i, *([True] if isinstance(em, _WideEmitter) else []))
+        widths = [em.state.last_exec_width() for em in ems[0::2]]
+        assert widths == [8 if n >= 8192 else 4 for n in wide_sizes]
+        handle = be.batch_create(arr, oarr)
+        for tick in range(4):
+            changed = 0
+            if tick in (1, 3):      # sizes: some cross the line in either direction, some only change their tile counts
+                for i, em in enumerate(ems):
+                    em.n = [em.n, max(1, em.n // 2 + 13 * i), em.n, min(em.CAP if hasattr(em, "CAP") else 320_000, em.n * 3 + 100)][tick]
+                    arr[i].NumInstances = em.n
+                changed |= abi.VVM_BATCH_CHANGED_INSTANCES
+            if tick == 2:
+                for em in ems:
+                    em.swap_outputs()
+                changed |= abi.VVM_BATCH_CHANGED_STREAMS
+            be.batch_exec(handle, changed)
+            for i, em in enumerate(ems):
+                em.check("handle tick %d, emitter %d" % (tick, i), *([tick == 2] if isinstance(em, _WideEmitter) else []))
+        # a tick in which only tile counts change (nobody changes kernel): every wide member already above the line grows a little
+        for i, em in enumerate(ems):
+            if em.n >= 8192:
+                em.n = min(em.n + 2048 + 7 * i, getattr(em, "CAP", 320_000))
+                arr[i].NumInstances = em.n
+        be.batch_exec(handle, abi.VVM_BATCH_CHANGED_INSTANCES)
+        for i, em in enumerate(ems):
+            em.check("tile counts only, emitter %d" % i)
+        be.batch_exec(handle, 0)
+        for i, em in enumerate(ems):
+            em.check("unchanged, emitter %d" % i)
+    finally:
+        if handle:
+            be.batch_destroy(handle)
+        for em in ems:
+            em.free()

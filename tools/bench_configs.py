@@ -293,6 +293,55 @@ def main():
         n = 1024 * 1024
         w = scripts.fountain()
         run_single("fountain 1Mi", w, scripts.fountain_streams_torch(0, n, dev, pad=PAD), 8, n)
+    if "batch_wide" in which:
+        # 4096 emitters x 16 Ki particles whose records carry sixteen attributes that the script hands through (24 streams each way)
+        import struct
+        from renderer_amd.assembler import FLOAT, Script
+        emitters, per, extra = 4096, 16384, 16
+        total = emitters * per
+        ins = scripts.fountain_streams_torch(0, total, dev, kill_half=True, pad=PAD) + [torch.rand(total + PAD, dtype=torch.float32, device=dev) for _ in range(extra)]
+        outs = [torch.zeros(total + PAD, dtype=torch.float32, device=dev) for _ in range(8 + extra)]
+        torch.cuda.synchronize()
+        s = Script()
+        dt, drag = s.const(0), s.const(4)
+        pos = [s.input(0, FLOAT, k) for k in range(3)]
+        vel = [s.input(0, FLOAT, 3 + k) for k in range(3)]
+        age, life = s.input(0, FLOAT, 6), s.input(0, FLOAT, 7)
+        rest = [s.input(0, FLOAT, 8 + k) for k in range(extra)]
+        age1 = s.temp(); s.op("add", age, dt, age1)
+        alive = s.temp(); s.op("cmplt", age1, life, alive)
+        s.acquireindex(alive, 0)
+        v1, p1 = s.temps(3), s.temps(3)
+        for c in range(3):
+            s.op("mad_mul", s.const(1 + c), dt, vel[c], drag, v1[c])
+            s.op("mad", v1[c], dt, pos[c], p1[c])
+        s.output_data(FLOAT, 0, [(p1[c], s.output(0, FLOAT, c)) for c in range(3)] + [(v1[c], s.output(0, FLOAT, 3 + c)) for c in range(3)] +
+                      [(age1, s.output(0, FLOAT, 6)), (life, s.output(0, FLOAT, 7))] + [(rest[k], s.output(0, FLOAT, 8 + k)) for k in range(extra)])
+        blob = s.build(alias_outputs=True).blob
+        consts = struct.pack("<6f", 1.0 / 60.0, 0.0, 0.0, -980.0, 0.98, 1.0) + bytes(8)
+        states, frames, opts = [], [], []
+        for e in range(emitters):
+            st = VectorVMState(blob, be)
+            states.append(st)
+            off = e * per * 4
+            frames.append(st.frame([abi.DataSet([t.data_ptr() + off for t in ins], [t.data_ptr() + off for t in outs], 0)], per, [consts]))
+            opts.append(abi.ExecOptions(0, 0, 0, None, args.batch_flags))
+        arr, oarr = be.pack_batch(frames, opts)
+        handle = be.batch_create(arr, oarr)
+        for _ in range(5):
+            be.batch_exec(handle, 0)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            be.batch_exec(handle, 0)
+        el = time.perf_counter() - t0
+        surv = sum(f.survivors(0) for f in frames)
+        alg = (32.0 + 4.0 * extra) * (total + surv)
+        print(json.dumps({"config": "batch 4096 emitters x 16Ki, %d streams each way, through vvm_batch_exec, nothing changes" % (8 + extra), "particles": total, "survivors": surv,
+                          "steps": args.steps, "ms_per_step": el / args.steps * 1e3, "updates_per_s": total * args.steps / el,
+                          "algorithmic_GBps_wallclock": alg * args.steps / el / 1e9, "width": states[0].last_exec_width()}), flush=True)
+        be.batch_destroy(handle)
+        for st in states:
+            st.close()
     if "batch" in which:
         emitters, per = 4096, 16384
         total = emitters * per
