@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--force-eight", action="store_true", help="single Execs: eight instances per lane whatever the size (and with it the lean form of a wide-record script)")
     ap.add_argument("--extras", default="16,8", help="wide_record: numbers of handed-through attributes to run")
     ap.add_argument("--wide-particles", type=int, default=32 * 1024 * 1024, help="wide_record: instances")
+    ap.add_argument("--wide-kill-half", action="store_true", help="wide_record: half of the particles die")
     ap.add_argument("--more-math", type=int, default=0, help="wide_record: that many of the extra attributes are scaled and offset instead of handed through")
     ap.add_argument("--separate-passes", action="store_true", help="two_datasets: one launch per dataset instead of one launch for both")
     ap.add_argument("--batch-variants", type=int, default=64, help="bytecode variants of the batch (the first 16 all fit the light kernel)")
@@ -203,7 +204,7 @@ def main():
             w.script = s.build(alias_outputs=True)
             w.constants = struct.pack("<6f", 1.0 / 60.0, 0.0, 0.0, -980.0, 0.98, 1.0) + bytes(8)
             n = args.wide_particles
-            base = scripts.fountain_streams_torch(0, n, dev, pad=PAD)
+            base = scripts.fountain_streams_torch(0, n, dev, kill_half=args.wide_kill_half, pad=PAD)
             more = [torch.rand(n + PAD, dtype=torch.float32, device=dev) for _ in range(extra)]
             run_single("fountain with %d more attributes, %d of them computed with, the others handed through (%d streams in / %d out), %d instances" % (extra, min(args.more_math, extra), 8 + extra, 8 + extra, n), w, base + more, 8 + extra, n)
             del more
