@@ -339,7 +339,8 @@ bool plan_through_programs(const vvm::ThawedScript& script, const vvm::LinkedPro
 {
 	through.clear();
 	if (getenv("VVM_NO_THROUGH")) return false;
-	if (fits_light || w.num_passes != 1 || w.num_chains != 1 || w.uses_ids || w.full_kernel || w.acquire_order.size() != 1) return false;
+	// (one acquired dataset, or two in one pass: then the first one's outputs, see LinkedProgram::through_input)
+	if (fits_light || w.num_passes != 1 || w.uses_ids || w.full_kernel || w.acquire_order.empty() || w.acquire_order.size() > 2) return false;
 	const size_t O = w.through_input.size();
 	for (size_t o = 0; o < O; ++o) {
 		if (w.through_input[o] == -2) { through.clear(); return false; }
@@ -355,7 +356,7 @@ bool plan_through_programs(const vvm::ThawedScript& script, const vvm::LinkedPro
 	// whole script is beyond it (more than sixteen registers) and the rest is not
 	lean = vvm::LinkedProgram();
 	bool ok = (w.many_registers || w.instances_per_lane == 1) && vvm::link_program(script, false, lean, why, 0, false, &select) == VVM_OK;
-	ok = ok && lean.instances_per_lane == 4 && !lean.many_registers && !lean.full_kernel && lean.num_passes == 1 && lean.num_chains == 1;
+	ok = ok && lean.instances_per_lane == 4 && !lean.many_registers && !lean.full_kernel && lean.num_passes == 1;      // (the general eight-wide kernel has the second chain)
 	if (!ok) { lean = vvm::LinkedProgram(); through.clear(); }
 	return ok;
 }

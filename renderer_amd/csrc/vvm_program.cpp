@@ -449,7 +449,8 @@ static int link_program_as(const ThawedScript& s, bool force_narrow, LinkedProgr
 				const uint32_t serial = p.second - out0;
 				if (writers[serial]++) { lp.through_input[serial] = -2; continue; }
 				const bool word_copy = d.op == VVM_OP_outputdata_float || d.op == VVM_OP_outputdata_int32;
-				const bool behind_acquire = d.dataset < acquired.size() && acquired[d.dataset];
+				// (of a script with two acquired datasets only the first one's: the copy kernel works from the first chain's results)
+				const bool behind_acquire = d.dataset < acquired.size() && acquired[d.dataset] && d.dataset == lp.acquire_order.front();
 				if (word_copy && behind_acquire && p.first >= T + C && p.first < T + C + I) {
 					const uint32_t i = p.first - (T + C);
 					if (!lp.inputs[i].noadvance && lp.inputs[i].type != 2) lp.through_input[serial] = (int32_t)i;

@@ -186,3 +186,51 @@ def test_lean_members_of_a_batch():
             be.batch_destroy(handle)
         for em in ems:
             em.free()
+
+
+def _two_dataset_wide_script(extra):
+    """The fountain update on a wide record, with a second dataset that receives position and age of the particles that die."""
+    from renderer_amd.assembler import FLOAT, Script
+    s = Script()
+    dt, drag = s.const(0), s.const(4)
+    pos = [s.input(0, FLOAT, k) for k in range(3)]
+    vel = [s.input(0, FLOAT, 3 + k) for k in range(3)]
+    age, life = s.input(0, FLOAT, 6), s.input(0, FLOAT, 7)
+    rest = [s.input(0, FLOAT, 8 + k) for k in range(extra)]
+    age1 = s.temp(); s.op("add", age, dt, age1)
+    alive, dead = s.temps(2)
+    s.op("cmplt", age1, life, alive)
+    s.op("cmpge", age1, life, dead)
+    s.acquireindex(alive, 0)
+    s.acquireindex(dead, 1)
+    v1, p1 = s.temps(3), s.temps(3)
+    for c in range(3):
+        s.op("mad_mul", s.const(1 + c), dt, vel[c], drag, v1[c])
+        s.op("mad", v1[c], dt, pos[c], p1[c])
+    s.output_data(FLOAT, 0, [(p1[c], s.output(0, FLOAT, c)) for c in range(3)] + [(v1[c], s.output(0, FLOAT, 3 + c)) for c in range(3)] +
+                  [(age1, s.output(0, FLOAT, 6)), (life, s.output(0, FLOAT, 7))] + [(rest[k], s.output(0, FLOAT, 8 + k)) for k in range(extra)])
+    s.output_data(FLOAT, 1, [(p1[c], s.output(1, FLOAT, c)) for c in range(3)] + [(age1, s.output(1, FLOAT, 3)), (rest[0], s.output(1, FLOAT, 4))])
+    return s.build()
+
+
+@pytest.mark.parametrize("n,death", [(3, 0.5), (2049, 0.0), (70001, 0.5), (70001, 1.0), (300001, 0.3)])
+def test_a_wide_record_with_a_second_dataset(n, death):
+    """Two acquired datasets in one pass of the general eight-wide kernel; the first dataset's handed-through streams go to the copy
+    kernel (it works from the first chain's ranks and look-back words), the second dataset's outputs, one of them an input handed
+    through, stay in the program."""
+    extra = 16
+    script = _two_dataset_wide_script(extra)
+    ins = sc.streams(n, extra, 0, death)
+    dts = [np.float32] * (8 + extra)
+    more = [[np.float32] * 5]
+    want_more, got_more = [], []
+    want, want_n, _ = run_oracle(script, [sc.CONSTANTS], ins, dts, n, more_datasets=more, more_results=want_more)
+    width = []
+    got, got_n, info = run_hip(script, [sc.CONSTANTS], ins, dts, n, flags=EIGHT, last_width=width, more_datasets=more, more_results=got_more)
+    assert info.Flags & 0x80000 and (info.Flags >> 24) == extra + 1 and info.Flags & 0x40000 and width == [8]
+    assert got_n == want_n and got_more[0][1] == want_more[0][1] == n - want_n
+    for g, w in zip(got, want):
+        np.testing.assert_array_equal(g[:got_n].view(np.uint32), w[:want_n].view(np.uint32))
+        assert (g[got_n:].view(np.uint8) == 0xCD).all()
+    for g, w in zip(got_more[0][0], want_more[0][0]):
+        np.testing.assert_array_equal(g[:n - want_n].view(np.uint32), w[:n - want_n].view(np.uint32))
