@@ -234,3 +234,36 @@ def test_a_wide_record_with_a_second_dataset(n, death):
         assert (g[got_n:].view(np.uint8) == 0xCD).all()
     for g, w in zip(got_more[0][0], want_more[0][0]):
         np.testing.assert_array_equal(g[:n - want_n].view(np.uint32), w[:n - want_n].view(np.uint32))
+
+
+def test_a_compiler_format_wide_record_script_through_the_optimizer():
+    """Compiler-format bytecode (all attributes read at the top, all written at the bottom) -> vvm_optimize_script -> the blob runs
+    lean on the GPU and whole on the oracle: same bits."""
+    from types import SimpleNamespace
+    from renderer_amd.assembler import FLOAT
+    from renderer_amd.original import K, OriginalScript
+    o = OriginalScript()
+    attrs = [o.input(0, FLOAT, i, o.temp()) for i in range(24)]
+    px, py, pz, vx, vy, vz, age, life = attrs[:8]
+    dt, g, drag = K(0), [K(1), K(2), K(3)], K(4)
+    age2 = o.temp(); o.op("add", age, dt, age2)
+    alive = o.temp(); o.op("cmplt", age2, life, alive)
+    vel, pos = [], []
+    for v, p, gi in zip((vx, vy, vz), (px, py, pz), g):
+        t = o.temp(); o.op("mad", gi, dt, v, t)
+        v2 = o.temp(); o.op("mul", t, drag, v2)
+        p2 = o.temp(); o.op("mad", v2, dt, p, p2)
+        vel.append(v2); pos.append(p2)
+    idx = o.temp(); o.acquireindex(alive, idx, 0)
+    for i, r in enumerate(pos + vel + [age2] + attrs[7:]):
+        o.output(FLOAT, 0, idx, r, i)
+    script = SimpleNamespace(blob=abi.load_hip_backend().optimize_script(o.done(), o.ext))
+    n = 150_001
+    ins = sc.streams(n, 16, 0, 0.4)
+    dts = [np.float32] * 24
+    want, want_n, _ = run_oracle(script, [sc.CONSTANTS], ins, dts, n)
+    width = []
+    got, got_n, info = run_hip(script, [sc.CONSTANTS], ins, dts, n, last_width=width)
+    assert info.Flags & 0x80000 and width == [8] and got_n == want_n
+    for g_, w_ in zip(got, want):
+        np.testing.assert_array_equal(g_[:got_n].view(np.uint32), w_[:want_n].view(np.uint32))

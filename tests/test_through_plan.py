@@ -74,3 +74,29 @@ def test_streams_that_are_not_plain_32_bit_copies_stay_in_the_program():
     s.output_data(HALF, 0, [(h, s.output(0, HALF, 0))], from_half=True)
     f = flags(s.build())
     assert f & LEAN and (f >> 24) == 17
+
+
+def test_a_compiler_format_script_with_a_wide_record_ends_up_lean():
+    """The realistic route: a script as the Niagara compiler writes it (every attribute read into a temp at the top, every attribute
+    written at the bottom, also the ones nothing happens to) goes through vvm_optimize_script, whose input folding turns the
+    untouched attributes into outputs that read their input directly; the blob that comes out gets the lean form."""
+    from renderer_amd.original import K, OriginalScript
+    o = OriginalScript()
+    attrs = [o.input(0, FLOAT, i, o.temp()) for i in range(24)]
+    px, py, pz, vx, vy, vz, age, life = attrs[:8]
+    dt, g, drag = K(0), [K(1), K(2), K(3)], K(4)
+    age2 = o.temp(); o.op("add", age, dt, age2)
+    alive = o.temp(); o.op("cmplt", age2, life, alive)
+    vel, pos = [], []
+    for v, p, gi in zip((vx, vy, vz), (px, py, pz), g):
+        t = o.temp(); o.op("mad", gi, dt, v, t)
+        v2 = o.temp(); o.op("mul", t, drag, v2)
+        p2 = o.temp(); o.op("mad", v2, dt, p, p2)
+        vel.append(v2); pos.append(p2)
+    idx = o.temp(); o.acquireindex(alive, idx, 0)
+    for i, r in enumerate(pos + vel + [age2] + attrs[7:]):
+        o.output(FLOAT, 0, idx, r, i)
+    blob = be().optimize_script(o.done(), o.ext)
+    info = be().inspect_blob(blob)
+    assert info.Flags & LEAN and (info.Flags >> 24) == 17, hex(info.Flags)
+    assert info.NumInputBuffers == 24
