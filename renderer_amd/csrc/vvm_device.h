@@ -173,7 +173,11 @@ struct VvmXorwowFill {
 // address, 0 = none), and vvm_through_kernel moves the streams behind it: from the look-back words, which all hold inclusive
 // counts once the Exec's kernel has ended, it takes where a tile's survivors start, from the ride words where each goes.
 #define VVM_THROUGH_MAX_PAIRS 56u
-#define VVM_THROUGH_PAIRS_PER_BLOCK 4u
+// (pairs one workgroup moves: measured on 24 / 40 streams each way at 32 Mi instances, all surviving / half dying, with 1, 2, 3, 4, 6
+// pairs: 1.12 / 1.84 / 0.85 / 1.38 ms with one, 1.17 / 1.96 / 0.95 / 1.56 ms with four: the more workgroups in flight the better)
+#ifndef VVM_THROUGH_PAIRS_PER_BLOCK
+#define VVM_THROUGH_PAIRS_PER_BLOCK 1u
+#endif
 struct VvmThroughArgs {
 	const unsigned long long* status;   // the Exec's look-back words
 	const uint32_t* ride;

@@ -1780,7 +1780,7 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (IS_LIGHT(V, SPILL) ? 3 : V
 }
 
 // The streams a script hands through unchanged, moved behind the Exec's own kernel (see VvmThroughArgs): workgroup (tile, b) moves
-// pairs [4 b, 4 b + 4) of one tile of eight instances per lane.  A tile whose instances all survive is copied as it lies, 128 bits
+// pairs [P b, P b + P) of one tile of eight instances per lane, P = VVM_THROUGH_PAIRS_PER_BLOCK.  A tile whose instances all survive is copied as it lies, 128 bits
 // per lane and half; otherwise every survivor's value goes to its rank in LDS (dead ones to the thread's sink word) and the tile's
 // survivors leave from there, 128 bits per lane, cut at the tile's count by the descriptor's bound.  Survivors keep instance order
 // (VectorVMRuntime.cpp:786-804) because the ranks are the acquireindex's own.
