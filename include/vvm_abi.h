@@ -241,7 +241,7 @@ enum {
 	 * handed-through streams, which a copy kernel moves behind that program's launch (it takes every survivor's place from what
 	 * the program's acquireindex left).  A single Exec of at least VVM_THROUGH_MIN_INSTANCES instances (VVM_THROUGH_MIN_INSTANCES_EIGHT_WIDE
 	 * where the whole script still fits the general eight-wide kernel) runs that way, and so does a member of a batch of at least
-	 * VVM_BATCH_LIGHT_MIN_INSTANCES instances whose whole script needs more than sixteen registers (one copy-kernel launch serves
+	 * VVM_BATCH_THROUGH_MIN_INSTANCES instances whose whole script needs more than sixteen registers (one copy-kernel launch serves
 	 * all such members of a slice) (bit
 	 * 0x80000 of vvm_state_info's Flags: the state has the form; the top byte holds the number of handed-through streams).
 	 * This flag runs the script whole instead (tests / comparison; so does VVM_NO_THROUGH=1 in the environment at
@@ -255,6 +255,8 @@ enum {
 /* ... and from this size on where the whole script fits the general eight-wide kernel (nine to sixteen per-lane registers): 12 to
  * 16 streams each way measured 1 to 3 % faster lean at 2 Mi instances, 8 to 12 % at 4 Mi, 7 to 17 % at 32 Mi, slower at 1 Mi */
 #define VVM_THROUGH_MIN_INSTANCES_EIGHT_WIDE (4 * 1024 * 1024)
+/* ... and for a member of a batch (whose launches are shared) whose whole script needs more than sixteen registers */
+#define VVM_BATCH_THROUGH_MIN_INSTANCES 1024
 /* ... and inside vvm_exec_batch / vvm_batch_exec, where the launch is shared, a member whose script fits the light eight-wide
  * kernel (eight per-lane registers; bit 0x20000 of vvm_state_info's Flags) runs eight-wide from this size on */
 #define VVM_BATCH_LIGHT_MIN_INSTANCES (8 * 1024)

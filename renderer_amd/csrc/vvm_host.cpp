@@ -456,10 +456,10 @@ int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, P
 		// (two launches instead of one: against the four-wide kernels with 32 registers that pays from 64 Ki instances on, against the
 		// general eight-wide kernel, which a script of nine to sixteen registers runs on whole, from about 2 Mi)
 		const bool whole_is_slow = st->wide.many_registers || st->wide.instances_per_lane == 1;
-		// (a member of a batch shares its launches with the others: there the form pays from the size on from which the light kernel
-		// does, for scripts that would otherwise run on the kernels with 32 registers and whose lean program fits the light kernel;
-		// 4096 emitters of 16 Ki instances, 24 streams each way: 3.11 ms whole)
-		const bool big = (pe.in_batch ? (whole_is_slow && st->lean.light && ctx->NumInstances >= VVM_BATCH_LIGHT_MIN_INSTANCES)
+		// (a member of a batch shares its launches with the others: there the form pays from 1 Ki instances on, for scripts that would
+		// otherwise run on the kernels with 32 registers and whose lean program fits the light kernel; 4096 emitters of 1 / 4 / 16 Ki
+		// instances, 24 streams each way: 0.25 / 0.52 / 1.99 ms against 0.28 / 0.83 / 3.11 ms whole)
+		const bool big = (pe.in_batch ? (whole_is_slow && st->lean.light && ctx->NumInstances >= VVM_BATCH_THROUGH_MIN_INSTANCES)
 		                              : ctx->NumInstances >= (whole_is_slow ? VVM_THROUGH_MIN_INSTANCES : VVM_THROUGH_MIN_INSTANCES_EIGHT_WIDE)) ||
 		                 ((flags & VVM_EXEC_FORCE_EIGHT_WIDE) && (!pe.in_batch || st->lean.light));
 		if (st->lean_ready && pass == 0 && !narrow && ctx->NumInstances > 0 && !pe.whole_only && !pe.reference_random && big &&

@@ -136,12 +136,12 @@ class _WideEmitter:
 
 
 def test_lean_members_of_a_batch():
-    """Wide-record emitters beside fountain emitters in vvm_exec_batch and in a vvm_batch handle over ticks: from 8 Ki instances on a
+    """Wide-record emitters beside fountain emitters in vvm_exec_batch and in a vvm_batch handle over ticks: from 1 Ki instances on a
     wide-record member runs lean (its program in the light kernel's launch, its handed-through streams in the batch's one
     copy-kernel launch), below it whole on the four-wide kernel.  Sizes cross that line between ticks, outputs are swapped."""
     from test_gpu_batch_handle import _Emitter
     be = abi.load_hip_backend()
-    wide_sizes = [20_000, 8_192, 8_191, 70_001, 1, 33_333, 2_049, 50_000, 9_000]
+    wide_sizes = [20_000, 1_024, 1_023, 70_001, 1, 33_333, 2_049, 50_000, 900]
     ems = []
     for e, n in enumerate(wide_sizes):
         ems.append(_WideEmitter(be, e, n, 10 + (e % 3) * 4, e % 3))
@@ -154,7 +154,7 @@ def test_lean_members_of_a_batch():
         for i, em in enumerate(ems):
             em.check("plain batch, emitter %d" % i, *([True] if isinstance(em, _WideEmitter) else []))
         widths = [em.state.last_exec_width() for em in ems[0::2]]
-        assert widths == [8 if n >= 8192 else 4 for n in wide_sizes]
+        assert widths == [8 if n >= 1024 else 4 for n in wide_sizes]
         handle = be.batch_create(arr, oarr)
         for tick in range(4):
             changed = 0
@@ -172,7 +172,7 @@ def test_lean_members_of_a_batch():
                 em.check("handle tick %d, emitter %d" % (tick, i), *([tick == 2] if isinstance(em, _WideEmitter) else []))
         # a tick in which only tile counts change (nobody changes kernel): every wide member already above the line grows a little
         for i, em in enumerate(ems):
-            if em.n >= 8192:
+            if em.n >= 1024:
                 em.n = min(em.n + 2048 + 7 * i, getattr(em, "CAP", 320_000))
                 arr[i].NumInstances = em.n
         be.batch_exec(handle, abi.VVM_BATCH_CHANGED_INSTANCES)

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--force-eight", action="store_true", help="single Execs: eight instances per lane whatever the size (and with it the lean form of a wide-record script)")
     ap.add_argument("--extras", default="16,8", help="wide_record: numbers of handed-through attributes to run")
     ap.add_argument("--wide-particles", type=int, default=32 * 1024 * 1024, help="wide_record: instances")
+    ap.add_argument("--batch-per", type=int, default=16384, help="batch_wide: particles per emitter")
     ap.add_argument("--wide-kill-half", action="store_true", help="wide_record: half of the particles die")
     ap.add_argument("--more-math", type=int, default=0, help="wide_record: that many of the extra attributes are scaled and offset instead of handed through")
     ap.add_argument("--separate-passes", action="store_true", help="two_datasets: one launch per dataset instead of one launch for both")
@@ -298,7 +299,7 @@ def main():
         # 4096 emitters x 16 Ki particles whose records carry sixteen attributes that the script hands through (24 streams each way)
         import struct
         from renderer_amd.assembler import FLOAT, Script
-        emitters, per, extra = 4096, 16384, 16
+        emitters, per, extra = 4096, args.batch_per, 16
         total = emitters * per
         ins = scripts.fountain_streams_torch(0, total, dev, kill_half=True, pad=PAD) + [torch.rand(total + PAD, dtype=torch.float32, device=dev) for _ in range(extra)]
         outs = [torch.zeros(total + PAD, dtype=torch.float32, device=dev) for _ in range(8 + extra)]
@@ -337,7 +338,7 @@ def main():
         el = time.perf_counter() - t0
         surv = sum(f.survivors(0) for f in frames)
         alg = (32.0 + 4.0 * extra) * (total + surv)
-        print(json.dumps({"config": "batch 4096 emitters x 16Ki, %d streams each way, through vvm_batch_exec, nothing changes" % (8 + extra), "particles": total, "survivors": surv,
+        print(json.dumps({"config": "batch 4096 emitters x %d, %d streams each way, through vvm_batch_exec, nothing changes" % (per, 8 + extra), "particles": total, "survivors": surv,
                           "steps": args.steps, "ms_per_step": el / args.steps * 1e3, "updates_per_s": total * args.steps / el,
                           "algorithmic_GBps_wallclock": alg * args.steps / el / 1e9, "width": states[0].last_exec_width()}), flush=True)
         be.batch_destroy(handle)
