@@ -249,9 +249,10 @@ enum {
 	VVM_EXEC_NO_THROUGH_KERNEL = 1u << 6
 };
 #define VVM_EIGHT_WIDE_MIN_INSTANCES (256 * 1024)
-/* the lean form of a wide-record script (VVM_EXEC_NO_THROUGH_KERNEL) runs from this size on: it is two launches, which measured
- * faster than the whole script from 64 Ki instances on (24 streams each way: 23 against 29 us per Exec) */
-#define VVM_THROUGH_MIN_INSTANCES (64 * 1024)
+/* the lean form of a wide-record script (VVM_EXEC_NO_THROUGH_KERNEL) runs from this size on: it is two launches, which still measured
+ * faster than the whole script on the kernels with 32 registers at every size tried (24 streams each way, 2 Ki / 32 Ki / 64 Ki
+ * instances: 21 / 22 / 23 us per Exec against 27 / 29 / 29 us) */
+#define VVM_THROUGH_MIN_INSTANCES 1024
 /* ... and from this size on where the whole script fits the general eight-wide kernel (nine to sixteen per-lane registers): 12 to
  * 16 streams each way measured 1 to 3 % faster lean at 2 Mi instances, 8 to 12 % at 4 Mi, 7 to 17 % at 32 Mi, slower at 1 Mi */
 #define VVM_THROUGH_MIN_INSTANCES_EIGHT_WIDE (4 * 1024 * 1024)

@@ -453,7 +453,7 @@ int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, P
 	{
 		// the lean form: for a single Exec large enough that a second launch pays (VVM_THROUGH_MIN_INSTANCES)
 		const uint32_t flags = opt ? opt->Flags : 0;
-		// (two launches instead of one: against the four-wide kernels with 32 registers that pays from 64 Ki instances on, against the
+		// (two launches instead of one: against the four-wide kernels with 32 registers that pays at every size measured, against the
 		// general eight-wide kernel, which a script of nine to sixteen registers runs on whole, from about 2 Mi)
 		const bool whole_is_slow = st->wide.many_registers || st->wide.instances_per_lane == 1;
 		// (a member of a batch shares its launches with the others: there the form pays from 1 Ki instances on, for scripts that would

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 EIGHT = abi.VVM_EXEC_FORCE_EIGHT_WIDE
 
 
-def _compare(n, extra_float, extra_int, death, flags=EIGHT, touch_one=False, instance_offset=0, expect_lean=True, lean_from=64 * 1024, more_math=0):
+def _compare(n, extra_float, extra_int, death, flags=EIGHT, touch_one=False, instance_offset=0, expect_lean=True, lean_from=1024, more_math=0):
     script = sc.wide_record_script(extra_float, extra_int, touch_one, more_math)
     ins = sc.streams(n, extra_float, extra_int, death)
     dts = sc.out_dtypes(extra_float, extra_int)
@@ -39,7 +39,7 @@ def test_wide_record_against_the_oracle(n, death):
 
 def test_the_same_script_whole():
     _compare(70001, 14, 2, 0.5, flags=EIGHT | abi.VVM_EXEC_NO_THROUGH_KERNEL)
-    _compare(30001, 14, 2, 0.5, flags=0)      # below the size from which the lean form runs: whole, four-wide
+    _compare(1001, 14, 2, 0.5, flags=0)      # below the size from which the lean form runs: whole, four-wide
 
 
 def test_a_handed_through_stream_that_the_arithmetic_reads_too():
@@ -47,10 +47,11 @@ def test_a_handed_through_stream_that_the_arithmetic_reads_too():
 
 
 def test_large_and_by_its_own_choice():
-    """From 64 Ki instances on the library takes the lean form by itself; below, the whole script."""
+    """From 1 Ki instances on the library takes the lean form by itself; below, the whole script."""
     _compare(3 * 1024 * 1024 + 5, 10, 0, 0.5, flags=0)
     _compare(70001, 10, 2, 0.25, flags=0)
-    _compare(60000, 10, 0, 0.5, flags=0)
+    _compare(1024, 10, 0, 0.5, flags=0)
+    _compare(1023, 10, 0, 0.5, flags=0)
 
 
 def test_scripts_that_stay_whole():
