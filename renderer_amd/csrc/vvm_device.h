@@ -167,7 +167,7 @@ struct VvmXorwowFill {
 };
 
 // Streams that a script hands through unchanged can stay out of its program (see vvm_host.cpp, plan_through): the program that
-// runs on the light eight-wide kernel then leaves, per tile and lane, the word the kernel keeps of the lane's acquireindex result
+// runs on an eight-wide kernel then leaves, per tile and lane, the word the light kernel keeps of the lane's acquireindex result
 // (keep bits [0:8) of the lane's eight instances, rank within the tile of its first survivor of the first half [8:20) and of the
 // second half [20:32)) at ride[tile * VVM_BLOCK_THREADS + lane] (the entry three before the Exec's output list holds the
 // address, 0 = none), and vvm_through_kernel moves the streams behind it: from the look-back words, which all hold inclusive
@@ -183,6 +183,9 @@ struct VvmThroughArgs {
 	const uint32_t* ride;
 	uint32_t num_instances, num_tiles, num_pairs;
 	uint32_t pad;                       // vvm_through_batch_kernel: the number of the Exec's first tile within the launch
+	uint32_t instances_per_lane;        // of the kernel that left the ride words: 8 (as above), or 4: tiles of 1024 instances, keep bits [0:4),
+	                                    // rank of the lane's first survivor [8:20) (vvm_through_kernel only)
+	uint32_t reserved[3];
 	uint64_t src[VVM_THROUGH_MAX_PAIRS];   // byte address of element [InstanceOffset] of the input stream
 	uint64_t dst[VVM_THROUGH_MAX_PAIRS];   // ... of the output stream
 };

@@ -340,7 +340,7 @@ bool plan_through_programs(const vvm::ThawedScript& script, const vvm::LinkedPro
 	through.clear();
 	if (getenv("VVM_NO_THROUGH")) return false;
 	// (one acquired dataset, or two in one pass: then the first one's outputs, see LinkedProgram::through_input)
-	if (fits_light || w.num_passes != 1 || w.uses_ids || w.full_kernel || w.acquire_order.empty() || w.acquire_order.size() > 2) return false;
+	if (fits_light || w.num_passes != 1 || w.uses_ids || w.acquire_order.empty() || w.acquire_order.size() > 2) return false;
 	const size_t O = w.through_input.size();
 	for (size_t o = 0; o < O; ++o) {
 		if (w.through_input[o] == -2) { through.clear(); return false; }
@@ -356,7 +356,9 @@ bool plan_through_programs(const vvm::ThawedScript& script, const vvm::LinkedPro
 	// whole script is beyond it (more than sixteen registers) and the rest is not
 	lean = vvm::LinkedProgram();
 	bool ok = (w.many_registers || w.instances_per_lane == 1) && vvm::link_program(script, false, lean, why, 0, false, &select) == VVM_OK;
-	ok = ok && lean.instances_per_lane == 4 && !lean.many_registers && !lean.full_kernel && lean.num_passes == 1;      // (the general eight-wide kernel has the second chain)
+	// (the general eight-wide kernel has the second chain; a lean program with transcendental or noise functions runs four instances
+	// per lane on the kernel that has those, with sixteen registers, and has one chain)
+	ok = ok && lean.instances_per_lane == 4 && !lean.many_registers && !lean.uses_ids && lean.num_passes == 1 && (!lean.full_kernel || lean.num_chains == 1);
 	if (!ok) { lean = vvm::LinkedProgram(); through.clear(); }
 	return ok;
 }
@@ -463,11 +465,11 @@ int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, P
 		                              : ctx->NumInstances >= (whole_is_slow ? VVM_THROUGH_MIN_INSTANCES : VVM_THROUGH_MIN_INSTANCES_EIGHT_WIDE)) ||
 		                 ((flags & VVM_EXEC_FORCE_EIGHT_WIDE) && (!pe.in_batch || st->lean.light));
 		if (st->lean_ready && pass == 0 && !narrow && ctx->NumInstances > 0 && !pe.whole_only && !pe.reference_random && big &&
-		    !(flags & (VVM_EXEC_NO_EIGHT_WIDE | VVM_EXEC_NO_THROUGH_KERNEL)) && !(st->lean.light && (flags & VVM_EXEC_NO_LIGHT_KERNEL))) {
+		    !(flags & VVM_EXEC_NO_THROUGH_KERNEL) && !(!st->lean.full_kernel && (flags & VVM_EXEC_NO_EIGHT_WIDE)) && !(st->lean.light && (flags & VVM_EXEC_NO_LIGHT_KERNEL))) {
 			pe.lean = true;
 			pe.lp = &st->lean;
 			pe.d_code = st->d_code_lean;
-			pe.instances_per_lane = 8;
+			pe.instances_per_lane = st->lean.full_kernel ? 4 : 8;
 			pe.light = st->lean.light;
 		}
 	}
@@ -1108,6 +1110,7 @@ static int exec_enqueue(vvm_exec_context* ctx, const vvm_exec_options* opt, bool
 			pe.ride_addr = (uint64_t)(uintptr_t)st->d_ride;
 			through.status = d_status; through.ride = st->d_ride;
 			through.num_instances = (uint32_t)ctx->NumInstances; through.num_tiles = pe.tiles; through.pad = 0;
+			through.instances_per_lane = pe.instances_per_lane;
 			rc = fill_through(st, ctx, through);
 			if (rc != VVM_OK) return rc;
 		}
@@ -1138,7 +1141,7 @@ static int exec_enqueue(vvm_exec_context* ctx, const vvm_exec_options* opt, bool
 		}
 		if (timed && pass == 0) HIP_TRY(hipEventRecord(st->ev_start[st->ev_used], stream));
 		const int lrc = vvm_launch_exec_kernel((int)pe.instances_per_lane, inline_block ? nullptr : (const VvmExecDesc*)st->ring.dev[slot], 1, pe.tiles, d_launch,
-		                                       pe.launch_many() ? 1 : 0, pe.lp->lds_spill_slots, pe.full() ? 1 : 0,
+		                                       pe.launch_many() ? 1 : 0, pe.lp->lds_spill_slots, pe.full() ? ((pe.lean && pe.instances_per_lane == 4) ? 2 : 1) : 0,
 		                                       grid_for(pe.tiles, pe.instances_per_lane, pe.full(), pe.launch_many()), stream,
 		                                       inline_block ? local_block : nullptr, inline_block ? (uint32_t)pe.bytes : 0u, 0u, 0);
 		if (lrc != 0) return hip_fail((hipError_t)lrc, "kernel launch");
@@ -1492,6 +1495,7 @@ int batch_fill_exec(BatchWorkspace& ws, const BatchPlan& plan, vvm_exec_context*
 		memset(t, 0, sizeof(*t));
 		t->status = ws.d_status + plan.status_off[(size_t)i]; t->ride = ride;
 		t->num_instances = (uint32_t)ctxs[i].NumInstances; t->num_tiles = pe.tiles; t->pad = plan.through_first_tile[(size_t)i];
+		t->instances_per_lane = 8;      // (lean members of a batch run on the light kernel)
 		const int trc = fill_through(st, &ctxs[i], *t);
 		if (trc != VVM_OK) return trc;
 	}

@@ -7,7 +7,8 @@
 extern "C" {
 // Enqueue the interpreter over `total_tiles` tiles described by `descs` (device memory).  instances_per_lane is 8, 4 or 1;
 // many_registers != 0 selects the kernels with 32 resident registers plus lds_spill_slots registers in LDS; full != 0 the
-// kernels that also implement the transcendental ops, the noise built-ins and the ID instructions.
+// kernels that also implement the transcendental ops, the noise built-ins and the ID instructions (full == 2, four instances per
+// lane without many_registers: the instantiation of that kernel that leaves the ride words for vvm_through_kernel).
 // A launch of one Exec may hand its parameter block over as a kernel argument instead: descs = null, inline_block = the block
 // as filled on the host with VVM_DESC_RELATIVE set, inline_bytes <= VVM_INLINE_PARAM_BYTES (copied before the call returns).
 // tag: 0 = the look-back words of this launch are tagged with the epoch kept in `ls`; otherwise the tag itself, 1..VVM_MAX_LAUNCH_TAG

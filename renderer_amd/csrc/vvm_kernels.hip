@@ -1088,7 +1088,7 @@ struct KernelEnv {
 };
 
 // ------------------------------------------------------------------------------------------------------
-template <int V, bool SPILL, bool FULL>
+template <int V, bool SPILL, bool FULL, bool RIDE = false>
 DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c, unsigned char* lds, uint32_t tile_local, uint32_t tag, VvmLaunchState* ls, uint32_t dbg, Pending& pend,
                   uint32_t& resolves, const u64 (&pre)[VVM_LB_WORDS_PER_LANE], bool have_pre,
                   RVEC& K0, RVEC& K1, RVEC& K2, RVEC& K3, RVEC& K4, RVEC& K5, RVEC& K6, RVEC& K7)
@@ -1618,8 +1618,11 @@ leave_run:
 	pend.unresolved = t_pending; pend.total = t_total; pend.base = t_base; pend.stage_end = stage_end; pend.last = last_tile;
 	pend.tile_local = tile_local; pend.status = status; pend.out_list = c.out_list;
 	pend.ride = t_keep | (t_rank << 8) | (t_rank_b << 20);
-	if constexpr (V == 8 && !IS_LIGHT(V, SPILL)) {
-		// the same word for vvm_through_kernel from the general eight-wide kernel, straight from the tile that made it (see store_tile)
+	if constexpr ((V == 8 && !IS_LIGHT(V, SPILL)) || RIDE) {
+		// the same word for vvm_through_kernel from the general eight-wide kernel, straight from the tile that made it (see store_tile);
+		// also from the instantiation of the four-wide kernel with the transcendental and noise functions that lean programs run on
+		// (RIDE; its t_rank_b nobody reads.  An instantiation of its own: in the kernel every such script runs on, the store cost 23 more
+		// spilled scalars and 0.5 to 1 % of the transcendental configuration's time)
 		const uint64_t ride_base = sload64(c.out_list - 3, 0);
 		if (ride_base != 0) {
 			const rsrc_t rr = make_rsrc(ride_base + (uint64_t)tile_local * (VVM_BLOCK_THREADS * 4u), VVM_BLOCK_THREADS * 4u);
@@ -1630,7 +1633,7 @@ leave_run:
 }
 
 // DBG: the bring-up switches of KernelEnv::debug_skip are compiled in (one instantiation only); otherwise they cost nothing.
-template <int V, bool SPILL, bool FULL, bool DBG = false>
+template <int V, bool SPILL, bool FULL, bool DBG = false, bool RIDE = false>
 __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (IS_LIGHT(V, SPILL) ? 3 : V == 8 || (V == 4 && SPILL) ? 2 : FULL ? 3 : (V == 4 ? 4 : 8))) vvm_exec_kernel(KernelEnv env)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -1743,7 +1746,7 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (IS_LIGHT(V, SPILL) ? 3 : V
 		c.valid = min(num_instances - tile_first, (uint32_t)(VVM_BLOCK_THREADS * V));
 		c.phase = FULL ? started++ : phase;      // (tiles this workgroup has started: with fused passes more than one per ticket)
 		if (!(dbgw & 1u))
-			run_tile<V, SPILL, FULL>((const VvmIns*)DESC_PTR(dp, prog), (gu64*)DESC_PTR(dp, status), last_tile, c, lds, tile_local, tag, env.ls, dbgw, pend, resolves, pre, have_pre && first_pass,
+			run_tile<V, SPILL, FULL, RIDE>((const VvmIns*)DESC_PTR(dp, prog), (gu64*)DESC_PTR(dp, status), last_tile, c, lds, tile_local, tag, env.ls, dbgw, pend, resolves, pre, have_pre && first_pass,
 			                         K0, K1, K2, K3, K4, K5, K6, K7);
 		first_pass = false;
 		} while (FULL && ++e < e_end);
@@ -1786,11 +1789,13 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (IS_LIGHT(V, SPILL) ? 3 : V
 // (VectorVMRuntime.cpp:786-804) because the ranks are the acquireindex's own.
 // SRC / DST: where pair i's stream addresses come from (the kernel's own arguments, or an Exec's block in device memory: scalar
 // loads either way, the index is uniform).
-template <typename SRC, typename DST>
+// V = 8: the tile layout of the eight-wide kernels (two halves of 1024 instances, a lane holds four consecutive instances of each);
+// V = 4: tiles of 1024 instances, four consecutive ones per lane.
+template <int V, typename SRC, typename DST>
 DEV void through_tile(const unsigned long long* status, const uint32_t* ride_words, uint32_t num_instances, uint32_t num_pairs, uint32_t tile, uint32_t p0,
                       uint32_t (&packed)[VVM_THROUGH_PAIRS_PER_BLOCK][VVM_BLOCK_THREADS * 8u + VVM_BLOCK_THREADS], SRC src, DST dst)
 {
-	constexpr uint32_t TILE = VVM_BLOCK_THREADS * 8u, PPB = VVM_THROUGH_PAIRS_PER_BLOCK;
+	constexpr uint32_t TILE = VVM_BLOCK_THREADS * (uint32_t)V, PPB = VVM_THROUGH_PAIRS_PER_BLOCK;
 	const uint32_t tid = threadIdx.x;
 	const uint32_t inclusive = (uint32_t)sload64(status, tile);
 	const uint32_t base = tile ? (uint32_t)sload64(status, tile - 1u) : 0u;
@@ -1804,7 +1809,8 @@ DEV void through_tile(const unsigned long long* status, const uint32_t* ride_wor
 		const bool used = p0 + j < num_pairs;
 		const rsrc_t rs = make_rsrc(src(used ? p0 + j : p0) + 4ull * first, used ? 4u * valid : 0u);
 		lo[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(tid * 16u), 0, AUX_STREAM_LOAD);
-		hi[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(VVM_HALF_TILE * 4u + tid * 16u), 0, AUX_STREAM_LOAD);
+		if constexpr (V == 8) hi[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(VVM_HALF_TILE * 4u + tid * 16u), 0, AUX_STREAM_LOAD);
+		else hi[j] = lo[j];
 	}
 	if (total == TILE) {
 #pragma unroll
@@ -1812,7 +1818,7 @@ DEV void through_tile(const unsigned long long* status, const uint32_t* ride_wor
 			const bool used = p0 + j < num_pairs;
 			const rsrc_t rd = make_rsrc(dst(used ? p0 + j : p0) + 4ull * base, used ? 4u * TILE : 0u);
 			__builtin_amdgcn_raw_buffer_store_b128(lo[j], rd, (int)(tid * 16u), 0, AUX_STREAM_STORE);
-			__builtin_amdgcn_raw_buffer_store_b128(hi[j], rd, (int)(VVM_HALF_TILE * 4u + tid * 16u), 0, AUX_STREAM_STORE);
+			if constexpr (V == 8) __builtin_amdgcn_raw_buffer_store_b128(hi[j], rd, (int)(VVM_HALF_TILE * 4u + tid * 16u), 0, AUX_STREAM_STORE);
 		}
 		return;
 	}
@@ -1822,10 +1828,10 @@ DEV void through_tile(const unsigned long long* status, const uint32_t* ride_wor
 		const uint32_t v[8] = {lo[j].x, lo[j].y, lo[j].z, lo[j].w, hi[j].x, hi[j].y, hi[j].z, hi[j].w};
 		uint32_t r = (ride >> 8) & 0xFFFu;
 #pragma unroll
-		for (int k = 0; k < 8; ++k) {
+		for (int k = 0; k < V; ++k) {
 			if (k == 4) r = ride >> 20;
 			const bool keep = (ride >> k) & 1u;
-			packed[j][keep ? r : TILE + tid] = v[k];
+			packed[j][keep ? r : VVM_BLOCK_THREADS * 8u + tid] = v[k];
 			r += keep ? 1u : 0u;
 		}
 	}
@@ -1835,15 +1841,18 @@ DEV void through_tile(const unsigned long long* status, const uint32_t* ride_wor
 		const bool used = p0 + j < num_pairs;
 		const rsrc_t rd = make_rsrc(dst(used ? p0 + j : p0) + 4ull * base, used ? 4u * total : 0u);
 		const u32x4 x = *(const u32x4*)&packed[j][tid * 4u];
-		const u32x4 y = *(const u32x4*)&packed[j][VVM_HALF_TILE + tid * 4u];
 		__builtin_amdgcn_raw_buffer_store_b128(x, rd, (int)(tid * 16u), 0, AUX_STREAM_STORE);
-		__builtin_amdgcn_raw_buffer_store_b128(y, rd, (int)(VVM_HALF_TILE * 4u + tid * 16u), 0, AUX_STREAM_STORE);
+		if constexpr (V == 8) {
+			const u32x4 y = *(const u32x4*)&packed[j][VVM_HALF_TILE + tid * 4u];
+			__builtin_amdgcn_raw_buffer_store_b128(y, rd, (int)(VVM_HALF_TILE * 4u + tid * 16u), 0, AUX_STREAM_STORE);
+		}
 	}
 }
+template <int V>
 __global__ void __launch_bounds__(VVM_BLOCK_THREADS) vvm_through_kernel(const VvmThroughArgs a)
 {
 	__shared__ __attribute__((aligned(16))) uint32_t packed[VVM_THROUGH_PAIRS_PER_BLOCK][VVM_BLOCK_THREADS * 8u + VVM_BLOCK_THREADS];
-	through_tile(a.status, a.ride, a.num_instances, a.num_pairs, blockIdx.x, blockIdx.y * VVM_THROUGH_PAIRS_PER_BLOCK, packed,
+	through_tile<V>(a.status, a.ride, a.num_instances, a.num_pairs, blockIdx.x, blockIdx.y * VVM_THROUGH_PAIRS_PER_BLOCK, packed,
 	             [&](uint32_t i) { return a.src[i]; }, [&](uint32_t i) { return a.dst[i]; });
 }
 // The same for the members of a batch: one block of VvmThroughArgs per Exec in device memory (pad = the number of its first tile
@@ -1859,7 +1868,7 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS) vvm_through_batch_kernel(co
 	const VvmThroughArgs* e = execs + lo;
 	const uint32_t tile = blockIdx.x - sload32(e, offsetof(VvmThroughArgs, pad) / 4);
 	if (tile >= sload32(e, offsetof(VvmThroughArgs, num_tiles) / 4)) return;
-	through_tile((const unsigned long long*)sload64(e, offsetof(VvmThroughArgs, status) / 8), (const uint32_t*)sload64(e, offsetof(VvmThroughArgs, ride) / 8),
+	through_tile<8>((const unsigned long long*)sload64(e, offsetof(VvmThroughArgs, status) / 8), (const uint32_t*)sload64(e, offsetof(VvmThroughArgs, ride) / 8),
 	             sload32(e, offsetof(VvmThroughArgs, num_instances) / 4), sload32(e, offsetof(VvmThroughArgs, num_pairs) / 4), tile, blockIdx.y * VVM_THROUGH_PAIRS_PER_BLOCK, packed,
 	             [&](uint32_t i) { return sload64(e, offsetof(VvmThroughArgs, src) / 8 + i); }, [&](uint32_t i) { return sload64(e, offsetof(VvmThroughArgs, dst) / 8 + i); });
 }
@@ -1867,7 +1876,8 @@ extern "C" int vvm_launch_through_kernel(const VvmThroughArgs* args, hipStream_t
 {
 	if (args->num_pairs == 0 || args->num_tiles == 0) return 0;
 	const dim3 grid(args->num_tiles, (args->num_pairs + VVM_THROUGH_PAIRS_PER_BLOCK - 1u) / VVM_THROUGH_PAIRS_PER_BLOCK);
-	hipLaunchKernelGGL(vvm_through_kernel, grid, dim3(VVM_BLOCK_THREADS), 0, stream, *args);
+	if (args->instances_per_lane == 4) hipLaunchKernelGGL(vvm_through_kernel<4>, grid, dim3(VVM_BLOCK_THREADS), 0, stream, *args);
+	else hipLaunchKernelGGL(vvm_through_kernel<8>, grid, dim3(VVM_BLOCK_THREADS), 0, stream, *args);
 	return (int)hipGetLastError();
 }
 extern "C" int vvm_launch_through_batch_kernel(const VvmThroughArgs* device_execs, uint32_t num_execs, uint32_t total_tiles, uint32_t max_pairs, hipStream_t stream)
@@ -2016,7 +2026,11 @@ extern "C" int vvm_launch_exec_kernel(int instances_per_lane, const VvmExecDesc*
 		else if (env.debug_skip) hipLaunchKernelGGL((vvm_exec_kernel<8, false, false, true>), dim3(grid), dim3(VVM_BLOCK_THREADS), lds_bytes, stream, env);
 		else VVM_LAUNCH(8, false, false);
 	} else if (instances_per_lane == 4) {
-		if (full) { if (spill) VVM_LAUNCH(4, true, true); else VVM_LAUNCH(4, false, true); }
+		if (full) {
+			if (spill) VVM_LAUNCH(4, true, true);
+			else if (full == 2) hipLaunchKernelGGL((vvm_exec_kernel<4, false, true, false, true>), dim3(grid), dim3(VVM_BLOCK_THREADS), lds_bytes, stream, env);      // (leaves ride words)
+			else VVM_LAUNCH(4, false, true);
+		}
 		else if (spill) VVM_LAUNCH(4, true, false);
 		else if (env.debug_skip) hipLaunchKernelGGL((vvm_exec_kernel<4, false, false, true>), dim3(grid), dim3(VVM_BLOCK_THREADS), lds_bytes, stream, env);
 		else VVM_LAUNCH(4, false, false);

@@ -11,8 +11,8 @@ pytestmark = pytest.mark.gpu
 EIGHT = abi.VVM_EXEC_FORCE_EIGHT_WIDE
 
 
-def _compare(n, extra_float, extra_int, death, flags=EIGHT, touch_one=False, instance_offset=0, expect_lean=True, lean_from=1024, more_math=0):
-    script = sc.wide_record_script(extra_float, extra_int, touch_one, more_math)
+def _compare(n, extra_float, extra_int, death, flags=EIGHT, touch_one=False, instance_offset=0, expect_lean=True, lean_from=1024, more_math=0, trig=False, lean_width=8):
+    script = sc.wide_record_script(extra_float, extra_int, touch_one, more_math, trig)
     ins = sc.streams(n, extra_float, extra_int, death)
     dts = sc.out_dtypes(extra_float, extra_int)
     want, want_n, _ = run_oracle(script, [sc.CONSTANTS], ins, dts, n, instance_offset=instance_offset)
@@ -22,7 +22,7 @@ def _compare(n, extra_float, extra_int, death, flags=EIGHT, touch_one=False, ins
     runs_lean = expect_lean and not (flags & abi.VVM_EXEC_NO_THROUGH_KERNEL) and ((flags & EIGHT) or n >= lean_from)
     if n > 0:
         whole_width = 8 if (extra_float + extra_int <= 8 and ((flags & EIGHT) or n >= 256 * 1024)) else 4      # (up to sixteen streams: the general eight-wide kernel)
-        assert width == [8 if runs_lean else whole_width]
+        assert width == [lean_width if runs_lean else whole_width]
     assert got_n == want_n
     for g, w in zip(got, want):
         np.testing.assert_array_equal(g[instance_offset:instance_offset + got_n].view(np.uint32), w[instance_offset:instance_offset + want_n].view(np.uint32))
@@ -268,3 +268,11 @@ def test_a_compiler_format_wide_record_script_through_the_optimizer():
     assert info.Flags & 0x80000 and width == [8] and got_n == want_n
     for g_, w_ in zip(got, want):
         np.testing.assert_array_equal(g_[:got_n].view(np.uint32), w_[:want_n].view(np.uint32))
+
+
+@pytest.mark.parametrize("n,death", [(1, 0.0), (1023, 0.5), (1025, 0.5), (70001, 0.3), (70001, 1.0), (70001, 0.0), (600001, 0.5)])
+def test_what_the_script_computes_needs_the_transcendental_functions(n, death):
+    """A sine and an exponential in what the script computes: the lean program runs four instances per lane on the kernel that has
+    them (sixteen registers), which leaves the ride words in its own layout, and the copy kernel works on its tiles of 1024."""
+    info = _compare(n, 16, 1, death, trig=True, lean_width=4, flags=0, lean_from=1 if n >= 1024 else 10 ** 9)
+    assert (info.Flags >> 24) == 18

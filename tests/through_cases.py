@@ -7,11 +7,12 @@ import numpy as np
 from renderer_amd.assembler import FLOAT, INT32, Script
 
 
-def wide_record_script(extra_float: int, extra_int: int, touch_one: bool = False, more_math: int = 0):
+def wide_record_script(extra_float: int, extra_int: int, touch_one: bool = False, more_math: int = 0, trig: bool = False):
     """8 float streams of the fountain + extra_float + extra_int handed-through streams.  touch_one: one of the extra float
     streams is also read by the arithmetic (so the program loads it and the copy kernel reads it again).  more_math: that many of
     the extra float streams are not handed through but scaled and offset (what the script computes then needs more registers than
-    the light kernel has)."""
+    the light kernel has).  trig: the new x velocity goes through a sine and the age through an exponential (the kernels with the
+    transcendental functions)."""
     s = Script()
     dt, drag = s.const(0), s.const(4)
     pos = [s.input(0, FLOAT, k) for k in range(3)]
@@ -28,6 +29,10 @@ def wide_record_script(extra_float: int, extra_int: int, touch_one: bool = False
         # (touch_one: the first extra stream stands in for pos.x, which is then not read at all, so that the computed part still
         # reads eight streams)
         s.op("mad", v1[c], dt, more_f[0] if (touch_one and more_f and c == 0) else pos[c], p1[c])
+    if trig:
+        t = s.temp(); s.op("sin", v1[0], t); v1[0] = t
+        t = s.temp(); s.op("exp", age1, t)
+        u = s.temp(); s.op("mul", p1[1], t, u); p1[1] = u
     changed = []
     for k in range(min(more_math, extra_float)):
         t = s.temp(); s.op("mad", more_f[k], drag, age1, t)

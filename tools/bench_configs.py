@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--force-eight", action="store_true", help="single Execs: eight instances per lane whatever the size (and with it the lean form of a wide-record script)")
     ap.add_argument("--extras", default="16,8", help="wide_record: numbers of handed-through attributes to run")
     ap.add_argument("--wide-particles", type=int, default=32 * 1024 * 1024, help="wide_record: instances")
+    ap.add_argument("--trig", action="store_true", help="wide_record: a sine and an exponential in what the script computes (the kernels with the transcendental functions)")
     ap.add_argument("--batch-per", type=int, default=16384, help="batch_wide: particles per emitter")
     ap.add_argument("--wide-kill-half", action="store_true", help="wide_record: half of the particles die")
     ap.add_argument("--more-math", type=int, default=0, help="wide_record: that many of the extra attributes are scaled and offset instead of handed through")
@@ -69,7 +70,7 @@ def main():
         print(json.dumps({"config": name, "particles": n, "survivors": surv, "steps": args.steps, "ms_per_step": el / args.steps * 1e3,
                           "kernel_ms": kernel_ms, "updates_per_s": n * args.steps / el, "algorithmic_GBps": alg / kernel_ms / 1e6,
                           "frac_of_8TBps": alg / kernel_ms / 1e6 / 8000.0, "instances_per_lane": width,
-                          "streams_left_to_the_copy_kernel": (info.Flags >> 24) if (info.Flags & 0x80000 and not args.no_through and width == 8) else 0}), flush=True)
+                          "streams_left_to_the_copy_kernel": (info.Flags >> 24) if (info.Flags & 0x80000 and not args.no_through and not args.no_light) else 0}), flush=True)
 
     def arith_script(n_ops):
         """4 streams in, 4 out, n_ops dependent mad / mul / add instructions spread over the streams: interpreter throughput."""
@@ -192,6 +193,10 @@ def main():
             for c in range(3):
                 s.op("mad_mul", s.const(1 + c), dt, vel[c], drag, v1[c])
                 s.op("mad", v1[c], dt, pos[c], p1[c])
+            if args.trig:
+                t = s.temp(); s.op("sin", v1[0], t); v1[0] = t
+                t = s.temp(); s.op("exp", age1, t)
+                u = s.temp(); s.op("mul", p1[1], t, u); p1[1] = u
             changed = []
             for k in range(min(args.more_math, extra)):
                 t = s.temp(); s.op("mad", rest[k], drag, age1, t)
@@ -207,7 +212,7 @@ def main():
             n = args.wide_particles
             base = scripts.fountain_streams_torch(0, n, dev, kill_half=args.wide_kill_half, pad=PAD)
             more = [torch.rand(n + PAD, dtype=torch.float32, device=dev) for _ in range(extra)]
-            run_single("fountain with %d more attributes, %d of them computed with, the others handed through (%d streams in / %d out), %d instances" % (extra, min(args.more_math, extra), 8 + extra, 8 + extra, n), w, base + more, 8 + extra, n)
+            run_single(("fountain with a sine and an exponential, " if args.trig else "fountain with ") + "%d more attributes, %d of them computed with, the others handed through (%d streams in / %d out), %d instances" % (extra, min(args.more_math, extra), 8 + extra, 8 + extra, n), w, base + more, 8 + extra, n)
             del more
     if "two_datasets" in which:
         # the fountain update with a second dataset that receives the particles that die this tick (position and age): both
