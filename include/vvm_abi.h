@@ -237,9 +237,10 @@ enum {
 	VVM_EXEC_SEPARATE_PASSES = 1u << 5,
 	/* A script whose particle record is wider than the register file of the light eight-wide kernel (every stream it reads is in a
 	 * per-lane register from the top of a tile), and whose extra width is attributes it hands through unchanged, is kept in a
-	 * lean form as well: a program for the light eight-wide kernel with everything the script computes, and the list of the
-	 * handed-through streams, which a copy kernel moves behind that program's launch (it takes every survivor's place from what
-	 * the program's acquireindex left).  A single Exec of at least VVM_THROUGH_MIN_INSTANCES instances (VVM_THROUGH_MIN_INSTANCES_EIGHT_WIDE
+	 * lean form as well: a program with everything the script computes (for the light eight-wide kernel; where that needs nine to
+	 * sixteen registers for the general eight-wide one, with transcendental or noise functions for the four-wide kernel that has
+	 * them), and the list of the handed-through streams, which a copy kernel moves behind that program's launch (it takes every
+	 * survivor's place from what the program's acquireindex left).  A single Exec of at least VVM_THROUGH_MIN_INSTANCES instances (VVM_THROUGH_MIN_INSTANCES_EIGHT_WIDE
 	 * where the whole script still fits the general eight-wide kernel) runs that way, and so does a member of a batch of at least
 	 * VVM_BATCH_THROUGH_MIN_INSTANCES instances whose whole script needs more than sixteen registers (one copy-kernel launch serves
 	 * all such members of a slice) (bit
