@@ -346,7 +346,7 @@ bool plan_through_programs(const vvm::ThawedScript& script, const vvm::LinkedPro
 		if (w.through_input[o] == -2) { through.clear(); return false; }
 		if (w.through_input[o] >= 0) through.push_back((uint32_t)o);
 	}
-	if (through.size() < 2 || through.size() > VVM_THROUGH_MAX_PAIRS) { through.clear(); return false; }
+	if (through.size() < 2) { through.clear(); return false; }
 	std::string why;
 	std::vector<uint8_t> select(O, 0);
 	for (size_t o = 0; o < O; ++o) select[o] = w.through_input[o] < 0;
@@ -373,11 +373,14 @@ int plan_through(vvm_state* st)
 }
 
 // The stream addresses of the handed-through pairs of an Exec, as fill_params forms them (element [InstanceOffset] of each stream).
-int fill_through(vvm_state* st, const vvm_exec_context* ctx, VvmThroughArgs& a)
+// `first`: the pairs from that one of the state's list on, as many as a block takes (a record with more handed-through streams
+// takes several launches of the copy kernel).
+int fill_through(vvm_state* st, const vvm_exec_context* ctx, VvmThroughArgs& a, size_t first = 0)
 {
 	const vvm::ThawedScript& s = st->script;
 	a.num_pairs = 0;
-	for (uint32_t o : st->through) {
+	for (size_t k = first; k < st->through.size() && k < first + VVM_THROUGH_MAX_PAIRS; ++k) {
+		const uint32_t o = st->through[k];
 		const vvm::InputInfo& in = st->wide.inputs[(size_t)st->wide.through_input[o]];
 		if (o >= s.num_outputs_remapped || s.out_dst[o] == 0xFFFF) continue;
 		const uint8_t dso = s.out_dataset[o];
@@ -461,9 +464,10 @@ int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, P
 		// (a member of a batch shares its launches with the others: there the form pays from 1 Ki instances on, for scripts that would
 		// otherwise run on the kernels with 32 registers and whose lean program fits the light kernel; 4096 emitters of 1 / 4 / 16 Ki
 		// instances, 24 streams each way: 0.25 / 0.52 / 1.99 ms against 0.28 / 0.83 / 3.11 ms whole)
-		const bool big = (pe.in_batch ? (whole_is_slow && st->lean.light && ctx->NumInstances >= VVM_BATCH_THROUGH_MIN_INSTANCES)
+		const bool one_block = st->through.size() <= VVM_THROUGH_MAX_PAIRS;      // (a member of a batch has one block for the copy kernel)
+		const bool big = (pe.in_batch ? (whole_is_slow && st->lean.light && one_block && ctx->NumInstances >= VVM_BATCH_THROUGH_MIN_INSTANCES)
 		                              : ctx->NumInstances >= (whole_is_slow ? VVM_THROUGH_MIN_INSTANCES : VVM_THROUGH_MIN_INSTANCES_EIGHT_WIDE)) ||
-		                 ((flags & VVM_EXEC_FORCE_EIGHT_WIDE) && (!pe.in_batch || st->lean.light));
+		                 ((flags & VVM_EXEC_FORCE_EIGHT_WIDE) && (!pe.in_batch || (st->lean.light && one_block)));
 		if (st->lean_ready && pass == 0 && !narrow && ctx->NumInstances > 0 && !pe.whole_only && !pe.reference_random && big &&
 		    !(flags & VVM_EXEC_NO_THROUGH_KERNEL) && !(!st->lean.full_kernel && (flags & VVM_EXEC_NO_EIGHT_WIDE)) && !(st->lean.light && (flags & VVM_EXEC_NO_LIGHT_KERNEL))) {
 			pe.lean = true;
@@ -1111,7 +1115,7 @@ static int exec_enqueue(vvm_exec_context* ctx, const vvm_exec_options* opt, bool
 			through.status = d_status; through.ride = st->d_ride;
 			through.num_instances = (uint32_t)ctx->NumInstances; through.num_tiles = pe.tiles; through.pad = 0;
 			through.instances_per_lane = pe.instances_per_lane;
-			rc = fill_through(st, ctx, through);
+			rc = fill_through(st, ctx, through);      // (validates the first block's streams before anything is launched; the rest below)
 			if (rc != VVM_OK) return rc;
 		}
 		if (pe.lp->updates_ids) {      // (one update_id per pass, and the passes follow each other on the stream: they share one piece of the buffers)
@@ -1146,8 +1150,14 @@ static int exec_enqueue(vvm_exec_context* ctx, const vvm_exec_options* opt, bool
 		                                       inline_block ? local_block : nullptr, inline_block ? (uint32_t)pe.bytes : 0u, 0u, 0);
 		if (lrc != 0) return hip_fail((hipError_t)lrc, "kernel launch");
 		if (pe.lean) {
-			const int trc = vvm_launch_through_kernel(&through, stream);
-			if (trc != 0) return hip_fail((hipError_t)trc, "kernel launch (handed-through streams)");
+			for (size_t first = 0; first < st->through.size(); first += VVM_THROUGH_MAX_PAIRS) {
+				if (first != 0) {
+					rc = fill_through(st, ctx, through, first);
+					if (rc != VVM_OK) return rc;
+				}
+				const int trc = vvm_launch_through_kernel(&through, stream);
+				if (trc != 0) return hip_fail((hipError_t)trc, "kernel launch (handed-through streams)");
+			}
 		}
 		if (timed && pass + 1 == num_passes) { HIP_TRY(hipEventRecord(st->ev_stop[st->ev_used], stream)); st->ev_used++; }
 		for (size_t u = 0; u < pe.lp->id_uses.size(); ++u) {
@@ -1842,7 +1852,7 @@ VVM_API int vvm_state_info(const vvm_state* st, vvm_program_info* out)
 	if (!st || !out) return fail(VVM_E_INVALID_ARG, "null argument");
 	fill_info(st->script, st->wide, out);
 	if (st->light_ready) out->Flags |= 0x20000u;
-	if (st->lean_ready) out->Flags |= 0x80000u | ((uint32_t)st->through.size() << 24);
+	if (st->lean_ready) out->Flags |= 0x80000u | ((uint32_t)std::min<size_t>(st->through.size(), 255) << 24);
 	return VVM_OK;
 }
 
@@ -1863,7 +1873,7 @@ VVM_API int vvm_inspect_blob(const uint8_t* blob, size_t num_bytes, vvm_program_
 	                        vvm::link_program(s, false, other, why, 0, true) == VVM_OK;
 	if (fits_light) out->Flags |= 0x20000u;
 	std::vector<uint32_t> through;
-	if (plan_through_programs(s, lp, fits_light, other, through)) out->Flags |= 0x80000u | ((uint32_t)through.size() << 24);
+	if (plan_through_programs(s, lp, fits_light, other, through)) out->Flags |= 0x80000u | ((uint32_t)std::min<size_t>(through.size(), 255) << 24);
 	return VVM_OK;
 }
 

@@ -276,3 +276,10 @@ def test_what_the_script_computes_needs_the_transcendental_functions(n, death):
     them (sixteen registers), which leaves the ride words in its own layout, and the copy kernel works on its tiles of 1024."""
     info = _compare(n, 16, 1, death, trig=True, lean_width=4, flags=0, lean_from=1 if n >= 1024 else 10 ** 9)
     assert (info.Flags >> 24) == 18
+
+
+@pytest.mark.parametrize("n,death", [(5000, 0.5), (300001, 0.2)])
+def test_a_record_with_more_streams_than_one_launch_of_the_copy_kernel_takes(n, death):
+    """120 handed-through streams: the whole script would run one instance per lane; lean, the copy kernel is launched three times."""
+    info = _compare(n, 110, 9, death, flags=0)
+    assert (info.Flags >> 24) == 120

@@ -38,8 +38,9 @@ def test_one_handed_through_stream_is_not_worth_a_second_launch():
     assert not f & LEAN and not f & LIGHT
 
 
-def test_more_streams_than_the_copy_kernel_takes_pairs():
-    assert not flags(tc.wide_record_script(60, 0)) & LEAN
+def test_more_streams_than_one_launch_of_the_copy_kernel_takes():
+    f = flags(tc.wide_record_script(100, 0))
+    assert f & LEAN and (f >> 24) == 101
 
 
 def test_what_the_script_computes_may_need_the_general_eight_wide_kernel():
