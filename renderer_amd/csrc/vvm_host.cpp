@@ -151,10 +151,11 @@ struct vvm_state {
 	std::vector<vvm::LinkedProgram> wide_more, narrow_more;
 	std::vector<VvmIns*> d_code_wide_more, d_code_narrow_more;
 
-	// A script whose record is too wide for the register file of the eight-wide kernels, but whose extra width is streams that it
-	// hands through unchanged, also has this form: a program for the light eight-wide kernel with everything the script computes
-	// (`lean`), and the list of handed-through outputs, which vvm_through_kernel moves behind that program's launch from the
-	// acquireindex results the program leaves per tile and lane (`d_ride`).  A large Exec runs that way.
+	// A script whose record is too wide for the register file of the light eight-wide kernel, but whose extra width is streams that
+	// it hands through unchanged, also has this form: a program with everything the script computes (`lean`: for the light kernel,
+	// else the general eight-wide one, else the four-wide one with the transcendental functions), and the list of handed-through
+	// outputs, which vvm_through_kernel moves behind that program's launch from the acquireindex results the program leaves per
+	// tile and lane (`d_ride`).  Which Execs run that way: prepare().
 	vvm::LinkedProgram lean;
 	VvmIns* d_code_lean = nullptr;
 	bool lean_ready = false;
@@ -403,8 +404,7 @@ int fill_through(vvm_state* st, const vvm_exec_context* ctx, VvmThroughArgs& a, 
 int ensure_ride(vvm_state* st, uint32_t tiles, hipStream_t stream)
 {
 	if (tiles <= st->ride_capacity) return VVM_OK;
-	HIP_TRY(hipStreamSynchronize(stream));
-	if (st->last_stream && st->last_stream != stream) HIP_TRY(hipStreamSynchronize(st->last_stream));
+	HIP_TRY(hipStreamSynchronize(stream));      // (the stream of the state's last Exec: exec_enqueue has waited for any other one)
 	if (st->d_ride) { HIP_TRY(hipFree(st->d_ride)); st->d_ride = nullptr; st->ride_capacity = 0; }
 	const uint32_t cap = std::max<uint32_t>(1024, tiles + tiles / 4);
 	HIP_TRY(hipMalloc((void**)&st->d_ride, (size_t)cap * VVM_BLOCK_THREADS * 4u));
