@@ -173,6 +173,7 @@ struct VvmXorwowFill {
 // address, 0 = none), and vvm_through_kernel moves the streams behind it: from the look-back words, which all hold inclusive
 // counts once the Exec's kernel has ended, it takes where a tile's survivors start, from the ride words where each goes.
 #define VVM_THROUGH_MAX_PAIRS 56u
+#define VVM_THROUGH_IS16 (1ull << 63)
 // (pairs one workgroup moves: measured on 24 / 40 streams each way at 32 Mi instances, all surviving / half dying, with 1, 2, 3, 4, 6
 // pairs: 1.12 / 1.84 / 0.85 / 1.38 ms with one, 1.17 / 1.96 / 0.95 / 1.56 ms with four: the more workgroups in flight the better)
 #ifndef VVM_THROUGH_PAIRS_PER_BLOCK
@@ -187,7 +188,7 @@ struct VvmThroughArgs {
 	                                    // rank of the lane's first survivor [8:20) (vvm_through_kernel only)
 	uint32_t reserved[3];
 	uint64_t src[VVM_THROUGH_MAX_PAIRS];   // byte address of element [InstanceOffset] of the input stream
-	uint64_t dst[VVM_THROUGH_MAX_PAIRS];   // ... of the output stream
+	uint64_t dst[VVM_THROUGH_MAX_PAIRS];   // ... of the output stream; VVM_THROUGH_IS16: both streams have 16-bit elements
 };
 
 // Launch-wide words in device memory; the last block to leave a launch re-arms them for the next one.

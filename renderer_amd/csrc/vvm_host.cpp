@@ -386,7 +386,8 @@ int fill_through(vvm_state* st, const vvm_exec_context* ctx, VvmThroughArgs& a, 
 		if (o >= s.num_outputs_remapped || s.out_dst[o] == 0xFFFF) continue;
 		const uint8_t dso = s.out_dataset[o];
 		const uint16_t ty = s.out_type[o];
-		if ((int)in.dataset >= ctx->DataSets.num || (int)dso >= ctx->DataSets.num || ty > 1) return fail(VVM_E_INVALID_ARG, "script reads or writes a dataset the context does not provide");
+		if ((int)in.dataset >= ctx->DataSets.num || (int)dso >= ctx->DataSets.num || ty > 2 || (ty == 2) != (in.type == 2))
+			return fail(VVM_E_INVALID_ARG, "script reads or writes a dataset the context does not provide");
 		const vvm_dataset_meta& dsi = ctx->DataSets.data[in.dataset];
 		const vvm_dataset_meta& dsw = ctx->DataSets.data[dso];
 		const uint32_t ii = dsi.InputRegisterTypeOffsets[in.type] + in.reg, oi = dsw.OutputRegisterTypeOffsets[ty] + s.out_dst[o];
@@ -394,8 +395,9 @@ int fill_through(vvm_state* st, const vvm_exec_context* ctx, VvmThroughArgs& a, 
 		if ((int)oi >= dsw.OutputRegisters.num || !dsw.OutputRegisters.data) return fail(VVM_E_INVALID_ARG, "output register index past OutputRegisters.num");
 		if (!dsw.OutputRegisters.data[oi]) continue;      // (no destination: nothing is written, as for any output)
 		if (!dsi.InputRegisters.data[ii]) return fail(VVM_E_INVALID_ARG, "an input stream the script reads is a null pointer");
-		a.src[a.num_pairs] = (uint64_t)(uintptr_t)dsi.InputRegisters.data[ii] + (uint64_t)(int64_t)dsi.InstanceOffset * 4u;
-		a.dst[a.num_pairs] = (uint64_t)(uintptr_t)dsw.OutputRegisters.data[oi] + (uint64_t)(int64_t)dsw.InstanceOffset * 4u;
+		const uint64_t stride = ty == 2 ? 2u : 4u;
+		a.src[a.num_pairs] = (uint64_t)(uintptr_t)dsi.InputRegisters.data[ii] + (uint64_t)(int64_t)dsi.InstanceOffset * stride;
+		a.dst[a.num_pairs] = ((uint64_t)(uintptr_t)dsw.OutputRegisters.data[oi] + (uint64_t)(int64_t)dsw.InstanceOffset * stride) | (ty == 2 ? VVM_THROUGH_IS16 : 0ull);
 		++a.num_pairs;
 	}
 	return VVM_OK;

@@ -1803,6 +1803,29 @@ DEV void through_tile(const unsigned long long* status, const uint32_t* ride_wor
 	if (total == 0 || p0 >= num_pairs) return;      // (uniform)
 	const uint32_t first = tile * TILE;
 	const uint32_t valid = min(num_instances - first, TILE);
+	if constexpr (PPB == 1) {
+		// a pair of 16-bit streams: element by element (the streams need not be aligned beyond their elements), every survivor
+		// straight to its place, dead ones past the end of the descriptor
+		const uint64_t d0 = dst(p0);
+		if (d0 & VVM_THROUGH_IS16) {
+			const rsrc_t rs = make_rsrc(src(p0) + 2ull * first, 2u * valid);
+			const rsrc_t rd = make_rsrc((d0 & ~VVM_THROUGH_IS16) + 2ull * base, 2u * total);
+			const uint32_t ride = (total == TILE) ? 0u : ride_words[(size_t)tile * VVM_BLOCK_THREADS + tid];
+			uint16_t v[V];
+#pragma unroll
+			for (int k = 0; k < V; ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b16(rs, (int)((tid * 4u + slot_offset<V>(k)) * 2u), 0, AUX_STREAM_LOAD);
+			uint32_t r = (ride >> 8) & 0xFFFu;
+#pragma unroll
+			for (int k = 0; k < V; ++k) {
+				if (k == 4) r = ride >> 20;
+				const bool keep = (total == TILE) || ((ride >> k) & 1u);
+				const uint32_t at = (total == TILE) ? tid * 4u + slot_offset<V>(k) : r;
+				__builtin_amdgcn_raw_buffer_store_b16(v[k], rd, (int)(keep ? at * 2u : VVM_RSRC_NOWHERE), 0, AUX_STREAM_STORE);
+				r += keep ? 1u : 0u;
+			}
+			return;
+		}
+	}
 	u32x4 lo[PPB], hi[PPB];
 #pragma unroll
 	for (uint32_t j = 0; j < PPB; ++j) {

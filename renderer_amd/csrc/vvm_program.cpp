@@ -449,11 +449,12 @@ static int link_program_as(const ThawedScript& s, bool force_narrow, LinkedProgr
 				const uint32_t serial = p.second - out0;
 				if (writers[serial]++) { lp.through_input[serial] = -2; continue; }
 				const bool word_copy = d.op == VVM_OP_outputdata_float || d.op == VVM_OP_outputdata_int32;
+				const bool half_copy = d.op == VVM_OP_outputdata_half_from_half;      // (16 bits as they are, VectorVMRuntime.cpp:663-742)
 				// (of a script with two acquired datasets only the first one's: the copy kernel works from the first chain's results)
 				const bool behind_acquire = d.dataset < acquired.size() && acquired[d.dataset] && d.dataset == lp.acquire_order.front();
-				if (word_copy && behind_acquire && p.first >= T + C && p.first < T + C + I) {
+				if ((word_copy || half_copy) && behind_acquire && p.first >= T + C && p.first < T + C + I) {
 					const uint32_t i = p.first - (T + C);
-					if (!lp.inputs[i].noadvance && lp.inputs[i].type != 2) lp.through_input[serial] = (int32_t)i;
+					if (!lp.inputs[i].noadvance && (lp.inputs[i].type == 2) == half_copy) lp.through_input[serial] = (int32_t)i;
 				}
 			}
 		}

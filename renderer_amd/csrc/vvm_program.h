@@ -82,8 +82,8 @@ struct LinkedProgram {
 	                                   // -2 = the ID register of update_id
 	std::vector<uint8_t> out_is16;     // per entry: the destination stream has 16-bit elements
 	// Per output serial index (the output's register minus the first output register): the remapped input whose value an output
-	// instruction hands through to it unchanged (an advancing 32-bit stream, written by outputdata_float / _int32 behind the
-	// dataset's acquireindex), or -1.  -2: the serial index is written by more than one pair.  See `out_select` of link_program.
+	// instruction hands through to it unchanged (an advancing 32-bit stream written by outputdata_float / _int32, or an advancing
+	// 16-bit stream written by outputdata_half_from_half, behind the dataset's acquireindex), or -1.  -2: the serial index is written by more than one pair.  See `out_select` of link_program.
 	std::vector<int32_t> through_input;
 };
 

@@ -283,3 +283,19 @@ def test_a_record_with_more_streams_than_one_launch_of_the_copy_kernel_takes(n, 
     """120 handed-through streams: the whole script would run one instance per lane; lean, the copy kernel is launched three times."""
     info = _compare(n, 110, 9, death, flags=0)
     assert (info.Flags >> 24) == 120
+
+
+@pytest.mark.parametrize("n,death,offset", [(1, 0.0, 0), (2047, 0.5, 1), (70001, 0.5, 3), (70001, 0.0, 0), (70001, 1.0, 5), (400001, 0.25, 7)])
+def test_sixteen_bit_streams_are_handed_through_too(n, death, offset):
+    """Three half streams among the handed-through ones, at odd instance offsets (the streams are aligned to their elements only)."""
+    script = sc.wide_record_script(12, 1, extra_half=3)
+    ins = sc.streams(n, 12, 1, death, extra_half=3)
+    dts = sc.out_dtypes(12, 1, 3)
+    want, want_n, _ = run_oracle(script, [sc.CONSTANTS], ins, dts, n, instance_offset=offset)
+    width = []
+    got, got_n, info = run_hip(script, [sc.CONSTANTS], ins, dts, n, instance_offset=offset, flags=EIGHT, last_width=width)
+    assert info.Flags & 0x80000 and (info.Flags >> 24) == 17 and width == [8] and got_n == want_n
+    for g, w, dt in zip(got, want, dts):
+        view = np.uint16 if dt == np.float16 else np.uint32
+        np.testing.assert_array_equal(g[offset:offset + got_n].view(view), w[offset:offset + want_n].view(view))
+        assert (g[offset + got_n:].view(np.uint8) == 0xCD).all()

@@ -62,8 +62,8 @@ def test_an_output_written_twice_keeps_the_script_whole():
     assert not flags(s.build()) & LEAN
 
 
-def test_streams_that_are_not_plain_32_bit_copies_stay_in_the_program():
-    """Half streams, no-advance inputs and outputs ahead of the acquireindex are not handed to the copy kernel."""
+def test_streams_that_are_not_plain_copies_stay_in_the_program():
+    """No-advance inputs are not handed to the copy kernel; a 16-bit stream copied as it is (outputdata_half_from_half) is."""
     from renderer_amd.assembler import HALF
     s = Script()
     x = [s.input(0, FLOAT, k) for k in range(18)]
@@ -73,6 +73,18 @@ def test_streams_that_are_not_plain_32_bit_copies_stay_in_the_program():
     t = s.temp(); s.op("add", x[0], x[1], t)
     s.output_data(FLOAT, 0, [(t, s.output(0, FLOAT, 0))] + [(x[k], s.output(0, FLOAT, k)) for k in range(1, 18)] + [(na, s.output(0, FLOAT, 18))])
     s.output_data(HALF, 0, [(h, s.output(0, HALF, 0))], from_half=True)
+    f = flags(s.build())
+    assert f & LEAN and (f >> 24) == 18      # seventeen float streams and the half one; not the no-advance input
+
+
+def test_a_float_written_to_a_half_stream_is_a_conversion_not_a_copy():
+    from renderer_amd.assembler import HALF
+    s = Script()
+    x = [s.input(0, FLOAT, k) for k in range(20)]
+    s.acquireindex(s.const(0), 0)
+    t = s.temp(); s.op("add", x[0], x[1], t)
+    s.output_data(FLOAT, 0, [(t, s.output(0, FLOAT, 0))] + [(x[k], s.output(0, FLOAT, k)) for k in range(1, 18)])
+    s.output_data(HALF, 0, [(x[18], s.output(0, HALF, 0)), (x[19], s.output(0, HALF, 1))])
     f = flags(s.build())
     assert f & LEAN and (f >> 24) == 17
 
