@@ -85,7 +85,9 @@ class _WideEmitter:
     """An emitter with a wide record (through_cases.wide_record_script) with the interface of test_gpu_batch_handle._Emitter."""
     CAP = 90_000
 
-    def __init__(self, be, e, n, extra_float, extra_int):
+    def __init__(self, be, e, n, extra_float, extra_int, cap=None):
+        if cap:
+            self.CAP = cap
         from renderer_amd.runtime import VectorVMState
         from vm_harness import PAD
         self.be, self.n, self.PAD = be, n, PAD
@@ -299,3 +301,29 @@ def test_sixteen_bit_streams_are_handed_through_too(n, death, offset):
         view = np.uint16 if dt == np.float16 else np.uint32
         np.testing.assert_array_equal(g[offset:offset + got_n].view(view), w[offset:offset + want_n].view(view))
         assert (g[offset + got_n:].view(np.uint8) == 0xCD).all()
+
+
+def test_lean_members_in_every_slice_of_a_large_batch():
+    """1100 emitters in one vvm_exec_batch call (three slices that are filled, uploaded and launched one after the other), every
+    fourth one with a wide record: each slice has its own row of blocks for the copy kernel and its own launch of it."""
+    be = abi.load_hip_backend()
+    ems = []
+    try:
+        for e in range(1100):
+            n = 1 + (e * 37) % 2900
+            # (the others run the same update on the plain eight-stream record, which fits the light kernel whole)
+            ems.append(_WideEmitter(be, e, n, 10, 1, cap=3000) if e % 4 == 1 else _WideEmitter(be, e, n, 0, 0, cap=3000))
+    except AssertionError:
+        for em in ems:
+            em.free()
+        raise
+    try:
+        arr, oarr = be.pack_batch([em.frame for em in ems], [abi.ExecOptions(0, 0, 0, None, 0) for _ in ems])
+        be.exec_batch_packed(arr, oarr)
+        for i in list(range(0, 1100, 7)) + [1, 5, 1097]:
+            ems[i].check("emitter %d" % i)
+        lean = [em.state.last_exec_width() == 8 for em in ems[1::4]]
+        assert lean == [em.n >= 1024 for em in ems[1::4]] and any(lean) and not all(lean)
+    finally:
+        for em in ems:
+            em.free()
