@@ -295,11 +295,13 @@ VVM_API int vvm_exec_finish(vvm_exec_context* ctx);
 /* vvm_exec_ex for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that forbid
  * hipMalloc): same arguments, same results, but the call makes no hipMalloc / hipFree / hipHostMalloc and creates no stream
  * or event.  The launch words, survivor counts and look-back words of the Exec live in an array that is part of the library's
- * code object (1 MiB + 4.25 KiB per device, held from the library's first use on that device until the process ends) instead
- * of in buffers sized per Exec.  Limits, each refused with a message (vvm_last_error):
+ * code object (5 MiB + 4.25 KiB per device, held from the library's first use on that device until the process ends) instead
+ * of in buffers sized per Exec; 4 MiB of it are the words through which a script with a wide record runs in its lean form (see
+ * VVM_EXEC_NO_THROUGH_KERNEL) up to 4096 tiles, i.e. 8 Mi instances: larger Execs of such a script run it whole, with the same
+ * results.  Limits, each refused with a message (vvm_last_error):
  *   - at most 131072 tiles: 128 Mi instances at four instances per lane, 256 Mi at eight (VVM_E_TOO_LARGE);
  *   - the script's parameter block (constants, stream addresses) fits the 1 KB that travels as a kernel argument: about
- *     40 streams and constants together (VVM_E_TOO_LARGE);
+ *     40 streams and constants together, for an Exec in the lean form those of the lean program only (VVM_E_TOO_LARGE);
  *   - no update_id / acquire_id (their scratch is sized per Exec), no VVM_EXEC_NO_VGPR_WIDE before a vvm_exec_ex has used it on
  *     the state (VVM_E_UNSUPPORTED_OP).
  * Every call on a device shares that device's array: calls that overlap in time on one device (two threads, or a queued

@@ -98,13 +98,16 @@ struct ParamRing {
 };
 
 // Working memory of vvm_exec_noalloc, the entry point for callers that must not allocate: the launch words (with the survivor
-// counts in their spare words) and one look-back word per tile.  The array is part of the code object, so every device the
+// counts in their spare words), one look-back word per tile and, for Execs that run the lean form of their script (vvm_state::lean),
+// one ride word per lane and tile up to VVM_NOALLOC_RIDE_TILES tiles (larger Execs run the whole script there).  The array is part of the code object, so every device the
 // library runs on holds a copy of its own from the moment the code object is loaded there until the process ends.  Its name is
 // only a handle on the host: the address on a device comes from hipGetSymbolAddress with that device current (ensure_device_info),
 // and that address is what host code passes on.
 #define VVM_NOALLOC_MAX_TILES 131072u
 #define VVM_NOALLOC_STATUS_OFF ((sizeof(VvmLaunchState) + 255u) & ~(size_t)255u)
-#define VVM_NOALLOC_SCRATCH_BYTES (VVM_NOALLOC_STATUS_OFF + 8u * (size_t)VVM_NOALLOC_MAX_TILES)
+#define VVM_NOALLOC_RIDE_TILES 4096u
+#define VVM_NOALLOC_RIDE_OFF (VVM_NOALLOC_STATUS_OFF + 8u * (size_t)VVM_NOALLOC_MAX_TILES)
+#define VVM_NOALLOC_SCRATCH_BYTES (VVM_NOALLOC_RIDE_OFF + 4u * (size_t)VVM_BLOCK_THREADS * VVM_NOALLOC_RIDE_TILES)
 static __device__ __align__(256) unsigned char scratch[VVM_NOALLOC_SCRATCH_BYTES];
 
 struct DeviceInfo {
@@ -273,7 +276,7 @@ struct PreparedExec {
 	uint32_t instances_per_lane = 4;                   // of the kernel this Exec runs on (8, 4 or 1)
 	bool light = false;                                // ... the light eight-wide kernel
 	bool in_batch = false;                             // set by the caller: the Exec is a member of a batch (decides the kernel of small Execs, see prepare)
-	bool whole_only = false;                           // set by the caller: never the lean form of the script (vvm_exec_noalloc)
+	uint32_t lean_max_tiles = 0;                       // set by the caller: the lean form of the script only up to so many tiles (vvm_exec_noalloc; 0: no limit)
 	bool lean = false;                                 // the Exec runs the state's lean program; vvm_through_kernel follows it
 	uint64_t ride_addr = 0;                            // where the program leaves its per-lane acquireindex results for that kernel (0: nowhere)
 	uint32_t id_buffers = 0;                           // which piece of the state's update_id buffers this pass works in (fused passes run together)
@@ -470,7 +473,9 @@ int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, P
 		const bool big = (pe.in_batch ? (whole_is_slow && st->lean.light && one_block && ctx->NumInstances >= VVM_BATCH_THROUGH_MIN_INSTANCES)
 		                              : ctx->NumInstances >= (whole_is_slow ? VVM_THROUGH_MIN_INSTANCES : VVM_THROUGH_MIN_INSTANCES_EIGHT_WIDE)) ||
 		                 ((flags & VVM_EXEC_FORCE_EIGHT_WIDE) && (!pe.in_batch || (st->lean.light && one_block)));
-		if (st->lean_ready && pass == 0 && !narrow && ctx->NumInstances > 0 && !pe.whole_only && !pe.reference_random && big &&
+		const uint64_t lean_tile = (uint64_t)VVM_BLOCK_THREADS * (st->lean.full_kernel ? 4u : 8u);
+		const bool room = pe.lean_max_tiles == 0 || ((uint64_t)std::max(ctx->NumInstances, 0) + lean_tile - 1) / lean_tile <= pe.lean_max_tiles;
+		if (st->lean_ready && pass == 0 && !narrow && ctx->NumInstances > 0 && room && !pe.reference_random && big &&
 		    !(flags & VVM_EXEC_NO_THROUGH_KERNEL) && !(!st->lean.full_kernel && (flags & VVM_EXEC_NO_EIGHT_WIDE)) && !(st->lean.light && (flags & VVM_EXEC_NO_LIGHT_KERNEL))) {
 			pe.lean = true;
 			pe.lp = &st->lean;
@@ -1025,7 +1030,7 @@ static int exec_enqueue(vvm_exec_context* ctx, const vvm_exec_options* opt, bool
 			return fail(VVM_E_TOO_LARGE, "vvm_exec_noalloc: too many output datasets for the scratch array's count words");
 	}
 	PreparedExec pe;
-	pe.whole_only = no_alloc;
+	pe.lean_max_tiles = no_alloc ? VVM_NOALLOC_RIDE_TILES : 0;
 	int rc = prepare(st, ctx, opt, pe);
 	if (rc != VVM_OK) return rc;
 	if (no_alloc && pe.reference_random) return fail(VVM_E_UNSUPPORTED_OP, "vvm_exec_noalloc: RandXorwowState needs a buffer sized per Exec");
@@ -1111,14 +1116,22 @@ static int exec_enqueue(vvm_exec_context* ctx, const vvm_exec_options* opt, bool
 		}
 		VvmThroughArgs through;
 		if (pe.lean) {
-			rc = ensure_ride(st, pe.tiles, stream);
-			if (rc != VVM_OK) return rc;
-			pe.ride_addr = (uint64_t)(uintptr_t)st->d_ride;
-			through.status = d_status; through.ride = st->d_ride;
+			uint32_t* ride = no_alloc ? (uint32_t*)(scratch_ptr + VVM_NOALLOC_RIDE_OFF) : nullptr;      // (prepare has kept the Exec within VVM_NOALLOC_RIDE_TILES)
+			if (!no_alloc) {
+				rc = ensure_ride(st, pe.tiles, stream);
+				if (rc != VVM_OK) return rc;
+				ride = st->d_ride;
+			}
+			pe.ride_addr = (uint64_t)(uintptr_t)ride;
+			through.status = d_status; through.ride = ride;
 			through.num_instances = (uint32_t)ctx->NumInstances; through.num_tiles = pe.tiles; through.pad = 0;
 			through.instances_per_lane = pe.instances_per_lane;
-			rc = fill_through(st, ctx, through);      // (validates the first block's streams before anything is launched; the rest below)
-			if (rc != VVM_OK) return rc;
+			// (every block's streams are validated before anything is launched: last block first, so that the first one is left in place)
+			const size_t blocks = (st->through.size() + VVM_THROUGH_MAX_PAIRS - 1) / VVM_THROUGH_MAX_PAIRS;
+			for (size_t b = blocks; b-- > 0;) {
+				rc = fill_through(st, ctx, through, b * VVM_THROUGH_MAX_PAIRS);
+				if (rc != VVM_OK) return rc;
+			}
 		}
 		if (pe.lp->updates_ids) {      // (one update_id per pass, and the passes follow each other on the stream: they share one piece of the buffers)
 			rc = ensure_id_buffers(st, 1, pe.num_chunks, (uint32_t)ctx->NumInstances, stream);

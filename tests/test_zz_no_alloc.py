@@ -113,3 +113,37 @@ def test_no_alloc_entry_point_with_two_datasets_in_one_pass():
         st_new.close()
         for s in held:
             s.free()
+
+
+def test_no_alloc_entry_point_runs_the_lean_form_of_a_wide_record():
+    """A wide record (twelve attributes handed through beside the fountain's eight): up to 4096 tiles the entry point runs the lean
+    program and the copy kernel with the ride words in the scratch array, beyond that the whole script; streams and counts equal
+    vvm_exec_ex's either way.  The second call is smaller and finds the first one's ride words in the array."""
+    import through_cases as sc
+    be = abi.load_hip_backend()
+    blob = sc.wide_record_script(12, 0).blob
+    st_ref, st_new = VectorVMState(blob, be), VectorVMState(blob, be)
+    held = []
+    try:
+        assert st_new.info().Flags & 0x80000
+        for n, width in ((300_000, 8), (70_001, 8), (4096 * 2048 + 1, 4)):
+            host = sc.streams(n, 12, 0, 0.5, seed=n % 1000)
+            a, b = _Streams(be, host, n, outs=20), _Streams(be, host, n, outs=20)
+            held += [a, b]
+            fa = st_ref.frame([abi.DataSet(a.ins, a.outs, 0)], n, [sc.CONSTANTS])
+            fb = st_new.frame([abi.DataSet(b.ins, b.outs, 0)], n, [sc.CONSTANTS])
+            be.exec_ex(fa, abi.ExecOptions(0, 0, 0, None, 0))
+            be.exec_noalloc(fb, abi.ExecOptions(0, 0, 0, None, 0))
+            assert st_ref.last_exec_width() == 8 and st_new.last_exec_width() == width
+            surv = fa.survivors(0)
+            assert fb.survivors(0) == surv and 0 < surv < n
+            for k in range(20):
+                assert np.array_equal(b.download(k), a.download(k)), "n = %d, stream %d" % (n, k)
+            for s in (a, b):
+                s.free()
+            held = []
+    finally:
+        st_ref.close()
+        st_new.close()
+        for s in held:
+            s.free()
