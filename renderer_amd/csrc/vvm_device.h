@@ -63,6 +63,10 @@ enum : uint32_t {
 // writes those two registers only after its acquireindex, and the kernel finishes the previous tile right after that instruction.
 #define VVM_LIGHT_GROUP_SLOTS 6
 #define VVM_LIGHT_RIDE_REG 8
+// ... unless the tile keeps at most this many instances: then they lie compacted in the unused last quarter of the staging slots
+// (three slots per output, 512 survivors each)
+#define VVM_LIGHT_STASH_MAX 1536u
+#define VVM_LIGHT_STASH_SLOTS 3u
 // entry of VvmExecDesc::out_list: byte address in the low 48 bits (0 = nothing is written), flags above
 #define VVM_OUT_IS16 (1ull << 62)         // the destination stream has 16-bit elements
 #define VVM_OUT_GROUP16 (1ull << 61)      // on a group's first entry: some entry of the group has VVM_OUT_IS16 or VVM_OUT_UPDATE_ID

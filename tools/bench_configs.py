@@ -3,6 +3,7 @@
 
   transcendental   16 Mi particles, sin_cos + exp + curl-noise script            (BASELINE.json configs[2])
   kill_half        64 Mi particles, fountain with 50 % death                      (configs[3], one GPU's share scaled down)
+  death_sweep      64 Mi particles, fountain with 1 % to 75 % death
   kill_half_250m   250 M particles, fountain with 50 % death                      (configs[3], one GPU's share of 2 G particles)
   one_million      1 Mi particles, fountain                                       (configs[0], the reference's CPU-runnable case)
   reference_random 16 Mi particles, three random draws: the counter-based generator against the reference's xorwow
@@ -271,6 +272,17 @@ def main():
         n = 64 * 1024 * 1024
         w = scripts.fountain()
         run_single("fountain 64Mi, 50% death", w, scripts.fountain_streams_torch(0, n, dev, kill_half=True, pad=PAD), 8, n)
+    if "death_sweep" in which:
+        # the fountain with a given share of the particles dying in the Exec (spatially random)
+        n = 64 * 1024 * 1024
+        w = scripts.fountain()
+        for rate in (0.01, 0.05, 0.1, 0.2, 0.25, 0.3, 0.4, 0.75):
+            ins = scripts.fountain_streams_torch(0, n, dev, pad=PAD)
+            g = torch.Generator(device=dev); g.manual_seed(11)
+            dead = torch.rand(n + PAD, device=dev, generator=g) < rate
+            ins[6] = torch.where(dead, ins[7], ins[6])
+            run_single("fountain 64Mi, %g%% death" % (rate * 100), w, ins, 8, n)
+            del ins, dead
     if "kill_half_250m" in which:
         n = 250_000_000
         w = scripts.fountain()
