@@ -276,7 +276,7 @@ def main():
         # the fountain with a given share of the particles dying in the Exec (spatially random)
         n = 64 * 1024 * 1024
         w = scripts.fountain()
-        for rate in (0.01, 0.05, 0.1, 0.2, 0.25, 0.3, 0.4, 0.75):
+        for rate in (0.0, 0.01, 0.05, 0.1, 0.2, 0.25, 0.3, 0.4, 0.5, 0.75):
             ins = scripts.fountain_streams_torch(0, n, dev, pad=PAD)
             g = torch.Generator(device=dev); g.manual_seed(11)
             dead = torch.rand(n + PAD, device=dev, generator=g) < rate
