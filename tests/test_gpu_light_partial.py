@@ -60,3 +60,76 @@ def test_every_keep_pattern_of_a_lane():
 def test_death_rates(rate):
     rng = np.random.default_rng(int(rate * 1000))
     _run(rng.random(150_001) < rate, instance_offset=1)
+
+
+class _Emitter:
+    """One member of a batch: the fountain on `n` instances of which a share `rate` dies, streams in device memory."""
+    CAP = 20_000
+
+    def __init__(self, be, e, n, rate):
+        from renderer_amd.runtime import VectorVMState
+        from vm_harness import PAD
+        self.be, self.n, self.pad = be, n, PAD
+        self.w = scripts.fountain(variant=e % 16)
+        self.host_in = scripts.fountain_streams_np(e * 1_000_003, self.CAP)
+        dead = np.random.default_rng(e).random(self.CAP) < rate
+        self.host_in[6] = np.where(dead, self.host_in[7], self.host_in[6] * f32(0.0)).astype(f32)
+        self.ins, self.outs = [], []
+        for a in self.host_in:
+            buf = np.zeros(self.CAP + PAD, f32)
+            buf[:self.CAP] = a
+            p = be.lib.vvm_device_alloc(buf.nbytes)
+            assert p
+            be._check(be.lib.vvm_device_upload(p, buf.ctypes.data, buf.nbytes), "upload")
+            self.ins.append(p)
+        for _ in range(8):
+            p = be.lib.vvm_device_alloc((self.CAP + PAD) * 4)
+            assert p
+            be._check(be.lib.vvm_device_memset(p, 0xCD, (self.CAP + PAD) * 4), "memset")
+            self.outs.append(p)
+        self.state = VectorVMState(self.w.script.blob, be)
+        self.frame = self.state.frame([abi.DataSet(self.ins, self.outs, 0)], n, [self.w.constants])
+
+    def check(self, tag):
+        from vm_harness import run_oracle
+        ref, ref_n, _ = run_oracle(self.w.script, [self.w.constants], [a[:max(self.n, 1)] for a in self.host_in], [f32] * 8, self.n)
+        assert self.frame.survivors(0) == ref_n, tag
+        for k in range(8):
+            h = np.empty(self.CAP + self.pad, np.uint32)
+            self.be._check(self.be.lib.vvm_device_download(h.ctypes.data, self.outs[k], h.nbytes), "download")
+            assert np.array_equal(h[:ref_n], ref[k][:ref_n].view(np.uint32)), (tag, k)
+            assert (h[ref_n:] == 0xCDCDCDCD).all(), (tag, k)
+
+    def free(self):
+        self.state.close()
+        for p in self.ins + self.outs:
+            self.be.lib.vvm_device_free(p)
+
+
+def test_members_of_a_batch_that_lose_instances_at_every_rate():
+    """Members of one launch of the light kernel: a workgroup finishes one member's last tile (its two riding outputs by any of
+    the three ways) while it runs the next member's first tile, whose death rate is another one."""
+    be = abi.load_hip_backend()
+    rates = [0.0, 0.03, 0.15, 0.3, 0.6, 0.97, 0.01, 0.5]
+    sizes = [2048, 4096, 6000, 10_000, 2049, 12_289, 17_000, 3000, 8192, 5]
+    ems = [_Emitter(be, e, sizes[e % len(sizes)], rates[e % len(rates)]) for e in range(40)]
+    handle = None
+    try:
+        opts = [abi.ExecOptions(0, 0, 0, None, abi.VVM_EXEC_FORCE_EIGHT_WIDE) for _ in ems]
+        arr, oarr = be.pack_batch([em.frame for em in ems], opts)
+        be.exec_batch_packed(arr, oarr)
+        for i, em in enumerate(ems):
+            em.check("plain batch, emitter %d" % i)
+            assert em.state.last_exec_width() == 8 and em.state.info().Flags & 0x20000
+        handle = be.batch_create(arr, oarr)
+        for i, em in enumerate(ems):
+            em.n = min(em.CAP, em.n + 1000 + 13 * i)
+            arr[i].NumInstances = em.n
+        be.batch_exec(handle, abi.VVM_BATCH_CHANGED_INSTANCES)
+        for i, em in enumerate(ems):
+            em.check("handle, emitter %d" % i)
+    finally:
+        if handle:
+            be.batch_destroy(handle)
+        for em in ems:
+            em.free()
