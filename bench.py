@@ -132,6 +132,73 @@ def recorded_traffic(workload, particles):
     return None
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def rank_environment(rank, world, port, base=None):
+    """The environment of one rank's process as the launcher below sets it up (what torch.distributed.run would set)."""
+    env = dict(os.environ if base is None else base)
+    env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
+                "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
+def launch_ranks(world, argv, timeout_s=1500.0, program=None):
+    """`python bench.py --gpus N` without an outside launcher: this process (which has made no GPU call and makes none) starts one
+    fresh process per rank, hands rank 0's result line through, and fails when any rank fails.  Returns the exit code."""
+    import subprocess
+    import threading
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        procs.append(subprocess.Popen([sys.executable, program or os.path.abspath(__file__)] + list(argv), env=rank_environment(r, world, port),
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    lines = []
+    reader = threading.Thread(target=lambda: lines.extend(procs[0].stdout.read().decode().splitlines()), daemon=True)
+    reader.start()
+    deadline = time.monotonic() + timeout_s
+    failed = None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = "rank %d exited with status %d" % bad[0]
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.monotonic() > deadline:
+            failed = "no result within %.0f s" % timeout_s
+            break
+        time.sleep(0.05)
+    if failed:
+        # the ranks that are left would wait for the lost one in a collective: they are ended here, each by its own process id
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        sys.stderr.write("bench.py: %s\n" % failed)
+        return 1
+    reader.join(10)
+    result = [l for l in lines if l.startswith("{")]
+    if len(result) != 1:
+        sys.stderr.write("bench.py: rank 0 printed %d result lines\n" % len(result))
+        return 1
+    sys.stdout.write(result[0] + "\n")
+    sys.stdout.flush()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,6 +220,11 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        ap.error("--gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
     # Rank 0 prints ONE line on stdout.  Libraries write there too (RCCL prints a version banner when its first communicator
     # comes up), so everything else that lands on descriptor 1 goes to stderr and the result line to the real stdout.
     sys.stdout.flush()
@@ -166,6 +238,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d, but the launcher started %d rank(s) (WORLD_SIZE)\n" % (args.gpus, world))
+        sys.exit(2)
     distributed = world > 1 or args.collective_at_one
     if distributed:
         import torch.distributed as dist
@@ -175,6 +250,10 @@ def main():
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
+            if local_rank >= torch.cuda.device_count():
+                sys.stderr.write("bench.py: rank %d has no GPU of its own (%d visible); --backend gloo rehearses the multi-rank path on one GPU\n"
+                                 % (rank, torch.cuda.device_count()))
+                sys.exit(2)
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -258,6 +337,25 @@ def main():
         if int(ok.item()) == 0 and comm:
             be.comm_destroy(comm)
             comm = None
+
+    comm_keepalive = None
+    if distributed and args.comm == "c-abi" and args.backend == "gloo":
+        # rehearsal of the same C-ABI path on one GPU: the library's callback communicator, its all-gather carried by gloo between
+        # the ranks' processes (host buffers, so every step waits for its Exec: a functional rehearsal, not a measurement)
+        def gloo_all_gather(send, recv, count, _stream):
+            mine = torch.tensor([send[i] for i in range(count)], dtype=torch.int32)
+            parts = [torch.zeros(count, dtype=torch.int32) for _ in range(world)]
+            dist.all_gather(parts, mine)
+            for r in range(world):
+                for i in range(count):
+                    recv[r * count + i] = int(parts[r][i])
+            return 0
+
+        comm, comm_keepalive = be.comm_create_callback(rank, world, gloo_all_gather, abi.VVM_COMM_BUFFERS_HOST)
+    comm_ranks = int(be.lib.vvm_comm_world(comm)) if comm else 0
+    if comm and comm_ranks != world:
+        sys.stderr.write("bench.py: the communicator reports %d rank(s), the job has %d\n" % (comm_ranks, world))
+        sys.exit(2)
 
     def step():
         k = steps_done[0] & 1
@@ -367,8 +465,11 @@ def main():
             "config": {"workload": "%s script (8 f32 streams in, 8 out, kill via acquireindex), %d particles per GPU, "
                                    "%.1f%% survive" % (args.workload, n, 100.0 * survivors / max(n, 1)),
                        "particles_per_gpu": n, "survivors_rank0": survivors, "instances_per_lane": state.last_exec_width(),
-                       "parallelism": "instance ranges sharded over %d GPU(s); all-gather of survivor counts by %s" % (
-                           world, "the library's RCCL communicator (vvm_exec_sharded_async)" if comm else "torch.distributed") if distributed
+                       "parallelism": "instance ranges sharded over %d rank(s)%s; all-gather of survivor counts by %s" % (
+                           world, "" if args.backend == "nccl" else " that share GPU 0 (gloo rehearsal)",
+                           ("the library's RCCL communicator of %d rank(s) (vvm_exec_sharded_async)" % comm_ranks if args.backend == "nccl" else
+                            "the library's callback communicator of %d rank(s) over gloo (vvm_exec_sharded_async)" % comm_ranks) if comm
+                           else "torch.distributed (%d ranks)" % dist.get_world_size()) if distributed
                        else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": recorded_traffic(args.workload, n), "kernel": "vvm_exec_kernel", "kernel_ms": kernel_ms, "launches": launches,

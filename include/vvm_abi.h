@@ -364,6 +364,8 @@ VVM_API int       vvm_comm_unique_id(uint8_t* out_128_bytes);
 VVM_API vvm_comm* vvm_comm_create_rccl(int32_t rank, int32_t world, const uint8_t* unique_id_128_bytes);
 VVM_API vvm_comm* vvm_comm_create_callback(int32_t rank, int32_t world, vvm_all_gather_fn fn, void* user, int32_t where);
 VVM_API void      vvm_comm_destroy(vvm_comm* comm);
+/* The number of ranks of the communicator: what ncclCommCount reports for an RCCL communicator, `world` for a callback one. */
+VVM_API int32_t   vvm_comm_world(const vvm_comm* comm);
 /* One rank's part of a sharded Exec: vvm_exec_ex over the local range, then the exchange.  Synchronous. */
 VVM_API int vvm_exec_sharded(vvm_exec_context* ctx, const vvm_exec_options* opt, vvm_comm* comm, vvm_shard_result* out);
 /* The same in two halves, so that the exchange of one step runs (on the communicator's own stream) beside the next step's Exec:

@@ -293,6 +293,8 @@ class HipBackend(Backend):
         L.vvm_comm_create_callback.argtypes = [C.c_int32, C.c_int32, ALL_GATHER_FN, C.c_void_p, C.c_int32]
         L.vvm_comm_destroy.restype = None
         L.vvm_comm_destroy.argtypes = [C.c_void_p]
+        L.vvm_comm_world.restype = C.c_int32
+        L.vvm_comm_world.argtypes = [C.c_void_p]
         L.vvm_exec_sharded.restype = C.c_int
         L.vvm_exec_sharded.argtypes = [C.POINTER(ExecContext), C.POINTER(ExecOptions), C.c_void_p, C.POINTER(ShardResult)]
         L.vvm_exec_sharded_async.restype = C.c_int

@@ -1973,6 +1973,7 @@ struct RcclApi {
 	int (*comm_init_rank)(void**, int, vvm_nccl_id, int) = nullptr;
 	int (*all_gather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
 	int (*comm_destroy)(void*) = nullptr;
+	int (*comm_count)(const void*, int*) = nullptr;
 	const char* (*get_error_string)(int) = nullptr;
 };
 RcclApi g_rccl;
@@ -1994,6 +1995,7 @@ int load_rccl()
 	api.comm_init_rank = (int (*)(void**, int, vvm_nccl_id, int))dlsym(h, "ncclCommInitRank");
 	api.all_gather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(h, "ncclAllGather");
 	api.comm_destroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+	api.comm_count = (int (*)(const void*, int*))dlsym(h, "ncclCommCount");
 	api.get_error_string = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
 	if (!api.get_unique_id || !api.comm_init_rank || !api.all_gather || !api.comm_destroy) return fail(VVM_E_RCCL, "librccl.so lacks an entry point this library needs");
 	g_rccl = api;
@@ -2018,6 +2020,7 @@ struct vvm_comm {
 	int32_t* h_send = nullptr; int32_t* h_recv = nullptr;      // pinned twins
 	hipEvent_t counted[kCommSlots] = {}, exchanged[kCommSlots] = {};
 	int32_t slot_datasets[kCommSlots] = {};
+	uint32_t slot_acquired[kCommSlots] = {};  // bit d: the slot's script runs acquireindex for dataset d (only those words are written by its kernel)
 	uint64_t issued = 0, waited = 0;          // exchanges enqueued / handed out so far
 };
 
@@ -2105,6 +2108,16 @@ VVM_API vvm_comm* vvm_comm_create_callback(int32_t rank, int32_t world, vvm_all_
 	return c;
 }
 
+VVM_API int32_t vvm_comm_world(const vvm_comm* c)
+{
+	if (!c) return 0;
+	if (c->nccl && g_rccl.comm_count) {
+		int n = 0;
+		if (g_rccl.comm_count(c->nccl, &n) == 0) return (int32_t)n;
+	}
+	return c->world;
+}
+
 VVM_API void vvm_comm_destroy(vvm_comm* c)
 {
 	if (!c) return;
@@ -2143,6 +2156,11 @@ VVM_API int vvm_exec_sharded_async(vvm_exec_context* ctx, const vvm_exec_options
 	if (rc != VVM_OK) return rc;
 	hipStream_t exec_stream = st->last_stream;
 	c->slot_datasets[k] = nds;
+	// the kernel writes the count words of the datasets the script acquires and no others: the rest of the slot still holds what
+	// an earlier Exec (of another script) left there, and is reported as zero
+	c->slot_acquired[k] = 0;
+	for (int32_t d = 0; d < nds; ++d)
+		if ((size_t)d < st->wide.acquires_dataset.size() && st->wide.acquires_dataset[d]) c->slot_acquired[k] |= 1u << d;
 	if (c->fn && c->where == VVM_COMM_BUFFERS_HOST) {
 		// a host-side exchange (another transport, a test): the counts come to the host first; the call returns when the exchange is done
 		HIP_TRY(hipMemcpyAsync(h_send, d_send, (size_t)nds * 4, hipMemcpyDeviceToHost, exec_stream));
@@ -2174,7 +2192,12 @@ VVM_API int vvm_exec_sharded_wait(vvm_comm* c, vvm_shard_result* out)
 	const int k = (int)(c->waited % kCommSlots);
 	HIP_TRY(hipEventSynchronize(c->exchanged[k]));
 	c->waited++;
-	return vvm_shard_offsets(c->rank, c->world, c->slot_datasets[k], c->h_recv + (size_t)k * VVM_MAX_SHARD_DATASETS * (size_t)c->world, out);
+	int32_t* const all = c->h_recv + (size_t)k * VVM_MAX_SHARD_DATASETS * (size_t)c->world;
+	const int32_t nds = c->slot_datasets[k];
+	for (int32_t r = 0; r < c->world; ++r)
+		for (int32_t d = 0; d < nds; ++d)
+			if (!(c->slot_acquired[k] >> d & 1u)) all[(size_t)r * (size_t)nds + (size_t)d] = 0;
+	return vvm_shard_offsets(c->rank, c->world, nds, all, out);
 }
 
 VVM_API int vvm_exec_sharded(vvm_exec_context* ctx, const vvm_exec_options* opt, vvm_comm* c, vvm_shard_result* out)

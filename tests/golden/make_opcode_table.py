@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """Writes tests/golden/opcode_table.json: the reference's list of VectorVM opcodes as data (Runtime/VectorVM/Public/VectorVM.h,
 the VVM_OP_XM_LIST table): for every opcode its position in the list (= its numeric value, EVectorVMOp is generated from the list
-in order), name, category, operand counts as the table states them and the table's merge offset / count columns (which the
-optimizer's merge pass is indexed by).  Nothing of the reference is compiled or executed: the script reads the table rows as
+in order), name, category and operand counts as the table states them (the table's other columns are not kept).  Nothing of the reference is compiled or executed: the script reads the table rows as
 text, where the reference's sources are present (this container), and stores the fields; the tests read only the JSON."""
 import json
 import os
@@ -23,9 +22,8 @@ def main():
                 continue
             first = first or lineno
             last = lineno
-            name, cat, nin, nout, dispatch, merge_off, merge_count, params = m.groups()
-            rows.append({"value": len(rows), "name": name, "category": cat, "num_inputs": int(nin), "num_outputs": int(nout), "dispatch": dispatch,
-                         "merge_table_offset": int(merge_off), "merge_table_count": int(merge_count), "params": params})
+            name, cat, nin, nout = m.groups()[:4]
+            rows.append({"value": len(rows), "name": name, "category": cat, "num_inputs": int(nin), "num_outputs": int(nout)})
     out = {"about": "VVM_OP_XM_LIST as data; written by make_opcode_table.py", "source": "VectorVM.h:%d-%d" % (first, last), "ops": rows}
     with open(OUT, "w") as f:
         json.dump(out, f, indent=0)
