@@ -187,6 +187,32 @@ def test_half_and_noadvance_inputs_and_constant_outputs():
     assert t.out_type == [0, 0, 0, 2]
 
 
+def test_half_input_copied_to_a_float_output():
+    """A half input that an output writes as float becomes outputdata_float_from_half (VectorVMOptimizer.cpp:1280-1398).  The
+    reference's runtime handler for that opcode is an empty stub (VectorVMRuntime.cpp:573-577); here the instruction converts."""
+    o = OriginalScript()
+    h = o.input(0, HALF, 0, o.temp())
+    x = o.input(0, FLOAT, 0, o.temp())
+    idx = o.temp(); o.acquireindex(x, idx, 0)
+    a1 = o.temp(); o.op("add", h, x, a1)
+    o.output(FLOAT, 0, idx, h, 0)                     # half copied to a float output
+    o.output(FLOAT, 0, idx, a1, 1)
+    o.output(HALF, 0, idx, h, 0)
+    n = 203
+    rng = np.random.default_rng(11)
+    hs = rng.integers(0, 0x7C00, n, dtype=np.uint32).astype(np.uint16).view(np.float16)      # finite halves, subnormals included
+    xs = np.where(rng.random(n) < 0.5, f32(-2.0), f32(2.0)).astype(f32)                      # sign bit = keep
+    a, b, t = both(o, ALL_ONES, [xs, hs], [f32, f32, np.float16], n)
+    assert_same(a, b, 2)
+    keep = xs < 0
+    assert a[1] == int(keep.sum())
+    np.testing.assert_array_equal(a[0][0][:a[1]].view(np.uint32), hs[keep].astype(f32).view(np.uint32))
+    np.testing.assert_array_equal(a[0][2][:a[1]].view(np.uint16), hs[keep].view(np.uint16))
+    names = [c[0] for c in t.code]
+    assert "outputdata_float_from_half" in names and "outputdata_half_from_half" in names and names.count("half_to_float") == 1
+    assert t.out_type == [0, 0, 2]
+
+
 def test_exec_index_merges():
     o = OriginalScript()
     x = o.input(0, INT32, 0, o.temp())

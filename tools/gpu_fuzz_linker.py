@@ -43,9 +43,10 @@ def gen(seed):
     ivals = [s.input(0, INT32, i) for i in range(ni)]
     if nna:
         fvals.append(s.input(0, FLOAT, nf, noadvance=True))
-    for i in range(nh):
+    hins = [s.input(0, HALF, i) for i in range(nh)]
+    for h in hins:
         t = s.temp()
-        s.op("half_to_float", s.input(0, HALF, i), t)
+        s.op("half_to_float", h, t)
         fvals.append(t)
     masks = []
     ext = []                                        # built-in ids in table order
@@ -175,6 +176,11 @@ def gen(seed):
             outs.append((FLOAT, r.choice(fvals) if r.random() < 0.95 else s.const(2)))
     for v in wide:
         outs.insert(r.randint(0, len(outs)), (FLOAT, v))
+    # half inputs copied straight to outputs: as float (outputdata_float_from_half) and as they are (outputdata_half_from_half)
+    straight = []
+    for h in hins:
+        if r.random() < 0.6:
+            straight.append((FLOAT if r.random() < 0.6 else HALF, h))
     # streams are ordered float, int32, half
     for typ in (FLOAT, INT32, HALF):
         idx = 0
@@ -187,6 +193,15 @@ def gen(seed):
             dts.append({FLOAT: f32, INT32: np.int32, HALF: np.float16}[typ])
         for i in range(0, len(group), 5):
             s.output_data(typ, 0, group[i:i + 5])
+        group = []
+        for t_, v in straight:
+            if t_ != typ:
+                continue
+            group.append((v, s.output(0, typ, idx)))
+            idx += 1
+            dts.append({FLOAT: f32, HALF: np.float16}[typ])
+        if group:
+            s.output_data(typ, 0, group, from_half=True)
     dts1 = []
     if seed % 4 == 1:                               # a second acquired dataset with outputs of its own
         s.acquireindex(r.choice(masks) if masks and r.random() < 0.8 else s.const(0), 1)
