@@ -292,9 +292,10 @@ VVM_API void vvm_xorwow_seed(uint64_t cycles_first, uint64_t cycles_second, uint
 VVM_API int vvm_exec_async(vvm_exec_context* ctx, const vvm_exec_options* opt);
 VVM_API int vvm_exec_finish(vvm_exec_context* ctx);
 
-/* vvm_exec_ex for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that forbid
- * hipMalloc): same arguments, same results, but the call makes no hipMalloc / hipFree / hipHostMalloc and creates no stream
- * or event.  The launch words, survivor counts and look-back words of the Exec live in an array that is part of the library's
+/* vvm_exec_ex for callers that cannot allocate (tight serving loops, harnesses that forbid hipMalloc, code that must not
+ * disturb the allocator while a HIP graph is being captured on ANOTHER stream): same arguments, same results, but the call makes
+ * no hipMalloc / hipFree / hipHostMalloc and creates no stream or event.  It is synchronous like vvm_exec_ex (it copies the
+ * survivor counts back and waits for its stream), so it cannot itself be issued on a stream that is being captured.  The launch words, survivor counts and look-back words of the Exec live in an array that is part of the library's
  * code object (5 MiB + 4.25 KiB per device, held from the library's first use on that device until the process ends) instead
  * of in buffers sized per Exec; 4 MiB of it are the words through which a script with a wide record runs in its lean form (see
  * VVM_EXEC_NO_THROUGH_KERNEL) up to 4096 tiles, i.e. 8 Mi instances: larger Execs of such a script run it whole, with the same
@@ -304,10 +305,17 @@ VVM_API int vvm_exec_finish(vvm_exec_context* ctx);
  *     40 streams and constants together, for an Exec in the lean form those of the lean program only (VVM_E_TOO_LARGE);
  *   - no update_id / acquire_id (their scratch is sized per Exec), no VVM_EXEC_NO_VGPR_WIDE before a vvm_exec_ex has used it on
  *     the state (VVM_E_UNSUPPORTED_OP).
- * Every call on a device shares that device's array: calls that overlap in time on one device (two threads, or a queued
- * vvm_exec_async of any state that also used this entry point) race; the call is synchronous, so calls from one thread never do.
+ * Every call on a device shares that device's array: concurrent calls of this entry point on one device take turns (a lock
+ * per device is held from enqueue to completion).  The array keeps the last call's contents, so vvm_state_device_counts of a
+ * state whose last Exec went through this entry point is valid only until the next such call on that device.
  * No counterpart in the reference, whose Exec mallocs its batch memory on every call (VectorVMRuntime.cpp:2268, 2302). */
 VVM_API int vvm_exec_noalloc(vvm_exec_context* ctx, const vvm_exec_options* opt);
+
+/* Test hook, no counterpart in the reference.  Every launch tags its look-back words with an epoch that counts 1 .. 2^30 - 1 and
+ * round again; the launch that follows the wrap clears the words first.  This sets the epoch the next launch will use, through
+ * the state's own launch words (scratch = 0) or through the scratch array of the state's device (scratch = 1, what
+ * vvm_exec_noalloc runs on), as if that many launches had gone before, so that a test can cross the wrap. */
+VVM_API int vvm_debug_set_launch_epoch(vvm_state* state, uint32_t epoch, int scratch);
 
 /* Many independent Execs (one state each, e.g. one per emitter) in one call: one kernel launch per kernel shape (a batch of 1024
  * Execs or more is cut into up to four slices that are filled and launched one after the other, so that filling the parameter

@@ -271,6 +271,8 @@ class HipBackend(Backend):
         L = lib
         L.vvm_exec_ex.restype = C.c_int
         L.vvm_exec_ex.argtypes = [C.POINTER(ExecContext), C.POINTER(ExecOptions)]
+        L.vvm_debug_set_launch_epoch.restype = C.c_int
+        L.vvm_debug_set_launch_epoch.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
         L.vvm_exec_noalloc.restype = C.c_int
         L.vvm_exec_noalloc.argtypes = [C.POINTER(ExecContext), C.POINTER(ExecOptions)]
         L.vvm_exec_async.restype = C.c_int

@@ -110,8 +110,26 @@ struct ParamRing {
 #define VVM_NOALLOC_SCRATCH_BYTES (VVM_NOALLOC_RIDE_OFF + 4u * (size_t)VVM_BLOCK_THREADS * VVM_NOALLOC_RIDE_TILES)
 static __device__ __align__(256) unsigned char scratch[VVM_NOALLOC_SCRATCH_BYTES];
 
+// Host-side twin of the epoch word of one set of launch words (VvmLaunchState::epoch): every launch through the set tags its
+// look-back words with the epoch and leaves the next one behind, 1 .. 2^30 - 1 and round again.  Once the count has gone round,
+// a word written 2^30 launches ago (by an Exec with more tiles than any since) could carry the live tag again, so the launch
+// that follows the wrap clears the look-back words first, on its stream.
+struct EpochMirror {
+	uint32_t next = 1;        // the epoch the next launch through the set will use
+	bool wrapped = false;     // the count has just gone round: clear the look-back words ahead of the next launch
+	void launched() { next = (next + 1u) & 0x3FFFFFFFu; if (next == 0) { next = 1; wrapped = true; } }
+	hipError_t before_launch(unsigned long long* status, size_t words, hipStream_t stream)
+	{
+		if (!wrapped) return hipSuccess;
+		wrapped = false;
+		return status && words ? hipMemsetAsync(status, 0, words * 8, stream) : hipSuccess;
+	}
+};
+
 struct DeviceInfo {
 	int num_cus = 256;
+	EpochMirror scratch_epoch[64];      // per device ordinal: of the launch words in that device's scratch array
+	std::mutex noalloc_mutex[64];       // per device ordinal: one vvm_exec_noalloc at a time (they share the scratch array)
 	bool ready[64] = {};      // per device ordinal: the kernels' LDS limit has been raised there
 	uint8_t* scratch_ptr[64] = {};      // per device ordinal: where that device's copy of `scratch` lies
 	uint32_t* xorwow_jump[64] = {};     // per device ordinal: the jump table of the reference's random generator (built on first use)
@@ -170,6 +188,7 @@ struct vvm_state {
 	VvmIns* d_code_narrow = nullptr;
 	uint8_t* d_perlin = nullptr;
 	VvmLaunchState* d_launch = nullptr;
+	EpochMirror epoch;                     // of *d_launch
 	unsigned long long* d_status = nullptr;
 	uint32_t status_capacity = 0;          // tiles
 	int32_t* d_counts = nullptr;
@@ -875,8 +894,10 @@ int enqueue_fused_passes(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_op
 	HIP_TRY(hipMemcpyAsync(dev, host, total, hipMemcpyHostToDevice, stream));
 	st->last_width = lanes;
 	if (timed) HIP_TRY(hipEventRecord(st->ev_start[st->ev_used], stream));
+	HIP_TRY(st->epoch.before_launch(st->d_status, st->status_capacity, stream));      // (fused passes always run on the state's own launch words)
 	const int lrc = vvm_launch_exec_kernel((int)lanes, (const VvmExecDesc*)dev, K, tiles, d_launch, many ? 1 : 0, spill, 1, grid_for(tiles, lanes, true, many), stream, nullptr, 0, 0u, 1);
 	if (lrc != 0) return hip_fail((hipError_t)lrc, "kernel launch (fused passes)");
+	st->epoch.launched();
 	if (timed) { HIP_TRY(hipEventRecord(st->ev_stop[st->ev_used], stream)); st->ev_used++; }
 	for (uint32_t k = 0; k < K; ++k)
 		for (size_t u = 0; u < pes[k].lp->id_uses.size(); ++u) {
@@ -1159,11 +1180,14 @@ static int exec_enqueue(vvm_exec_context* ctx, const vvm_exec_options* opt, bool
 			HIP_TRY(hipMemcpyAsync(st->ring.dev[slot], st->ring.host[slot], pe.bytes, hipMemcpyHostToDevice, stream));
 		}
 		if (timed && pass == 0) HIP_TRY(hipEventRecord(st->ev_start[st->ev_used], stream));
+		EpochMirror& epoch = no_alloc ? g_dev.scratch_epoch[st->device] : st->epoch;
+		HIP_TRY(epoch.before_launch(d_status, st->cur_status_words, stream));
 		const int lrc = vvm_launch_exec_kernel((int)pe.instances_per_lane, inline_block ? nullptr : (const VvmExecDesc*)st->ring.dev[slot], 1, pe.tiles, d_launch,
 		                                       pe.launch_many() ? 1 : 0, pe.lp->lds_spill_slots, pe.full() ? ((pe.lean && pe.instances_per_lane == 4) ? 2 : 1) : 0,
 		                                       grid_for(pe.tiles, pe.instances_per_lane, pe.full(), pe.launch_many()), stream,
 		                                       inline_block ? local_block : nullptr, inline_block ? (uint32_t)pe.bytes : 0u, 0u, 0);
 		if (lrc != 0) return hip_fail((hipError_t)lrc, "kernel launch");
+		epoch.launched();
 		if (pe.lean) {
 			for (size_t first = 0; first < st->through.size(); first += VVM_THROUGH_MAX_PAIRS) {
 				if (first != 0) {
@@ -1224,6 +1248,7 @@ VVM_API int vvm_exec_finish(vvm_exec_context* ctx)
 		if (ls->pad != 0) {
 			const bool lds_base = ls->pad == 2;
 			(void)reset_launch_state(st->cur_launch);
+			(st->cur_launch == st->d_launch ? st->epoch : g_dev.scratch_epoch[st->device]) = EpochMirror();
 			if (st->cur_status) (void)memset_and_wait(st->cur_status, 0, st->cur_status_words * 8);
 			if (lds_base) return fail(VVM_E_HIP, "the kernel's dynamic LDS does not start at address 0 (the noise tables are addressed absolutely)");
 			return fail(VVM_E_HIP, "look-back timed out inside the kernel (a tile never published its count)");
@@ -1257,9 +1282,30 @@ VVM_API int vvm_exec_async(vvm_exec_context* ctx, const vvm_exec_options* opt) {
 
 VVM_API int vvm_exec_noalloc(vvm_exec_context* ctx, const vvm_exec_options* opt)
 {
+	if (!ctx || !ctx->VVMState) return fail(VVM_E_INVALID_ARG, "null context or state");
+	const int dev = ctx->VVMState->device;
+	if (dev < 0 || dev >= 64) return fail(VVM_E_INVALID_ARG, "device ordinal out of range");
+	// every state on a device works in that device's one scratch array (launch words, counts, look-back words, ride words): the
+	// calls are synchronous, so concurrent callers simply take turns
+	std::lock_guard<std::mutex> lock(g_dev.noalloc_mutex[dev]);
 	int rc = exec_enqueue(ctx, opt, true);
 	if (rc != VVM_OK) return rc;
 	return vvm_exec_finish(ctx);
+}
+
+// Test hook: sets the epoch (1 .. 2^30 - 1) that the next launch through the state's own launch words (scratch = 0) or through the
+// scratch array of the state's device (scratch = 1) tags its look-back words with, as if that many launches had gone before.
+VVM_API int vvm_debug_set_launch_epoch(vvm_state* st, uint32_t epoch, int scratch)
+{
+	if (!st || epoch == 0 || epoch > 0x3FFFFFFFu) return fail(VVM_E_INVALID_ARG, "bad state or epoch");
+	if (st->last_stream) HIP_TRY(hipStreamSynchronize(st->last_stream));
+	VvmLaunchState* ls = scratch ? (VvmLaunchState*)g_dev.scratch_ptr[st->device] : st->d_launch;
+	if (!ls) return fail(VVM_E_INVALID_ARG, "no launch words");
+	HIP_TRY(hipMemcpy(&ls->epoch, &epoch, 4, hipMemcpyHostToDevice));
+	EpochMirror& m = scratch ? g_dev.scratch_epoch[st->device] : st->epoch;
+	m.next = epoch;
+	m.wrapped = false;
+	return VVM_OK;
 }
 
 VVM_API int vvm_exec_ex(vvm_exec_context* ctx, const vvm_exec_options* opt)
