@@ -418,6 +418,10 @@ VVM_API void vvm_set_page_size_kb(int kb);
  * instructions of the program (negative status code on failure).  narrow = 1 links for the 1-instance-per-lane kernel,
  * narrow = 2 for the light eight-wide kernel (VVM_E_UNSUPPORTED_OP when the script does not fit it). */
 VVM_API int vvm_inspect_code(const uint8_t* blob, size_t num_bytes, int narrow, uint32_t* out_words, int32_t capacity_instructions);
+/* The same program as it is uploaded: 8 dwords per instruction, the four above followed by what the eight-wide kernels' hand-written
+ * core executes from (renderer_amd/csrc/vvm_threaded.h: routine offset, operand bytes, destination byte; zeros for an instruction
+ * that takes the compiled path), and one more `done` at the end.  Returns the number of entries.  No counterpart in the reference. */
+VVM_API int vvm_inspect_device_code(const uint8_t* blob, size_t num_bytes, int narrow, uint32_t* out_words, int32_t capacity_instructions);
 
 /* ---- script compile side (host only, no device) ----
  * OptimizeVectorVMScript (VectorVMOptimizer.h:17, VectorVMOptimizer.cpp:700-3177) followed by FreezeOptimizerContext

@@ -315,6 +315,8 @@ class HipBackend(Backend):
         L.vvm_inspect_blob.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(ProgramInfo)]
         L.vvm_inspect_code.restype = C.c_int
         L.vvm_inspect_code.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_uint32), C.c_int32]
+        L.vvm_inspect_device_code.restype = C.c_int
+        L.vvm_inspect_device_code.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_uint32), C.c_int32]
         L.vvm_state_last_exec_width.restype = C.c_int32
         L.vvm_state_last_exec_width.argtypes = [C.c_void_p]
         L.vvm_xorwow_seed.restype = None
@@ -466,6 +468,16 @@ class HipBackend(Backend):
         buf = (C.c_uint32 * (4 * n))()
         self.lib.vvm_inspect_code(blob, len(blob), int(narrow), buf, n)
         return [tuple(buf[4 * i:4 * i + 4]) for i in range(n)]
+
+    def inspect_device_code(self, blob: bytes, narrow: int = 0):
+        """The program as uploaded: a list of 8-word tuples (linker words, routine offset, operand bytes a|c|d|e, operand byte b,
+        destination byte), one trailing `done` included (no device needed).  narrow = 2: the light eight-wide program."""
+        n = self.lib.vvm_inspect_device_code(blob, len(blob), int(narrow), None, 0)
+        if n < 0:
+            self._check(-n, "vvm_inspect_device_code")
+        buf = (C.c_uint32 * (8 * n))()
+        self.lib.vvm_inspect_device_code(blob, len(blob), int(narrow), buf, n)
+        return [tuple(buf[8 * i:8 * i + 8]) for i in range(n)]
 
     def info(self, state: int) -> ProgramInfo:
         pi = ProgramInfo()

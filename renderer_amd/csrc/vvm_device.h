@@ -85,6 +85,16 @@ struct VvmIns {
 };
 #define VVM_INS_W0(op, nin, nout, aux, aux2) \
 	((uint32_t)(op) | ((uint32_t)(nin) << 8) | ((uint32_t)(nout) << 11) | ((uint32_t)(aux) << 16) | ((uint32_t)(aux2) << 24))
+// The instruction as it lies in device memory, 32 bytes: the linker's four words, then what the hand-written core of the eight-wide
+// kernels executes from (vvm_threaded.h; the host fills these when it uploads a program, the other kernels skip them).
+struct VvmDevIns {
+	VvmIns   ins;
+	uint32_t routine;     // byte offset of the instruction's routine in the routine table; 0: none (not an ordinary instruction, or an op / operand kind without one)
+	uint32_t opnds;       // operand bytes a | c << 8 | d << 16 | e << 24: 8 x register index, or the lane of a uniform register
+	uint32_t opnd_b;      // operand byte b
+	uint32_t dst;         // destination byte: 8 x register index
+};
+#define VVM_INS_STRIDE 32u
 
 // Persistent-ID tables of the dataset an Exec's update_id / acquire_id works on.  Lives in device memory.
 // The reference runs an Exec chunk by chunk (VectorVMRuntime.cpp:2218-2261) and two results depend on where the chunks end:

@@ -24,6 +24,7 @@
 #include "../../include/vvm_abi.h"
 #include "vvm_device.h"
 #include "vvm_kernels.h"
+#include "vvm_threaded.h"
 #include "vvm_program.h"
 
 #include "vvm_perlin_table.inc"
@@ -149,6 +150,8 @@ int ensure_device_info()
 	HIP_TRY(hipGetDeviceProperties(&prop, dev));
 	g_dev.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 	(void)vvm_kernel_max_dynamic_lds();      // (a function attribute belongs to the device that is current)
+	// the kernels jump to the routine offsets that this file writes into the programs: both must come from the same table
+	if (vvm_kernel_threaded_layout() != VVM_T_LAYOUT) return fail(VVM_E_HIP, "vvm_kernels.o and vvm_host.o were built from different routine tables (vvm_threaded_gen.h): rebuild");
 	uint8_t* ptr = nullptr;
 	HIP_TRY(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
 	if (!ptr) return fail(VVM_E_HIP, "hipGetSymbolAddress(scratch) returned no address");
@@ -240,10 +243,48 @@ struct vvm_state {
 
 namespace {
 
+// The program as it lies in device memory (VvmDevIns): the linker's instructions, each followed by what the hand-written core of the
+// eight-wide kernels executes from (vvm_threaded.h): the routine for the instruction's op and operand kinds, and its operands as bytes.
+// An instruction gets a routine when it is an ordinary one whose op has routines, whose operands are per-lane registers of the file
+// (light program: eight registers and the two riding ones; otherwise sixteen) or uniform registers, not all of them uniform, and
+// whose destination is a register of the file.  The other kernels read the linker's four words only.
+void encode_device_program(const vvm::LinkedProgram& lp, std::vector<VvmDevIns>& out)
+{
+	const uint32_t file_regs = lp.light ? VVM_LIGHT_RIDE_REG + 2u : 16u;
+	out.clear();
+	out.reserve(lp.code.size() + 1);
+	for (const VvmIns& k : lp.code) {
+		VvmDevIns d = {k, 0, 0, 0, 0};
+		const uint32_t op = k.w0 & 0xFFu, nin = (k.w0 >> 8) & 7u;
+		if (nin >= 1 && nin <= 5 && op != VVM_OP_done) {
+			const uint32_t o[6] = {k.w1 & 0xFFFFu, k.w1 >> 16, k.w2 & 0xFFFFu, k.w2 >> 16, k.w3 & 0xFFFFu, k.w3 >> 16};
+			uint32_t byte[5] = {0, 0, 0, 0, 0}, uniform_mask = 0;
+			bool ok = VVM_OPND_CLS(o[5]) == VVM_OPC_VREG && VVM_OPND_IDX(o[5]) < file_regs;
+			for (uint32_t i = 0; i < nin && ok; ++i) {
+				const uint32_t cls = VVM_OPND_CLS(o[i]), idx = VVM_OPND_IDX(o[i]);
+				if (cls == VVM_OPC_VREG && idx < file_regs) byte[i] = idx * 8u;
+				else if (cls == VVM_OPC_UNIF && idx < VVM_MAX_UNIFORMS) { byte[i] = idx; uniform_mask |= 1u << i; }
+				else ok = false;
+			}
+			const uint32_t routine = ok ? vvm_threaded_routine(op, nin, uniform_mask) : 0u;
+			if (routine != 0) {
+				d.routine = routine;
+				d.opnds = byte[0] | byte[2] << 8 | byte[3] << 16 | byte[4] << 24;
+				d.opnd_b = byte[1];
+				d.dst = VVM_OPND_IDX(o[5]) * 8u;
+			}
+		}
+		out.push_back(d);
+	}
+	out.push_back(VvmDevIns{VvmIns{VVM_INS_W0(VVM_OP_done, VVM_NIN_SPECIAL, 0, 0, 0), 0, 0, 0}, 0, 0, 0, 0});      // (the core fetches two instructions ahead)
+}
+
 int upload_code(const vvm::LinkedProgram& lp, VvmIns** d_code)
 {
-	HIP_TRY(hipMalloc((void**)d_code, lp.code.size() * sizeof(VvmIns)));
-	HIP_TRY(hipMemcpy(*d_code, lp.code.data(), lp.code.size() * sizeof(VvmIns), hipMemcpyHostToDevice));
+	std::vector<VvmDevIns> dev;
+	encode_device_program(lp, dev);
+	HIP_TRY(hipMalloc((void**)d_code, dev.size() * sizeof(VvmDevIns)));
+	HIP_TRY(hipMemcpy(*d_code, dev.data(), dev.size() * sizeof(VvmDevIns), hipMemcpyHostToDevice));
 	return VVM_OK;
 }
 
@@ -1949,6 +1990,22 @@ VVM_API int vvm_inspect_code(const uint8_t* blob, size_t num_bytes, int narrow, 
 	const int32_t n = (int32_t)lp.code.size();
 	if (out_words && capacity_instructions > 0)
 		memcpy(out_words, lp.code.data(), sizeof(VvmIns) * (size_t)std::min(n, capacity_instructions));
+	return n;
+}
+
+VVM_API int vvm_inspect_device_code(const uint8_t* blob, size_t num_bytes, int narrow, uint32_t* out_words, int32_t capacity_instructions)
+{
+	vvm::ThawedScript s;
+	vvm::LinkedProgram lp;
+	std::string err;
+	int rc = vvm::thaw_blob(blob, num_bytes, s, err);
+	if (rc == VVM_OK) rc = (narrow == 2) ? vvm::link_program(s, false, lp, err, 0, true) : vvm::link_program(s, narrow != 0, lp, err);
+	if (rc != VVM_OK) { fail(rc, err); return -rc; }
+	std::vector<VvmDevIns> dev;
+	encode_device_program(lp, dev);
+	const int32_t n = (int32_t)dev.size();
+	if (out_words && capacity_instructions > 0)
+		memcpy(out_words, dev.data(), sizeof(VvmDevIns) * (size_t)std::min(n, capacity_instructions));
 	return n;
 }
 

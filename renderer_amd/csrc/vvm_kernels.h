@@ -31,4 +31,6 @@ int vvm_launch_through_batch_kernel(const VvmThroughArgs* device_execs, uint32_t
 int vvm_kernel_max_dynamic_lds(void);
 uint32_t vvm_kernel_resident_registers(int instances_per_lane, int many_registers);
 uint32_t vvm_kernel_lds_fixed_bytes(int instances_per_lane, int full);
+// VVM_T_LAYOUT of the routine table (vvm_threaded_gen.h) that the eight-wide kernels were built with
+uint32_t vvm_kernel_threaded_layout(void);
 }

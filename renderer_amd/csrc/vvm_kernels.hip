@@ -969,8 +969,8 @@ template <int V, bool ANY16, bool FULL, bool TWO> DEV void store_slots(const uin
 	}
 #undef VVM_SLOT
 }
-template <int V, bool FULL, bool LIGHT, bool TWO, typename VEC> DEV void store_tile(Pending& p, const Ctx& c, unsigned char* lds, uint32_t dbg,
-                                                                       VEC R0, VEC R1, VEC R2, VEC R3, VEC R4, VEC R5, VEC R6, VEC R7)
+// ride (LIGHT): the values of the tile's two riding outputs, [output][instance slot] (registers VVM_LIGHT_RIDE_REG, +1 of the file)
+template <int V, bool FULL, bool LIGHT, bool TWO> DEV void store_tile(Pending& p, const Ctx& c, unsigned char* lds, uint32_t dbg, const float (&ride)[16])
 {
 	static_assert(VVM_STAGE_SLOTS == 8, "store_slots is written for eight slots");
 	if constexpr (LIGHT) {
@@ -1004,8 +1004,8 @@ template <int V, bool FULL, bool LIGHT, bool TWO, typename VEC> DEV void store_t
 				const uint64_t ptr = entry[VVM_LIGHT_GROUP_SLOTS + h] & VVM_OUT_ADDR_MASK;
 				if (ptr) {
 					const rsrc_t rs = make_rsrc(ptr + a.off4, a.rec4);
-					const uint32_t v[8] = {fbits(R0[VVM_LIGHT_RIDE_REG + h]), fbits(R1[VVM_LIGHT_RIDE_REG + h]), fbits(R2[VVM_LIGHT_RIDE_REG + h]), fbits(R3[VVM_LIGHT_RIDE_REG + h]),
-					                       fbits(R4[VVM_LIGHT_RIDE_REG + h]), fbits(R5[VVM_LIGHT_RIDE_REG + h]), fbits(R6[VVM_LIGHT_RIDE_REG + h]), fbits(R7[VVM_LIGHT_RIDE_REG + h])};
+					const uint32_t v[8] = {fbits(ride[8 * h + 0]), fbits(ride[8 * h + 1]), fbits(ride[8 * h + 2]), fbits(ride[8 * h + 3]),
+					                       fbits(ride[8 * h + 4]), fbits(ride[8 * h + 5]), fbits(ride[8 * h + 6]), fbits(ride[8 * h + 7])};
 					if (p.total <= VVM_LIGHT_STASH_MAX) {
 						// run_tile has left the survivors' values compacted in the unused ends of the staging slots (see there): survivor
 						// r is entry r % 512 of the end of the output's slot r / 512; 128 bits per lane and round, like a staged output
@@ -1124,17 +1124,218 @@ struct KernelEnv {
 	alignas(64) uint8_t block[VVM_INLINE_PARAM_BYTES];
 };
 
+// The cases of the interpreter's opcode switches, one list per operand count (the lists are used by run_tile and by the compiled path of the
+// eight-wide kernels; they expand where LANES, A .. E, IA .., SETF / SETI / SETM, r, c, aux, aux2, inst_i, V and FULL are defined)
+#define VVM_CASES_NIN2 \
+				case VVM_OP_add: SETF(A + B); \
+				case VVM_OP_sub: SETF(A - B); \
+				case VVM_OP_mul: SETF(A * B); \
+				case VVM_OP_div: SETF(f_div(A, B)); \
+				case VVM_OP_atan2: if constexpr (FULL) SETF(ue_atan2(A, B)); \
+				case VVM_OP_fmod: if constexpr (FULL) SETF(f_fmod(A, B)); \
+				case VVM_OP_min: SETF(f_min(A, B)); \
+				case VVM_OP_max: SETF(f_max(A, B)); \
+				case VVM_OP_pow: if constexpr (FULL) SETF(f_pow(A, B)); \
+				case VVM_OP_step: SETF(f_step(B - A));                     /* RT.cpp:1939 */ \
+				case VVM_OP_cmplt: SETM(A < B); \
+				case VVM_OP_cmple: SETM(A <= B); \
+				case VVM_OP_cmpgt: SETM(A > B); \
+				case VVM_OP_cmpge: SETM(A >= B); \
+				case VVM_OP_cmpeq: SETM(A == B); \
+				case VVM_OP_cmpneq: SETM(A != B); \
+				case VVM_OP_addi: SETI(UA + UB); \
+				case VVM_OP_subi: SETI(UA - UB); \
+				case VVM_OP_muli: SETI(UA * UB); \
+				case VVM_OP_divi: SETI(i_div(IA, IB)); \
+				case VVM_OP_mini: SETI(i_min(IA, IB)); \
+				case VVM_OP_maxi: SETI(i_max(IA, IB)); \
+				case VVM_OP_cmplti: SETM(IA < IB); \
+				case VVM_OP_cmplei: SETM(IA <= IB); \
+				case VVM_OP_cmpgti: SETM(IA > IB); \
+				case VVM_OP_cmpgei: SETM(IA >= IB); \
+				case VVM_OP_cmpeqi: SETM(IA == IB); \
+				case VVM_OP_cmpneqi: SETM(IA != IB); \
+				case VVM_OP_bit_and: case VVM_OP_logic_and: SETI(UA & UB); \
+				case VVM_OP_bit_or: case VVM_OP_logic_or: SETI(UA | UB); \
+				case VVM_OP_bit_xor: case VVM_OP_logic_xor: SETI(UA ^ UB); \
+				case VVM_OP_bit_lshift: SETI(i_shl(UA, UB)); \
+				case VVM_OP_bit_rshift: SETI(i_shr(UA, UB)); \
+				case VVM_OP_sub_neg: SETF(f_neg(A - B)); \
+				case VVM_OP_div_f2i: SETI(cvtt(f_div(A, B))); \
+				case VVM_OP_i2f_div0: SETF(f_div(i2f(IA), B)); \
+				case VVM_OP_i2f_div1: SETF(f_div(B, i2f(IA))); \
+				case VVM_OP_i2f_mul: SETF(i2f(IA) * B); \
+				case VVM_OP_f2i_maxi: SETI(i_max(cvtt(A), IB)); \
+				case VVM_OP_f2i_addi: SETI((uint32_t)cvtt(A) + UB); \
+				case VVM_OP_bit_and_i2f: SETF(i2f((int32_t)(UA & UB))); \
+				case VVM_OP_neg_cmplt: SETM(f_neg(A) < B); \
+				case VVM_OP_max_f2i: SETI(cvtt(f_max(A, B))); \
+				case VVM_OP_random_add: SETF(rand01(draw_bits<FULL>(c, inst_i + slot_offset<V>(k), aux2)) * A + B); \
+				default: { _Pragma("unroll") LANES r[k] = 0.0f; } break;
+#define VVM_CASES_NIN3 \
+				case VVM_OP_mad: SETF(f_mad(A, B, C)); \
+				case VVM_OP_lerp: SETF(f_lerp(A, B, C)); \
+				case VVM_OP_clamp: SETF(f_clamp(A, B, C)); \
+				case VVM_OP_select: SETF(f_sel(A, B, C)); \
+				case VVM_OP_clampi: SETI(i_min(i_max(IA, IB), IC)); \
+				case VVM_OP_cmplt_logic_and: SETI((A < B ? ~0u : 0u) & UC); \
+				case VVM_OP_cmple_logic_and: SETI((A <= B ? ~0u : 0u) & UC); \
+				case VVM_OP_cmpgt_logic_and: SETI((A > B ? ~0u : 0u) & UC); \
+				case VVM_OP_cmpge_logic_and: SETI((A >= B ? ~0u : 0u) & UC); \
+				case VVM_OP_cmpeq_logic_and: SETI((A == B ? ~0u : 0u) & UC); \
+				case VVM_OP_cmpne_logic_and: SETI((A != B ? ~0u : 0u) & UC); \
+				case VVM_OP_cmplti_logic_and: SETI((IA < IB ? ~0u : 0u) & UC); \
+				case VVM_OP_cmplei_logic_and: SETI((IA <= IB ? ~0u : 0u) & UC); \
+				case VVM_OP_cmpgti_logic_and: SETI((IA > IB ? ~0u : 0u) & UC); \
+				case VVM_OP_cmpgei_logic_and: SETI((IA >= IB ? ~0u : 0u) & UC); \
+				case VVM_OP_cmpeqi_logic_and: SETI((IA == IB ? ~0u : 0u) & UC); \
+				case VVM_OP_cmpnei_logic_and: SETI((IA != IB ? ~0u : 0u) & UC); \
+				case VVM_OP_cmplt_logic_or: SETI((A < B ? ~0u : 0u) | UC); \
+				case VVM_OP_cmple_logic_or: SETI((A <= B ? ~0u : 0u) | UC); \
+				case VVM_OP_cmpgt_logic_or: SETI((A > B ? ~0u : 0u) | UC); \
+				case VVM_OP_cmpge_logic_or: SETI((A >= B ? ~0u : 0u) | UC); \
+				case VVM_OP_cmpeq_logic_or: SETI((A == B ? ~0u : 0u) | UC); \
+				case VVM_OP_cmpne_logic_or: SETI((A != B ? ~0u : 0u) | UC); \
+				case VVM_OP_cmplti_logic_or: SETI((IA < IB ? ~0u : 0u) | UC); \
+				case VVM_OP_cmplei_logic_or: SETI((IA <= IB ? ~0u : 0u) | UC); \
+				case VVM_OP_cmpgti_logic_or: SETI((IA > IB ? ~0u : 0u) | UC); \
+				case VVM_OP_cmpgei_logic_or: SETI((IA >= IB ? ~0u : 0u) | UC); \
+				case VVM_OP_cmpeqi_logic_or: SETI((IA == IB ? ~0u : 0u) | UC); \
+				case VVM_OP_cmpnei_logic_or: SETI((IA != IB ? ~0u : 0u) | UC); \
+				case VVM_OP_mad_sqrt: SETF(ieee_sqrt(f_mad(A, B, C)));      /* unguarded, RT.cpp:2033 */ \
+				case VVM_OP_mul_add: SETF((A * B) + C); \
+				case VVM_OP_mul_sub0: SETF((A * B) - C); \
+				case VVM_OP_mul_sub1: SETF(C - (A * B)); \
+				case VVM_OP_mul_mul: SETF((A * B) * C); \
+				case VVM_OP_mul_max: SETF(f_max(A * B, C)); \
+				case VVM_OP_add_add: SETF((A + B) + C); \
+				case VVM_OP_sub_cmplt1: SETM(C < (A - B)); \
+				case VVM_OP_sub_mul: SETF((A - B) * C); \
+				case VVM_OP_div_mul: SETF(f_div(A, B) * C); \
+				case VVM_OP_muli_addi: SETI(UA * UB + UC); \
+				case VVM_OP_addi_bit_rshift: SETI(i_shr(UA + UB, UC)); \
+				case VVM_OP_addi_muli: SETI((UA + UB) * UC); \
+				case VVM_OP_i2f_mad0: SETF(f_mad(i2f(IA), B, C)); \
+				case VVM_OP_i2f_mad1: SETF(f_mad(A, B, i2f(IC))); \
+				case VVM_OP_f2i_select1: SETI((UA & (uint32_t)cvtt(B)) | (~UA & UC)); \
+				case VVM_OP_fmod_add: if constexpr (FULL) SETF(f_fmod(A, B) + C); \
+				case VVM_OP_bit_rshift_bit_and: SETI(i_shr(UA, UB) & UC); \
+				case VVM_OP_bit_or_muli: SETI((UA | UB) * UC); \
+				case VVM_OP_bit_lshift_bit_or: SETI(i_shl(UA, UB) | UC); \
+				case VVM_OP_external_func_call: \
+					/* aux = built-in id, aux2 = which output this device instruction produces (VectorVMRuntime.cpp:1450-1464 lists the */ \
+					/* operands as inputs then outputs; the linker emits one instruction per output in use) */ \
+					if constexpr (FULL) { \
+						if (aux == VVM_EXTFN_PERLIN3) { _Pragma("unroll") LANES r[k] = perlin3(A, B, C); } \
+						else { _Pragma("unroll") LANES r[k] = curl_noise3_component(A, B, C, aux2); } \
+					} \
+					break; \
+				default: { _Pragma("unroll") LANES r[k] = 0.0f; } break;
+#define VVM_CASES_NIN1 \
+				case VVM_DOP_COPY: SETF(A); \
+				case VVM_OP_rcp: SETF(f_rcp(A)); \
+				case VVM_OP_rsq: SETF(f_rsq(A)); \
+				case VVM_OP_sqrt: SETF(f_sqrtg(A)); \
+				case VVM_OP_neg: SETF(f_neg(A)); \
+				case VVM_OP_abs: SETF(f_abs(A)); \
+				case VVM_OP_exp: if constexpr (FULL) SETF(mf_exp(A)); \
+				case VVM_OP_exp2: if constexpr (FULL) SETF(lib_exp2(A)); \
+				case VVM_OP_log: if constexpr (FULL) SETF(f_log(A)); \
+				case VVM_OP_log2: if constexpr (FULL) SETF(lib_log2(A)); \
+				case VVM_OP_sin: if constexpr (FULL) SETF(mf_sin(A)); \
+				case VVM_OP_cos: if constexpr (FULL) SETF(mf_cos(A)); \
+				case VVM_OP_tan: if constexpr (FULL) SETF(lib_tan(A)); \
+				case VVM_OP_asin: if constexpr (FULL) SETF(f_asin(A)); \
+				case VVM_OP_acos: if constexpr (FULL) SETF(f_acos(A)); \
+				case VVM_OP_atan: if constexpr (FULL) SETF(lib_atan(A)); \
+				case VVM_OP_ceil: SETF(ceilf(A)); \
+				case VVM_OP_floor: SETF(floorf(A)); \
+				case VVM_OP_frac: SETF(f_frac(A)); \
+				case VVM_OP_trunc: SETF(truncf(A)); \
+				case VVM_OP_round: SETF(rintf(A));                         /* SSE.h:2819-2822 (nearest even) */ \
+				case VVM_OP_sign: SETF(f_sign(A)); \
+				case VVM_OP_absi: SETI(i_abs(IA)); \
+				case VVM_OP_negi: SETI(0u - UA); \
+				case VVM_OP_signi: SETI(IA >= 0 ? 1 : -1); \
+				case VVM_OP_bit_not: case VVM_OP_logic_not: SETI(~UA); \
+				case VVM_OP_f2i: SETI(cvtt(A)); \
+				case VVM_OP_i2f: SETF(i2f(IA)); \
+				case VVM_OP_f2b: SETM(A > 0.0f); \
+				case VVM_OP_b2f: SETF(f_sel(A, 1.0f, 0.0f)); \
+				case VVM_OP_i2b: SETM(IA > 0); \
+				case VVM_OP_b2i: SETI(UA & 1u); \
+				case VVM_OP_sin_cos: if constexpr (FULL) { _Pragma("unroll") LANES { float sn, cs; f_sincos(A, sn, cs); r[k] = aux ? cs : sn; } } break;   /* aux: 0 sine, 1 cosine */ \
+				case VVM_OP_half_to_float: SETF(load_half(UA));             /* RT.cpp:1113-1127 */ \
+				case VVM_OP_exec_index_addi: SETI(DESC_U32(c.dp, exec_index_base) + inst_i + slot_offset<V>(k) + UA);             /* RT.cpp:925-951 */ \
+				/* aux2 = ordinal of the random op within the script */ \
+				case VVM_OP_random: SETF(rand01(draw_bits<FULL>(c, inst_i + slot_offset<V>(k), aux2)) * A); \
+				case VVM_OP_randomi: SETI(cvtt(rand01(draw_bits<FULL>(c, inst_i + slot_offset<V>(k), aux2)) * i2f(IA))); \
+				default: { _Pragma("unroll") LANES r[k] = 0.0f; } break;
+#define VVM_CASES_NIN4 \
+				/* merged ops, VectorVMRuntime.cpp:1999-2074 */ \
+				case VVM_OP_cmplt_select: SETF(f_sel(mask(A < B), C, D)); \
+				case VVM_OP_cmple_select: SETF(f_sel(mask(A <= B), C, D)); \
+				case VVM_OP_cmpeq_select: SETF(f_sel(mask(A == B), C, D)); \
+				case VVM_OP_cmplti_select: SETF(f_sel(mask(IA < IB), C, D)); \
+				case VVM_OP_cmplei_select: SETF(f_sel(mask(IA <= IB), C, D)); \
+				case VVM_OP_cmpeqi_select: SETF(f_sel(mask(IA == IB), C, D)); \
+				case VVM_OP_mad_add: SETF(f_mad(A, B, C) + D); \
+				case VVM_OP_mad_sub0: SETF(f_mad(A, B, C) - D); \
+				case VVM_OP_mad_sub1: SETF(D - f_mad(A, B, C)); \
+				case VVM_OP_mad_mul: SETF(f_mad(A, B, C) * D); \
+				case VVM_OP_mul_mad0: SETF(f_mad(A * B, C, D)); \
+				case VVM_OP_mul_mad1: SETF(f_mad(C, D, A * B)); \
+				case VVM_OP_add_mad1: SETF(f_mad(C, D, A + B)); \
+				case VVM_OP_div_mad0: SETF(f_mad(f_div(A, B), C, D)); \
+				case VVM_OP_select_mul: SETF(f_sel(A, B, C) * D); \
+				case VVM_OP_select_add: SETF(f_sel(A, B, C) + D); \
+				default: { _Pragma("unroll") LANES r[k] = 0.0f; } break;
+#define VVM_CASES_NIN0 \
+				case VVM_OP_exec_index: SETI(DESC_U32(c.dp, exec_index_base) + inst_i + slot_offset<V>(k));                       /* RT.cpp:880-900 */ \
+				case VVM_OP_exec_indexf: SETF(i2f((int32_t)(DESC_U32(c.dp, exec_index_base) + inst_i + slot_offset<V>(k))));      /* RT.cpp:902-923 */ \
+				case VVM_OP_acquire_id: if constexpr (FULL) { \
+					/* VectorVMRuntime.cpp:1404-1440.  Instance g of the Exec takes FreeIDTable[NumFreeIDs - 1 - g]: each chunk pops its */ \
+					/* IDs from the end of the free list, reversed (:1417-1421), and the chunks pop in order.  The IDs are also logged as */ \
+					/* spawned: chunk c's, in instance order, at FreeIDTable[Max - (NumSpawnedIDs + instances up to the end of chunk c)] */ \
+					/* (:1429-1432).  aux 1 is the instruction's second destination, the tag (:1435). */ \
+					const void* idp = (const void*)(DESC_PTR(c.dp, ids) + (uint64_t)aux2 * sizeof(VvmIdDesc));      /* (aux2: the dataset's descriptor) */ \
+					if (aux == 1) { \
+						const uint32_t tag_value = sload32(idp, offsetof(VvmIdDesc, acquire_tag) / 4); \
+						_Pragma("unroll") LANES r[k] = bitsf(tag_value); \
+					} else { \
+						const uint32_t table_max = sload32(idp, offsetof(VvmIdDesc, free_table_max) / 4); \
+						const rsrc_t rs_free = make_rsrc(sload64(idp, offsetof(VvmIdDesc, free_table) / 8), 4u * table_max); \
+						const uint32_t num_free = sload32(idp, offsetof(VvmIdDesc, num_free_start) / 4), num_spawned = sload32(idp, offsetof(VvmIdDesc, num_spawned_start) / 4); \
+						const uint32_t chunk = sload32(idp, offsetof(VvmIdDesc, chunk_instances) / 4); \
+						_Pragma("unroll") LANES { \
+							const uint32_t g = inst_i + slot_offset<V>(k); \
+							const uint32_t ok = (uint32_t)(g < c.num_instances) & (uint32_t)(g < num_free); \
+							const uint32_t id = __builtin_amdgcn_raw_buffer_load_b32(rs_free, (int)(ok ? (num_free - 1u - g) * 4u : VVM_RSRC_NOWHERE), 0, 0); \
+							const uint32_t ci = g / chunk; \
+							const uint32_t chunk_end = min(c.num_instances, (ci + 1u) * chunk); \
+							uint32_t pos = table_max - (num_spawned + chunk_end) + (g - ci * chunk); \
+							asm volatile("" : "+v"(pos));      /* computed for every lane, then selected: otherwise the division ends up behind a per-lane branch */ \
+							__builtin_amdgcn_raw_buffer_store_b32(id, rs_free, (int)(ok ? pos * 4u : VVM_RSRC_NOWHERE), 0, 0); \
+							r[k] = bitsf(id); \
+						} \
+					} \
+				} break; \
+				default: { _Pragma("unroll") LANES r[k] = 0.0f; } break;
+#define VVM_CASES_NIN5 \
+				case VVM_OP_mad_mad0: SETF(f_mad(D, E, f_mad(A, B, C))); \
+				case VVM_OP_mad_mad1: SETF(f_mad(f_mad(A, B, C), D, E)); \
+				default: { _Pragma("unroll") LANES r[k] = 0.0f; } break;
+
 // ------------------------------------------------------------------------------------------------------
 template <int V, bool SPILL, bool FULL, bool RIDE = false>
 DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c, unsigned char* lds, uint32_t tile_local, uint32_t tag, VvmLaunchState* ls, uint32_t dbg, Pending& pend,
-                  uint32_t& resolves, const u64 (&pre)[VVM_LB_WORDS_PER_LANE], bool have_pre,
-                  RVEC& K0, RVEC& K1, RVEC& K2, RVEC& K3, RVEC& K4, RVEC& K5, RVEC& K6, RVEC& K7)
+                  uint32_t& resolves, const u64 (&pre)[VVM_LB_WORDS_PER_LANE], bool have_pre)
 {
-	// The register file starts every tile as zeros, except in the light kernel: there it is carried from tile to tile (K0..K7),
-	// because the previous tile's riding outputs are still in registers VVM_LIGHT_RIDE_REG, +1 (the loads below replace registers 0..7).
-	RVEC R0 = 0.0f, R1 = 0.0f, R2 = 0.0f, R3 = 0.0f, R4 = 0.0f, R5 = 0.0f, R6 = 0.0f, R7 = 0.0f;
-	if constexpr (IS_LIGHT(V, SPILL)) { R0 = K0; R1 = K1; R2 = K2; R3 = K3; R4 = K4; R5 = K5; R6 = K6; R7 = K7; }
+	// (four instances per lane or one; the eight-wide kernels have a tile program of their own, vvm_eight_wide.h)
+	static_assert(V != 8, "eight instances per lane: run_tile8");
+	RVEC R0 = 0.0f, R1 = 0.0f, R2 = 0.0f, R3 = 0.0f, R4 = 0.0f, R5 = 0.0f, R6 = 0.0f, R7 = 0.0f;      // the register file starts every tile as zeros
 	uint32_t* lds_ctrl = (uint32_t*)lds;
+	const float no_ride[16] = {};      // (store_tile's riding outputs exist in the light eight-wide kernel only)
 	// acquireindex state of the tile: all wave-uniform except keep and rank
 	uint32_t t_keep = 0, t_rank = 0, t_rank_b = 0;      // (t_rank_b: the second half of an eight-instance tile)
 	uint32_t t_total = 0, t_base = 0;
@@ -1177,30 +1378,11 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 	} while (0)
 	const void* load_ptrs = (const void*)DESC_TABLE(c, load_ptrs);
 	uint32_t pc0 = 0;
-	if constexpr (IS_LIGHT(V, SPILL)) {
-		// The light kernel's program starts with exactly one load instruction, for up to eight 32-bit streams into registers 0..7
-		// (the linker sees to it): every stream goes straight to its register, a fixed element of the register vectors, with no
-		// staging copy and no index mode.  The slots past the count read through an empty descriptor (zeros, no memory access).
-		const uint32_t w0 = sload32(prog, 0);
-		const uint32_t cnt = (w0 >> 16) & 0xFFu;
-		uint64_t ptr[8];
-		sload64x8(load_ptrs, sload32(prog, 1), ptr);
-#pragma unroll
-		for (int j = 0; j < 8; ++j) {
-			const bool used = (uint32_t)j < cnt && !(dbg & 2u);
-			const rsrc_t rs = make_rsrc(ptr[j] + 4ull * c.tile_first, used ? 4u * c.valid : 0u);
-			const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(c.tid * 16u), 0, AUX_STREAM_LOAD);
-			const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(VVM_HALF_TILE * 4u + c.tid * 16u), 0, AUX_STREAM_LOAD);
-			R0[j] = bitsf(lo.x); R1[j] = bitsf(lo.y); R2[j] = bitsf(lo.z); R3[j] = bitsf(lo.w);
-			R4[j] = bitsf(hi.x); R5[j] = bitsf(hi.y); R6[j] = bitsf(hi.z); R7[j] = bitsf(hi.w);
-		}
-		pc0 = 1;
-	} else
 	for (;; ++pc0) {
-		const uint32_t w0 = sload32(prog, pc0 * 4 + 0);
+		const uint32_t w0 = sload32(prog, pc0 * (VVM_INS_STRIDE / 4u) + 0);
 		const uint32_t lop = w0 & 0xFFu;
 		if (lop != VVM_DOP_LOADN && lop != VVM_DOP_LOADN16) break;
-		const uint32_t w1 = sload32(prog, pc0 * 4 + 1);
+		const uint32_t w1 = sload32(prog, pc0 * (VVM_INS_STRIDE / 4u) + 1);
 		float st[8][V];
 		VVM_ISSUE_LOADS(w0, w1, st);
 		VVM_WRITE_LOADS(w0, st);
@@ -1218,15 +1400,15 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 	// whole register file.
 	const u64 tl1 = (dbg & 128u) ? __builtin_amdgcn_s_memtime() : 0;
 	VvmIns nxt;
-	uint32_t pc = pc0 * (uint32_t)sizeof(VvmIns);       // byte offset of the next instruction to fetch
+	uint32_t pc = pc0 * VVM_INS_STRIDE;       // byte offset of the next instruction to fetch (the linker's four words of each VvmDevIns)
 	sload32x4_at(prog, pc, nxt.w0, nxt.w1, nxt.w2, nxt.w3);
-	pc += (uint32_t)sizeof(VvmIns);
+	pc += VVM_INS_STRIDE;
 	for (;;) {
 		uint32_t op, aux, aux2, o0, o1, o2, o3, o4, o5;
 		for (;;) {
 			const VvmIns ins = nxt;
 			sload32x4_at(prog, pc, nxt.w0, nxt.w1, nxt.w2, nxt.w3);
-			pc += (uint32_t)sizeof(VvmIns);
+			pc += VVM_INS_STRIDE;
 			const uint32_t w0 = ins.w0;
 			op = w0 & 0xFFu; aux = (w0 >> 16) & 0xFFu; aux2 = w0 >> 24;
 			const uint32_t nin = (w0 >> 8) & 7u;
@@ -1263,51 +1445,7 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 				fetch<V, SPILL>(RARGS, uni, c, o1, b);
 				HOTF(VVM_OP_mul, A * B) HOTF(VVM_OP_add, A + B) HOTF(VVM_OP_sub, A - B) HOTM(VVM_OP_cmplt, A < B)
 				switch (op) {
-				case VVM_OP_add: SETF(A + B);
-				case VVM_OP_sub: SETF(A - B);
-				case VVM_OP_mul: SETF(A * B);
-				case VVM_OP_div: SETF(f_div(A, B));
-				case VVM_OP_atan2: if constexpr (FULL) SETF(ue_atan2(A, B));
-				case VVM_OP_fmod: if constexpr (FULL) SETF(f_fmod(A, B));
-				case VVM_OP_min: SETF(f_min(A, B));
-				case VVM_OP_max: SETF(f_max(A, B));
-				case VVM_OP_pow: if constexpr (FULL) SETF(f_pow(A, B));
-				case VVM_OP_step: SETF(f_step(B - A));                     // RT.cpp:1939
-				case VVM_OP_cmplt: SETM(A < B);
-				case VVM_OP_cmple: SETM(A <= B);
-				case VVM_OP_cmpgt: SETM(A > B);
-				case VVM_OP_cmpge: SETM(A >= B);
-				case VVM_OP_cmpeq: SETM(A == B);
-				case VVM_OP_cmpneq: SETM(A != B);
-				case VVM_OP_addi: SETI(UA + UB);
-				case VVM_OP_subi: SETI(UA - UB);
-				case VVM_OP_muli: SETI(UA * UB);
-				case VVM_OP_divi: SETI(i_div(IA, IB));
-				case VVM_OP_mini: SETI(i_min(IA, IB));
-				case VVM_OP_maxi: SETI(i_max(IA, IB));
-				case VVM_OP_cmplti: SETM(IA < IB);
-				case VVM_OP_cmplei: SETM(IA <= IB);
-				case VVM_OP_cmpgti: SETM(IA > IB);
-				case VVM_OP_cmpgei: SETM(IA >= IB);
-				case VVM_OP_cmpeqi: SETM(IA == IB);
-				case VVM_OP_cmpneqi: SETM(IA != IB);
-				case VVM_OP_bit_and: case VVM_OP_logic_and: SETI(UA & UB);
-				case VVM_OP_bit_or: case VVM_OP_logic_or: SETI(UA | UB);
-				case VVM_OP_bit_xor: case VVM_OP_logic_xor: SETI(UA ^ UB);
-				case VVM_OP_bit_lshift: SETI(i_shl(UA, UB));
-				case VVM_OP_bit_rshift: SETI(i_shr(UA, UB));
-				case VVM_OP_sub_neg: SETF(f_neg(A - B));
-				case VVM_OP_div_f2i: SETI(cvtt(f_div(A, B)));
-				case VVM_OP_i2f_div0: SETF(f_div(i2f(IA), B));
-				case VVM_OP_i2f_div1: SETF(f_div(B, i2f(IA)));
-				case VVM_OP_i2f_mul: SETF(i2f(IA) * B);
-				case VVM_OP_f2i_maxi: SETI(i_max(cvtt(A), IB));
-				case VVM_OP_f2i_addi: SETI((uint32_t)cvtt(A) + UB);
-				case VVM_OP_bit_and_i2f: SETF(i2f((int32_t)(UA & UB)));
-				case VVM_OP_neg_cmplt: SETM(f_neg(A) < B);
-				case VVM_OP_max_f2i: SETI(cvtt(f_max(A, B)));
-				case VVM_OP_random_add: SETF(rand01(draw_bits<FULL>(c, inst_i + slot_offset<V>(k), aux2)) * A + B);
-				default: { _Pragma("unroll") LANES r[k] = 0.0f; } break;
+				VVM_CASES_NIN2
 				}
 			}
 			else if (nin_is(nin, 3u)) {
@@ -1317,109 +1455,14 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 				fetch<V, SPILL>(RARGS, uni, c, o2, cc);
 				HOTF(VVM_OP_mad, f_mad(A, B, C)) HOTF(VVM_OP_select, f_sel(A, B, C)) HOTF(VVM_OP_mul_add, (A * B) + C)
 				switch (op) {
-				case VVM_OP_mad: SETF(f_mad(A, B, C));
-				case VVM_OP_lerp: SETF(f_lerp(A, B, C));
-				case VVM_OP_clamp: SETF(f_clamp(A, B, C));
-				case VVM_OP_select: SETF(f_sel(A, B, C));
-				case VVM_OP_clampi: SETI(i_min(i_max(IA, IB), IC));
-				case VVM_OP_cmplt_logic_and: SETI((A < B ? ~0u : 0u) & UC);
-				case VVM_OP_cmple_logic_and: SETI((A <= B ? ~0u : 0u) & UC);
-				case VVM_OP_cmpgt_logic_and: SETI((A > B ? ~0u : 0u) & UC);
-				case VVM_OP_cmpge_logic_and: SETI((A >= B ? ~0u : 0u) & UC);
-				case VVM_OP_cmpeq_logic_and: SETI((A == B ? ~0u : 0u) & UC);
-				case VVM_OP_cmpne_logic_and: SETI((A != B ? ~0u : 0u) & UC);
-				case VVM_OP_cmplti_logic_and: SETI((IA < IB ? ~0u : 0u) & UC);
-				case VVM_OP_cmplei_logic_and: SETI((IA <= IB ? ~0u : 0u) & UC);
-				case VVM_OP_cmpgti_logic_and: SETI((IA > IB ? ~0u : 0u) & UC);
-				case VVM_OP_cmpgei_logic_and: SETI((IA >= IB ? ~0u : 0u) & UC);
-				case VVM_OP_cmpeqi_logic_and: SETI((IA == IB ? ~0u : 0u) & UC);
-				case VVM_OP_cmpnei_logic_and: SETI((IA != IB ? ~0u : 0u) & UC);
-				case VVM_OP_cmplt_logic_or: SETI((A < B ? ~0u : 0u) | UC);
-				case VVM_OP_cmple_logic_or: SETI((A <= B ? ~0u : 0u) | UC);
-				case VVM_OP_cmpgt_logic_or: SETI((A > B ? ~0u : 0u) | UC);
-				case VVM_OP_cmpge_logic_or: SETI((A >= B ? ~0u : 0u) | UC);
-				case VVM_OP_cmpeq_logic_or: SETI((A == B ? ~0u : 0u) | UC);
-				case VVM_OP_cmpne_logic_or: SETI((A != B ? ~0u : 0u) | UC);
-				case VVM_OP_cmplti_logic_or: SETI((IA < IB ? ~0u : 0u) | UC);
-				case VVM_OP_cmplei_logic_or: SETI((IA <= IB ? ~0u : 0u) | UC);
-				case VVM_OP_cmpgti_logic_or: SETI((IA > IB ? ~0u : 0u) | UC);
-				case VVM_OP_cmpgei_logic_or: SETI((IA >= IB ? ~0u : 0u) | UC);
-				case VVM_OP_cmpeqi_logic_or: SETI((IA == IB ? ~0u : 0u) | UC);
-				case VVM_OP_cmpnei_logic_or: SETI((IA != IB ? ~0u : 0u) | UC);
-				case VVM_OP_mad_sqrt: SETF(ieee_sqrt(f_mad(A, B, C)));      // unguarded, RT.cpp:2033
-				case VVM_OP_mul_add: SETF((A * B) + C);
-				case VVM_OP_mul_sub0: SETF((A * B) - C);
-				case VVM_OP_mul_sub1: SETF(C - (A * B));
-				case VVM_OP_mul_mul: SETF((A * B) * C);
-				case VVM_OP_mul_max: SETF(f_max(A * B, C));
-				case VVM_OP_add_add: SETF((A + B) + C);
-				case VVM_OP_sub_cmplt1: SETM(C < (A - B));
-				case VVM_OP_sub_mul: SETF((A - B) * C);
-				case VVM_OP_div_mul: SETF(f_div(A, B) * C);
-				case VVM_OP_muli_addi: SETI(UA * UB + UC);
-				case VVM_OP_addi_bit_rshift: SETI(i_shr(UA + UB, UC));
-				case VVM_OP_addi_muli: SETI((UA + UB) * UC);
-				case VVM_OP_i2f_mad0: SETF(f_mad(i2f(IA), B, C));
-				case VVM_OP_i2f_mad1: SETF(f_mad(A, B, i2f(IC)));
-				case VVM_OP_f2i_select1: SETI((UA & (uint32_t)cvtt(B)) | (~UA & UC));
-				case VVM_OP_fmod_add: if constexpr (FULL) SETF(f_fmod(A, B) + C);
-				case VVM_OP_bit_rshift_bit_and: SETI(i_shr(UA, UB) & UC);
-				case VVM_OP_bit_or_muli: SETI((UA | UB) * UC);
-				case VVM_OP_bit_lshift_bit_or: SETI(i_shl(UA, UB) | UC);
-				case VVM_OP_external_func_call:
-					// aux = built-in id, aux2 = which output this device instruction produces (VectorVMRuntime.cpp:1450-1464 lists the
-					// operands as inputs then outputs; the linker emits one instruction per output in use)
-					if constexpr (FULL) {
-						if (aux == VVM_EXTFN_PERLIN3) { _Pragma("unroll") LANES r[k] = perlin3(A, B, C); }
-						else { _Pragma("unroll") LANES r[k] = curl_noise3_component(A, B, C, aux2); }
-					}
-					break;
-				default: { _Pragma("unroll") LANES r[k] = 0.0f; } break;
+				VVM_CASES_NIN3
 				}
 			}
 			else if (nin_is(nin, 1u)) {
 				float a[V];
 				fetch<V, SPILL>(RARGS, uni, c, o0, a);
 				switch (op) {
-				case VVM_DOP_COPY: SETF(A);
-				case VVM_OP_rcp: SETF(f_rcp(A));
-				case VVM_OP_rsq: SETF(f_rsq(A));
-				case VVM_OP_sqrt: SETF(f_sqrtg(A));
-				case VVM_OP_neg: SETF(f_neg(A));
-				case VVM_OP_abs: SETF(f_abs(A));
-				case VVM_OP_exp: if constexpr (FULL) SETF(mf_exp(A));
-				case VVM_OP_exp2: if constexpr (FULL) SETF(lib_exp2(A));
-				case VVM_OP_log: if constexpr (FULL) SETF(f_log(A));
-				case VVM_OP_log2: if constexpr (FULL) SETF(lib_log2(A));
-				case VVM_OP_sin: if constexpr (FULL) SETF(mf_sin(A));
-				case VVM_OP_cos: if constexpr (FULL) SETF(mf_cos(A));
-				case VVM_OP_tan: if constexpr (FULL) SETF(lib_tan(A));
-				case VVM_OP_asin: if constexpr (FULL) SETF(f_asin(A));
-				case VVM_OP_acos: if constexpr (FULL) SETF(f_acos(A));
-				case VVM_OP_atan: if constexpr (FULL) SETF(lib_atan(A));
-				case VVM_OP_ceil: SETF(ceilf(A));
-				case VVM_OP_floor: SETF(floorf(A));
-				case VVM_OP_frac: SETF(f_frac(A));
-				case VVM_OP_trunc: SETF(truncf(A));
-				case VVM_OP_round: SETF(rintf(A));                         // SSE.h:2819-2822 (nearest even)
-				case VVM_OP_sign: SETF(f_sign(A));
-				case VVM_OP_absi: SETI(i_abs(IA));
-				case VVM_OP_negi: SETI(0u - UA);
-				case VVM_OP_signi: SETI(IA >= 0 ? 1 : -1);
-				case VVM_OP_bit_not: case VVM_OP_logic_not: SETI(~UA);
-				case VVM_OP_f2i: SETI(cvtt(A));
-				case VVM_OP_i2f: SETF(i2f(IA));
-				case VVM_OP_f2b: SETM(A > 0.0f);
-				case VVM_OP_b2f: SETF(f_sel(A, 1.0f, 0.0f));
-				case VVM_OP_i2b: SETM(IA > 0);
-				case VVM_OP_b2i: SETI(UA & 1u);
-				case VVM_OP_sin_cos: if constexpr (FULL) { _Pragma("unroll") LANES { float sn, cs; f_sincos(A, sn, cs); r[k] = aux ? cs : sn; } } break;   // aux: 0 sine, 1 cosine
-				case VVM_OP_half_to_float: SETF(load_half(UA));             // RT.cpp:1113-1127
-				case VVM_OP_exec_index_addi: SETI(DESC_U32(c.dp, exec_index_base) + inst_i + slot_offset<V>(k) + UA);             // RT.cpp:925-951
-				// aux2 = ordinal of the random op within the script
-				case VVM_OP_random: SETF(rand01(draw_bits<FULL>(c, inst_i + slot_offset<V>(k), aux2)) * A);
-				case VVM_OP_randomi: SETI(cvtt(rand01(draw_bits<FULL>(c, inst_i + slot_offset<V>(k), aux2)) * i2f(IA)));
-				default: { _Pragma("unroll") LANES r[k] = 0.0f; } break;
+				VVM_CASES_NIN1
 				}
 			}
 			else if (nin_is(nin, 4u)) {
@@ -1430,61 +1473,15 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 				fetch<V, SPILL>(RARGS, uni, c, o3, dd);
 				HOTF(VVM_OP_mad_mul, f_mad(A, B, C) * D) HOTF(VVM_OP_mad_add, f_mad(A, B, C) + D)
 				switch (op) {
-				// merged ops, VectorVMRuntime.cpp:1999-2074
-				case VVM_OP_cmplt_select: SETF(f_sel(mask(A < B), C, D));
-				case VVM_OP_cmple_select: SETF(f_sel(mask(A <= B), C, D));
-				case VVM_OP_cmpeq_select: SETF(f_sel(mask(A == B), C, D));
-				case VVM_OP_cmplti_select: SETF(f_sel(mask(IA < IB), C, D));
-				case VVM_OP_cmplei_select: SETF(f_sel(mask(IA <= IB), C, D));
-				case VVM_OP_cmpeqi_select: SETF(f_sel(mask(IA == IB), C, D));
-				case VVM_OP_mad_add: SETF(f_mad(A, B, C) + D);
-				case VVM_OP_mad_sub0: SETF(f_mad(A, B, C) - D);
-				case VVM_OP_mad_sub1: SETF(D - f_mad(A, B, C));
-				case VVM_OP_mad_mul: SETF(f_mad(A, B, C) * D);
-				case VVM_OP_mul_mad0: SETF(f_mad(A * B, C, D));
-				case VVM_OP_mul_mad1: SETF(f_mad(C, D, A * B));
-				case VVM_OP_add_mad1: SETF(f_mad(C, D, A + B));
-				case VVM_OP_div_mad0: SETF(f_mad(f_div(A, B), C, D));
-				case VVM_OP_select_mul: SETF(f_sel(A, B, C) * D);
-				case VVM_OP_select_add: SETF(f_sel(A, B, C) + D);
-				default: { _Pragma("unroll") LANES r[k] = 0.0f; } break;
+				VVM_CASES_NIN4
 				}
 			}
 			else if (nin_is(nin, 0u)) {
 				switch (op) {
-				case VVM_OP_exec_index: SETI(DESC_U32(c.dp, exec_index_base) + inst_i + slot_offset<V>(k));                       // RT.cpp:880-900
-				case VVM_OP_exec_indexf: SETF(i2f((int32_t)(DESC_U32(c.dp, exec_index_base) + inst_i + slot_offset<V>(k))));      // RT.cpp:902-923
-				case VVM_OP_acquire_id: if constexpr (FULL) {
-					// VectorVMRuntime.cpp:1404-1440.  Instance g of the Exec takes FreeIDTable[NumFreeIDs - 1 - g]: each chunk pops its
-					// IDs from the end of the free list, reversed (:1417-1421), and the chunks pop in order.  The IDs are also logged as
-					// spawned: chunk c's, in instance order, at FreeIDTable[Max - (NumSpawnedIDs + instances up to the end of chunk c)]
-					// (:1429-1432).  aux 1 is the instruction's second destination, the tag (:1435).
-					const void* idp = (const void*)(DESC_PTR(c.dp, ids) + (uint64_t)aux2 * sizeof(VvmIdDesc));      // (aux2: the dataset's descriptor)
-					if (aux == 1) {
-						const uint32_t tag_value = sload32(idp, offsetof(VvmIdDesc, acquire_tag) / 4);
-						_Pragma("unroll") LANES r[k] = bitsf(tag_value);
-					} else {
-						const uint32_t table_max = sload32(idp, offsetof(VvmIdDesc, free_table_max) / 4);
-						const rsrc_t rs_free = make_rsrc(sload64(idp, offsetof(VvmIdDesc, free_table) / 8), 4u * table_max);
-						const uint32_t num_free = sload32(idp, offsetof(VvmIdDesc, num_free_start) / 4), num_spawned = sload32(idp, offsetof(VvmIdDesc, num_spawned_start) / 4);
-						const uint32_t chunk = sload32(idp, offsetof(VvmIdDesc, chunk_instances) / 4);
-						_Pragma("unroll") LANES {
-							const uint32_t g = inst_i + slot_offset<V>(k);
-							const uint32_t ok = (uint32_t)(g < c.num_instances) & (uint32_t)(g < num_free);
-							const uint32_t id = __builtin_amdgcn_raw_buffer_load_b32(rs_free, (int)(ok ? (num_free - 1u - g) * 4u : VVM_RSRC_NOWHERE), 0, 0);
-							const uint32_t ci = g / chunk;
-							const uint32_t chunk_end = min(c.num_instances, (ci + 1u) * chunk);
-							uint32_t pos = table_max - (num_spawned + chunk_end) + (g - ci * chunk);
-							asm volatile("" : "+v"(pos));      // computed for every lane, then selected: otherwise the division ends up behind a per-lane branch
-							__builtin_amdgcn_raw_buffer_store_b32(id, rs_free, (int)(ok ? pos * 4u : VVM_RSRC_NOWHERE), 0, 0);
-							r[k] = bitsf(id);
-						}
-					}
-				} break;
-				default: { _Pragma("unroll") LANES r[k] = 0.0f; } break;
+				VVM_CASES_NIN0
 				}
 			}
-			else if (!IS_LIGHT(V, SPILL) && nin_is(nin, 5u)) {
+			else if (nin_is(nin, 5u)) {
 				float a[V], b[V], cc[V], dd[V], ee[V];
 				fetch<V, SPILL>(RARGS, uni, c, o0, a);
 				fetch<V, SPILL>(RARGS, uni, c, o1, b);
@@ -1492,9 +1489,7 @@ DEV void run_tile(const VvmIns* prog, gu64* status, bool last_tile, const Ctx& c
 				fetch<V, SPILL>(RARGS, uni, c, o3, dd);
 				fetch<V, SPILL>(RARGS, uni, c, o4, ee);
 				switch (op) {
-				case VVM_OP_mad_mad0: SETF(f_mad(D, E, f_mad(A, B, C)));
-				case VVM_OP_mad_mad1: SETF(f_mad(f_mad(A, B, C), D, E));
-				default: { _Pragma("unroll") LANES r[k] = 0.0f; } break;
+				VVM_CASES_NIN5
 				}
 			}
 			else goto leave_run;      // VVM_NIN_SPECIAL: done, or a device-only instruction (handled below)
@@ -1560,7 +1555,7 @@ leave_run:
 		// tile's look-back has been in flight since this tile was claimed.
 		if (pend.active) {
 			resolve_tile<V, TWO>(pend, c, lds_ctrl, resolves, tag, ls, dbg, pre, have_pre);
-			store_tile<V, FULL, IS_LIGHT(V, SPILL), TWO>(pend, c, lds, dbg, RARGS);
+			store_tile<V, FULL, false, TWO>(pend, c, lds, dbg, no_ride);
 			__syncthreads();      // every thread has read its staged values: the slots may be written again
 		}
 		if (op == VVM_DOP_ACQUIRE) continue;
@@ -1575,7 +1570,7 @@ leave_run:
 			cur.tile_local = tile_local; cur.status = status; cur.out_list = c.out_list; cur.ride = 0;
 			cur.unresolved1 = u_pending; cur.total1 = u_total; cur.base1 = u_base; cur.tiles = exec_tiles;
 			resolve_tile<V, TWO>(cur, c, lds_ctrl, resolves, tag, ls, dbg, pre, false);
-			store_tile<V, FULL, IS_LIGHT(V, SPILL), TWO>(cur, c, lds, dbg, RARGS);
+			store_tile<V, FULL, false, TWO>(cur, c, lds, dbg, no_ride);
 			__syncthreads();      // the slots are written again right away
 			t_base = cur.base; t_pending = false; stage_end = 0;
 			u_base = cur.base1; u_pending = false;
@@ -1655,7 +1650,7 @@ leave_run:
 	pend.unresolved = t_pending; pend.total = t_total; pend.base = t_base; pend.stage_end = stage_end; pend.last = last_tile;
 	pend.tile_local = tile_local; pend.status = status; pend.out_list = c.out_list;
 	pend.ride = t_keep | (t_rank << 8) | (t_rank_b << 20);
-	if constexpr ((V == 8 && !IS_LIGHT(V, SPILL)) || RIDE) {
+	if constexpr (RIDE) {
 		// the same word for vvm_through_kernel from the general eight-wide kernel, straight from the tile that made it (see store_tile);
 		// also from the instantiation of the four-wide kernel with the transcendental and noise functions that lean programs run on
 		// (RIDE; its t_rank_b nobody reads.  An instantiation of its own: in the kernel every such script runs on, the store cost 23 more
@@ -1666,35 +1661,10 @@ leave_run:
 			__builtin_amdgcn_raw_buffer_store_b32(t_keep | (t_rank << 8) | (t_rank_b << 20), rr, (int)(c.tid * 4u), 0, 0);
 		}
 	}
-	if constexpr (IS_LIGHT(V, SPILL)) {
-		// A tile that keeps at most three quarters of its instances leaves the last quarter of every staging slot unused (the staged
-		// outputs are compacted: entries 0 .. total-1).  The two outputs that otherwise wait in registers go there, compacted as well
-		// (512 survivors per slot end, three slot ends per output), so that store_tile writes them like the staged ones: 128 bits per lane
-		// instead of one 32-bit store per survivor at its rank.  (The barrier inside resolve_tile lies between these writes and the reads.)
-		if (stage_end != 0 && t_total <= VVM_LIGHT_STASH_MAX) {
-			const uint64_t e6 = sload64(c.out_list, VVM_LIGHT_GROUP_SLOTS), e7 = sload64(c.out_list, VVM_LIGHT_GROUP_SLOTS + 1);
-			if (((e6 | e7) & VVM_OUT_ADDR_MASK) != 0) {
-				float* const stage = (float*)(lds + LDS_STAGE_OFF(FULL)) + VVM_LIGHT_STASH_MAX;
-				float* const sink = (float*)(lds + LDS_STAGE_SINK_OFF(V, FULL, true)) + c.tid;
-#pragma unroll
-				for (uint32_t h = 0; h < 2; ++h) {
-					const float v[8] = {R0[VVM_LIGHT_RIDE_REG + h], R1[VVM_LIGHT_RIDE_REG + h], R2[VVM_LIGHT_RIDE_REG + h], R3[VVM_LIGHT_RIDE_REG + h],
-					                    R4[VVM_LIGHT_RIDE_REG + h], R5[VVM_LIGHT_RIDE_REG + h], R6[VVM_LIGHT_RIDE_REG + h], R7[VVM_LIGHT_RIDE_REG + h]};
-					uint32_t r = t_rank;
-#pragma unroll
-					for (int k = 0; k < 8; ++k) {
-						if (k == 4) r = t_rank_b;
-						const bool keep = (t_keep >> k) & 1u;
-						float* q = keep ? stage + (VVM_LIGHT_STASH_SLOTS * h + (r >> 9)) * (VVM_BLOCK_THREADS * V) + (r & 511u) : sink;
-						*q = v[k];
-						r += keep ? 1u : 0u;
-					}
-				}
-			}
-		}
-		K0 = R0; K1 = R1; K2 = R2; K3 = R3; K4 = R4; K5 = R5; K6 = R6; K7 = R7;
-	}
 }
+
+#include "vvm_threaded.h"
+#include "vvm_eight_wide.h"
 
 // DBG: the bring-up switches of KernelEnv::debug_skip are compiled in (one instantiation only); otherwise they cost nothing.
 template <int V, bool SPILL, bool FULL, bool DBG = false, bool RIDE = false>
@@ -1705,7 +1675,10 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (IS_LIGHT(V, SPILL) ? 3 : V
 	uint32_t* lds_ctrl = (uint32_t*)lds;
 	uint8_t* lds_perlin = lds + LDS_PERLIN_OFF;
 	float* lds_spill = (float*)(lds + LDS_SPILL_OFF(V, FULL, IS_LIGHT(V, SPILL)));
-	RVEC K0 = 0.0f, K1 = 0.0f, K2 = 0.0f, K3 = 0.0f, K4 = 0.0f, K5 = 0.0f, K6 = 0.0f, K7 = 0.0f;      // (light kernel: the register file between tiles)
+	// (eight instances per lane: the register file, in fixed VGPRs from here to the end of the kernel; the light kernel's riding outputs
+	// wait in it from one tile to the next)
+	File8<IS_LIGHT(V, SPILL)> file8;
+	if constexpr (V == 8) file_clear<IS_LIGHT(V, SPILL)>(file8);
 	Pending pend;
 	pend.active = false; pend.unresolved = false; pend.last = false; pend.total = 0; pend.base = 0; pend.stage_end = 0; pend.tile_local = 0;
 	pend.status = nullptr; pend.out_list = nullptr; pend.ride = 0;
@@ -1809,9 +1782,12 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (IS_LIGHT(V, SPILL) ? 3 : V
 		c.tile_first = tile_first;
 		c.valid = min(num_instances - tile_first, (uint32_t)(VVM_BLOCK_THREADS * V));
 		c.phase = FULL ? started++ : phase;      // (tiles this workgroup has started: with fused passes more than one per ticket)
-		if (!(dbgw & 1u))
-			run_tile<V, SPILL, FULL, RIDE>((const VvmIns*)DESC_PTR(dp, prog), (gu64*)DESC_PTR(dp, status), last_tile, c, lds, tile_local, tag, env.ls, dbgw, pend, resolves, pre, have_pre && first_pass,
-			                         K0, K1, K2, K3, K4, K5, K6, K7);
+		if (!(dbgw & 1u)) {
+			if constexpr (V == 8)
+				run_tile8<IS_LIGHT(V, SPILL)>((const void*)DESC_PTR(dp, prog), (gu64*)DESC_PTR(dp, status), last_tile, c, lds, tile_local, tag, env.ls, dbgw, pend, resolves, pre, have_pre && first_pass, file8);
+			else
+				run_tile<V, SPILL, FULL, RIDE>((const VvmIns*)DESC_PTR(dp, prog), (gu64*)DESC_PTR(dp, status), last_tile, c, lds, tile_local, tag, env.ls, dbgw, pend, resolves, pre, have_pre && first_pass);
+		}
 		first_pass = false;
 		} while (FULL && ++e < e_end);
 	}
@@ -1821,7 +1797,10 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (IS_LIGHT(V, SPILL) ? 3 : V
 		c.tid = tid; c.wave = wave; c.inst0 = 0; c.num_instances = 0; c.tile_first = 0; c.valid = 0; c.phase = 0;
 		const u64 none[VVM_LB_WORDS_PER_LANE] = {};
 		resolve_tile<V, HAS_TWO_CHAINS(V, SPILL, FULL)>(pend, c, lds_ctrl, resolves, tag, env.ls, dbgw, none, false);
-		store_tile<V, FULL, IS_LIGHT(V, SPILL), HAS_TWO_CHAINS(V, SPILL, FULL)>(pend, c, lds, dbgw, K0, K1, K2, K3, K4, K5, K6, K7);
+		float ride[16];
+#pragma unroll
+		for (int k = 0; k < 16; ++k) { if constexpr (IS_LIGHT(V, SPILL)) ride[k] = file8.f2[k]; else ride[k] = 0.0f; }
+		store_tile<V, FULL, IS_LIGHT(V, SPILL), HAS_TWO_CHAINS(V, SPILL, FULL)>(pend, c, lds, dbgw, ride);
 	}
 
 	// the last workgroup to leave re-arms the launch words for the next launch
@@ -2151,4 +2130,5 @@ extern "C" uint32_t vvm_kernel_resident_registers(int instances_per_lane, int ma
 	if (instances_per_lane == 1) return RegTraits<1, true>::RV;
 	return many_registers ? RegTraits<4, true>::RV : RegTraits<4, false>::RV;
 }
+extern "C" uint32_t vvm_kernel_threaded_layout(void) { return VVM_T_LAYOUT; }
 extern "C" uint32_t vvm_kernel_lds_fixed_bytes(int instances_per_lane, int full) { return instances_per_lane == 4 ? LDS_SPILL_OFF(4, full != 0, false) : LDS_SPILL_OFF(1, full != 0, false); }

@@ -38,6 +38,10 @@ def secondary_only_script():
 def main():
     import faulthandler
     faulthandler.enable()
+    trace = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "libnative_trace.so")
+    if os.path.exists(trace):      # (a crash inside a native library then prints its native call stack as well)
+        import ctypes
+        ctypes.CDLL(trace).native_trace_install()
 
     def stage(text):      # (what the parent prints when a rank dies)
         print("rank %s: %s" % (sys.argv[1], text), flush=True)

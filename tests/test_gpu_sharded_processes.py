@@ -52,7 +52,7 @@ def test_rank_processes_exchange_counts_through_vvm_exec_sharded(n, world, tmp_p
             if p.poll() is None:
                 p.kill()
     for r, p in enumerate(procs):
-        assert p.returncode == 0, "rank %d failed:\n%s" % (r, logs[r][-3000:])
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, logs[r][-8000:])
     reports = [json.load(open(f)) for f in files]
     blobs = [open(f + ".bin", "rb").read() for f in files]
 
