@@ -195,7 +195,7 @@ typedef struct vvm_exec_options {
 	uint64_t RandSeed;          /* key of the counter-based generator used by random / randomi / random_add / random_2x */
 	int32_t  ExecIndexBase;     /* added to exec_index*: global index of this shard's first instance */
 	int32_t  RandInstanceBase;  /* added to the instance index that keys the generator (shard-invariant streams) */
-	void*    Stream;            /* hipStream_t to enqueue on; NULL = the state's own stream */
+	void*    Stream;            /* hipStream_t to enqueue on; NULL = the state's stream: one of four per device that the library's states share in turn */
 	uint32_t Flags;             /* VVM_EXEC_* */
 	int32_t* DeviceCounts;      /* device memory, MaxOutputDataSet ints, or NULL: where the Exec leaves the survivor count of every
 	                             * dataset it runs acquireindex for, instead of the state's own words (vvm_state_device_counts). For

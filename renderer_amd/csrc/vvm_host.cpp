@@ -134,10 +134,26 @@ struct DeviceInfo {
 	bool ready[64] = {};      // per device ordinal: the kernels' LDS limit has been raised there
 	uint8_t* scratch_ptr[64] = {};      // per device ordinal: where that device's copy of `scratch` lies
 	uint32_t* xorwow_jump[64] = {};     // per device ordinal: the jump table of the reference's random generator (built on first use)
+	// per device ordinal: the streams that states run on when the caller names none.  A few, shared: a process that holds streams
+	// by the thousand (one per emitter's state) uses up what the device has for ALL processes, and a process that starts then fails
+	// inside the runtime while it creates its first queue (seen with 1024 states of one stream each).
+	hipStream_t state_streams[64][4] = {};
+	uint32_t next_state_stream[64] = {};
 };
 DeviceInfo g_dev;
 std::mutex g_dev_mutex;
 hipError_t reset_launch_state(VvmLaunchState* d);
+
+// The stream of a new state on the current device: the next of the device's few, made on first use and kept for the process.
+int state_stream(int dev, hipStream_t* out)
+{
+	std::lock_guard<std::mutex> lock(g_dev_mutex);
+	if (dev < 0 || dev >= 64) return fail(VVM_E_INVALID_ARG, "device ordinal out of range");
+	const uint32_t k = g_dev.next_state_stream[dev]++ & 3u;
+	if (!g_dev.state_streams[dev][k]) HIP_TRY(hipStreamCreateWithFlags(&g_dev.state_streams[dev][k], hipStreamNonBlocking));
+	*out = g_dev.state_streams[dev][k];
+	return VVM_OK;
+}
 
 int ensure_device_info()
 {
@@ -208,8 +224,7 @@ struct vvm_state {
 	                                       // back from d_counts (same layout there), [2 nc, 3 nc) MaxUsedID per dataset on its way to the
 	                                       // device, from word mirror_word() on the launch words as read back
 	ParamRing ring;
-	hipStream_t stream = nullptr;
-	bool own_stream = false;
+	hipStream_t stream = nullptr;          // one of the device's shared streams (state_stream)
 	hipStream_t last_stream = nullptr;
 	bool in_flight = false;                // an asynchronous Exec has been enqueued and not finished yet
 	uint64_t batch_stamp = 0;              // the last vvm_exec_batch call this state took part in
@@ -1040,8 +1055,7 @@ VVM_API vvm_state* vvm_alloc_state(const uint8_t* blob, size_t num_bytes)
 	const size_t host_bytes = st->mirror_word() * 4 + sizeof(VvmLaunchState);
 	if ((e = hipHostMalloc((void**)&st->h_counts, host_bytes, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc(counts)");
 	memset(st->h_counts, 0, host_bytes);
-	if ((e = hipStreamCreateWithFlags(&st->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
-	st->own_stream = true;
+	if (state_stream(st->device, &st->stream) != VVM_OK) { vvm_free_state(st); return nullptr; }
 	return st;
 }
 
@@ -1067,7 +1081,6 @@ VVM_API void vvm_free_state(vvm_state* st)
 	if (st->h_counts) (void)hipHostFree(st->h_counts);
 	for (hipEvent_t e : st->ev_start) (void)hipEventDestroy(e);
 	for (hipEvent_t e : st->ev_stop) (void)hipEventDestroy(e);
-	if (st->own_stream && st->stream) (void)hipStreamDestroy(st->stream);
 	delete st;
 }
 

@@ -40,6 +40,8 @@ def test_rank_processes_exchange_counts_through_vvm_exec_sharded(n, world, tmp_p
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
+    if os.environ.get("VVM_TEST_RANK_DEBUG"):      # (diagnostic runs: the HIP runtime's and the kernel driver interface's logging in the ranks)
+        env.update(HSAKMT_DEBUG_LEVEL="7", AMD_LOG_LEVEL="4")
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "sharded_rank_process.py"), str(r), str(world), str(port), str(n), files[r]],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     logs = []
@@ -51,6 +53,11 @@ def test_rank_processes_exchange_counts_through_vvm_exec_sharded(n, world, tmp_p
         for p in procs:
             if p.poll() is None:
                 p.kill()
+    keep = os.environ.get("VVM_TEST_RANK_LOGS")
+    if keep:
+        for r, text in enumerate(logs):
+            with open(os.path.join(keep, "rank_n%d_w%d_r%d.log" % (n, world, r)), "w") as f:
+                f.write(text)
     for r, p in enumerate(procs):
         assert p.returncode == 0, "rank %d failed:\n%s" % (r, logs[r][-8000:])
     reports = [json.load(open(f)) for f in files]
