@@ -168,12 +168,16 @@ template <bool LIGHT> DEV void exec_ordinary8(File8<LIGHT>& F, uint32_t uni, con
 // One tile of eight instances per lane: two halves of 1024 instances, lane t holding instances [4 t, 4 t + 4) of each (slots 0..3 and
 // 4..7), so that every stream access is a 128-bit access of four consecutive instances.  Same steps as run_tile.
 template <bool LIGHT>
-DEV void run_tile8(const void* prog, gu64* status, bool last_tile, const Ctx& c, unsigned char* lds, uint32_t tile_local, uint32_t tag, VvmLaunchState* ls, uint32_t dbg, Pending& pend,
+DEV void run_tile8(const void* prog_in, gu64* status, bool last_tile, const Ctx& c, unsigned char* lds, uint32_t tile_local, uint32_t tag, VvmLaunchState* ls, uint32_t dbg, Pending& pend,
                    uint32_t& resolves, const u64 (&pre)[VVM_LB_WORDS_PER_LANE], bool have_pre, File8<LIGHT>& F)
 {
 	constexpr int V = 8;
 	constexpr bool FULL = false;
 	constexpr bool TWO = !LIGHT;      // the general kernel runs two acquired datasets in one pass
+	// (the program's address as a value of unknown origin: otherwise the compiler, short of scalar registers, loads it from the Exec's
+	// descriptor again in front of every entry into the routines and waits for that load)
+	const void* prog = prog_in;
+	asm volatile("" : "+s"(prog));
 	uint32_t* lds_ctrl = (uint32_t*)lds;
 	uint32_t t_keep = 0, t_rank = 0, t_rank_b = 0;
 	uint32_t t_total = 0, t_base = 0;
@@ -236,6 +240,9 @@ DEV void run_tile8(const void* prog, gu64* status, bool last_tile, const Ctx& c,
 
 	const u64 tl1 = (dbg & 128u) ? __builtin_amdgcn_s_memtime() : 0;
 	uint32_t pc = pc0 * VVM_INS_STRIDE;
+	// The stream loads are waited for HERE, once.  Left to the compiler, the wait lands in front of the routines' entry inside the loop
+	// below (the file is their operand), where it also runs after an acquireindex, when the only vector memory operations in flight are
+	// the previous tile's output stores, issued a moment ago: the tile would stand still until those have drained.
 	for (;;) {
 		uint32_t x[4];
 		run_ordinary8<LIGHT>(F, prog, pc, uni, x);

@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--separate-passes", action="store_true", help="two_datasets: one launch per dataset instead of one launch for both")
     ap.add_argument("--batch-variants", type=int, default=64, help="bytecode variants of the batch (the first 16 all fit the light kernel)")
     ap.add_argument("--batch-flags", type=int, default=0, help="vvm_exec_options.Flags of every member of the batch (4: force eight instances per lane)")
+    ap.add_argument("--arith-ops", default="16,64", help="arith: instruction counts to run")
     args = ap.parse_args()
     import torch
     from renderer_amd import abi, scripts
@@ -99,7 +100,7 @@ def main():
         from renderer_amd import scripts as _s
         n = 64 * 1024 * 1024
         ins = _s.fountain_streams_torch(0, n, dev, pad=PAD)
-        for n_ops in (16, 64):
+        for n_ops in [int(x) for x in args.arith_ops.split(",")]:
             class W:      # (run_single wants .script and .constants)
                 pass
             w = W()
