@@ -179,7 +179,9 @@ DEV void run_tile8(const void* prog_in, gu64* status, bool last_tile, const Ctx&
 	const void* prog = prog_in;
 	asm volatile("" : "+s"(prog));
 	uint32_t* lds_ctrl = (uint32_t*)lds;
-	uint32_t t_keep = 0, t_rank = 0, t_rank_b = 0;
+	uint32_t t_keep = 0, t_rank = 0, t_rank_b = 0;      // (general kernel; the light one keeps them in LDS: light_ride_word)
+	uint32_t kw_new = 0;
+	bool first_special = true;
 	uint32_t t_total = 0, t_base = 0;
 	bool t_pending = false;
 	uint32_t u_keep = 0, u_rank = 0, u_rank_b = 0, u_total = 0, u_base = 0;
@@ -238,6 +240,19 @@ DEV void run_tile8(const void* prog_in, gu64* status, bool last_tile, const Ctx&
 		}
 	}
 
+	// Light kernel: the look-back words that wave 0 polled ahead of time (have_pre) wait in LDS while the program runs, not in eight
+	// registers per lane: the kernel has 168, 96 of them the routines', and what does not fit goes to scratch memory.  (The words were
+	// requested before the stream loads and arrive before them.  Half of them lie in the sink words, which are written only while
+	// outputs are staged: after the previous tile's and before this one's.)
+	static_assert(VVM_LB_WORDS_PER_LANE == 4, "two words per lane in the sink words, two in the kilobyte behind the keep words");
+	u64* const pre_park[4] = {(u64*)(lds + LDS_STAGE_SINK_OFF(V, FULL, true)) + (c.tid & 63u), (u64*)(lds + LDS_STAGE_SINK_OFF(V, FULL, true)) + 64u + (c.tid & 63u),
+	                          (u64*)(lds + LDS_LIGHT_PRE_OFF) + (c.tid & 63u), (u64*)(lds + LDS_LIGHT_PRE_OFF) + 64u + (c.tid & 63u)};
+	if constexpr (LIGHT) {
+		if (have_pre && c.wave == 0) {
+#pragma unroll
+			for (int j = 0; j < VVM_LB_WORDS_PER_LANE; ++j) *pre_park[j] = pre[j];
+		}
+	}
 	const u64 tl1 = (dbg & 128u) ? __builtin_amdgcn_s_memtime() : 0;
 	uint32_t pc = pc0 * VVM_INS_STRIDE;
 	// The stream loads are waited for HERE, once.  Left to the compiler, the wait lands in front of the routines' entry inside the loop
@@ -285,18 +300,33 @@ DEV void run_tile8(const void* prog_in, gu64* status, bool last_tile, const Ctx&
 			const uint32_t chain = TWO ? aux : 0u;
 			const uint3 rt = acquire_rank_and_publish<2>(kb, c, lds_ctrl, status + (size_t)chain * exec_tiles, tile_local, tag, dbg, chain);
 			if (TWO && chain) { u_keep = kb; u_rank = rt.x; u_rank_b = rt.y; u_total = SCALAR(rt.z); u_pending = true; }
+			else if constexpr (LIGHT) { kw_new = kb | (rt.x << 8) | (rt.y << 20); t_total = SCALAR(rt.z); t_pending = true; }
 			else { t_keep = kb; t_rank = rt.x; t_rank_b = rt.y; t_total = SCALAR(rt.z); t_pending = true; }
 		}
 		// The previous tile is finished here: after this tile has published its own count (every later tile's look-back waits for
 		// that word, so it goes out first), and before this tile needs the staging slots.  (A light program writes its two riding
 		// registers only after its acquireindex: the previous tile's values are still in them here.)
 		if (pend.active) {
-			resolve_tile<V, TWO>(pend, c, lds_ctrl, resolves, tag, ls, dbg, pre, have_pre);
+			u64 pre_here[VVM_LB_WORDS_PER_LANE] = {};
+#pragma unroll
+			for (int j = 0; j < VVM_LB_WORDS_PER_LANE; ++j) {
+				if constexpr (LIGHT) { if (have_pre && c.wave == 0) pre_here[j] = *pre_park[j]; }
+				else pre_here[j] = pre[j];
+			}
+			resolve_tile<V, TWO>(pend, c, lds_ctrl, resolves, tag, ls, dbg, pre_here, have_pre);
 			float ride[16];
 #pragma unroll
 			for (int k = 0; k < 16; ++k) { if constexpr (LIGHT) ride[k] = F.f2[k]; else ride[k] = 0.0f; }
 			store_tile<V, FULL, LIGHT, TWO>(pend, c, lds, dbg, ride);
 			__syncthreads();      // every thread has read its staged values: the slots may be written again
+		}
+		if constexpr (LIGHT) {
+			// The lane's acquireindex result of THIS tile (keep bits, ranks) waits in LDS from here on, not in registers that would have to
+			// survive the routines: the word of the previous tile has just been used (store_tile above), so its place is free.  A tile
+			// starts without a result (0: nothing survives) and gets one at its acquireindex.
+			if (op == VVM_DOP_ACQUIRE) *light_ride_word(lds, c.tid) = kw_new;
+			else if (first_special) *light_ride_word(lds, c.tid) = 0u;
+			first_special = false;
 		}
 		if (op == VVM_DOP_ACQUIRE) continue;
 		if (op == VVM_OP_done) break;
@@ -320,7 +350,14 @@ DEV void run_tile8(const void* prog_in, gu64* status, bool last_tile, const Ctx&
 		// that index modulo VVM_STAGE_SLOTS.  Without an acquireindex before it nothing survives (VectorVMRuntime.cpp:565, 769).
 		{
 			const bool second = TWO && aux2 != 0;
-			const uint32_t o_total = second ? u_total : t_total, o_keep = second ? u_keep : t_keep, o_rank = second ? u_rank : t_rank, o_rank_b = second ? u_rank_b : t_rank_b;
+			uint32_t o_keep, o_rank, o_rank_b;
+			if constexpr (LIGHT) {
+				const uint32_t kw = *light_ride_word(lds, c.tid);
+				o_keep = kw & 0xFFu; o_rank = (kw >> 8) & 0xFFFu; o_rank_b = kw >> 20;
+			} else {
+				o_keep = second ? u_keep : t_keep; o_rank = second ? u_rank : t_rank; o_rank_b = second ? u_rank_b : t_rank_b;
+			}
+			const uint32_t o_total = second ? u_total : t_total;
 			const bool all_alive = (o_total == VVM_BLOCK_THREADS * V);
 			const uint32_t kind = op - VVM_DOP_OUTPUT32;          // 0: 32-bit value  1: float -> half  2: low 16 bits as they are  3: half bits -> float
 			const uint32_t first_slot = o4 | (o5 << 16);
@@ -368,7 +405,7 @@ DEV void run_tile8(const void* prog_in, gu64* status, bool last_tile, const Ctx&
 	pend.unresolved1 = u_pending; pend.total1 = u_total; pend.base1 = u_base; pend.tiles = exec_tiles;
 	pend.unresolved = t_pending; pend.total = t_total; pend.base = t_base; pend.stage_end = stage_end; pend.last = last_tile;
 	pend.tile_local = tile_local; pend.status = status; pend.out_list = c.out_list;
-	pend.ride = t_keep | (t_rank << 8) | (t_rank_b << 20);
+	pend.ride = LIGHT ? 0u : (t_keep | (t_rank << 8) | (t_rank_b << 20));
 	if constexpr (!LIGHT) {
 		// the lane's acquireindex result for vvm_through_kernel, straight from the tile that made it (the light kernel keeps the word for
 		// its riding outputs and stores it in store_tile)
@@ -388,13 +425,15 @@ DEV void run_tile8(const void* prog_in, gu64* status, bool last_tile, const Ctx&
 			if (((e6 | e7) & VVM_OUT_ADDR_MASK) != 0) {
 				float* const stage = (float*)(lds + LDS_STAGE_OFF(FULL)) + VVM_LIGHT_STASH_MAX;
 				float* const sink = (float*)(lds + LDS_STAGE_SINK_OFF(V, FULL, true)) + c.tid;
+				const uint32_t kw = *light_ride_word(lds, c.tid);
+				const uint32_t s_keep = kw & 0xFFu, s_rank = (kw >> 8) & 0xFFFu, s_rank_b = kw >> 20;
 #pragma unroll
 				for (uint32_t h = 0; h < 2; ++h) {
-					uint32_t r = t_rank;
+					uint32_t r = s_rank;
 #pragma unroll
 					for (int k = 0; k < 8; ++k) {
-						if (k == 4) r = t_rank_b;
-						const bool keep = (t_keep >> k) & 1u;
+						if (k == 4) r = s_rank_b;
+						const bool keep = (s_keep >> k) & 1u;
 						float* q = keep ? stage + (VVM_LIGHT_STASH_SLOTS * h + (r >> 9)) * (VVM_BLOCK_THREADS * V) + (r & 511u) : sink;
 						*q = F.f2[h * 8 + k];
 						r += keep ? 1u : 0u;

@@ -130,7 +130,12 @@ template <typename VEC> __device__ __forceinline__ VEC vset(VEC v, uint32_t i, f
 #define LDS_SLOTS(LIGHT) ((LIGHT) ? VVM_LIGHT_STAGE_SLOTS : (uint32_t)VVM_STAGE_SLOTS)
 #define LDS_STAGE_SINK_OFF(V, FULL, LIGHT) (LDS_STAGE_OFF(FULL) + LDS_SLOTS(LIGHT) * VVM_BLOCK_THREADS * (V) * 4u)
 #define LDS_STAGE_KEEP_OFF(V, FULL, LIGHT) (LDS_STAGE_SINK_OFF(V, FULL, LIGHT) + VVM_BLOCK_THREADS * 4u)
-#define LDS_STAGE_BYTES(V, LIGHT)  (LDS_SLOTS(LIGHT) * VVM_BLOCK_THREADS * (V) * 4u + 2u * VVM_BLOCK_THREADS * 4u)
+// (LIGHT: and 1 KB more.  Wave 0 parks the look-back words it polled ahead of time there and in the sink words, which nothing uses
+// before the tile's first output, while the tile's program runs: 2 KB.  A light workgroup may use 53760 bytes: LDS is handed out in
+// units of 1280 bytes, and three workgroups share a CU's 160 KB.)
+#define LDS_STAGE_BYTES(V, LIGHT)  (LDS_SLOTS(LIGHT) * VVM_BLOCK_THREADS * (V) * 4u + 2u * VVM_BLOCK_THREADS * 4u + ((LIGHT) ? 1024u : 0u))
+#define LDS_LIGHT_PRE_OFF (LDS_STAGE_KEEP_OFF(8, false, true) + VVM_BLOCK_THREADS * 4u)
+static_assert(LDS_STAGE_OFF(false) + LDS_STAGE_BYTES(8, true) <= 53760u, "the light kernel's LDS no longer fits three workgroups per CU");
 #define LDS_SPILL_OFF(V, FULL, LIGHT) (LDS_STAGE_OFF(FULL) + LDS_STAGE_BYTES(V, LIGHT))
 
 DEV uint32_t fbits(float f) { return __float_as_uint(f); }
@@ -970,6 +975,10 @@ template <int V, bool ANY16, bool FULL, bool TWO> DEV void store_slots(const uin
 #undef VVM_SLOT
 }
 // ride (LIGHT): the values of the tile's two riding outputs, [output][instance slot] (registers VVM_LIGHT_RIDE_REG, +1 of the file)
+// The light kernel keeps a lane's acquireindex word (Pending::ride's layout) here between the tile that made it and the next one, which
+// stores that tile's outputs: a register held across the whole tile program is one more than the kernel has.  Written and read by
+// the same thread.
+DEV uint32_t* light_ride_word(unsigned char* lds, uint32_t tid) { return (uint32_t*)(lds + LDS_STAGE_KEEP_OFF(8, false, true)) + tid; }
 template <int V, bool FULL, bool LIGHT, bool TWO> DEV void store_tile(Pending& p, const Ctx& c, unsigned char* lds, uint32_t dbg, const float (&ride)[16])
 {
 	static_assert(VVM_STAGE_SLOTS == 8, "store_slots is written for eight slots");
@@ -979,7 +988,7 @@ template <int V, bool FULL, bool LIGHT, bool TWO> DEV void store_tile(Pending& p
 		const uint64_t ride_base = sload64(p.out_list - 3, 0);
 		if (ride_base != 0) {
 			const rsrc_t rr = make_rsrc(ride_base + (uint64_t)p.tile_local * (VVM_BLOCK_THREADS * 4u), VVM_BLOCK_THREADS * 4u);
-			__builtin_amdgcn_raw_buffer_store_b32(p.ride, rr, (int)(c.tid * 4u), 0, 0);
+			__builtin_amdgcn_raw_buffer_store_b32(*light_ride_word(lds, c.tid), rr, (int)(c.tid * 4u), 0, 0);
 		}
 	}
 	const uint32_t n_staged = STAGED_COUNT(p.stage_end);
@@ -1006,17 +1015,26 @@ template <int V, bool FULL, bool LIGHT, bool TWO> DEV void store_tile(Pending& p
 					const rsrc_t rs = make_rsrc(ptr + a.off4, a.rec4);
 					const uint32_t v[8] = {fbits(ride[8 * h + 0]), fbits(ride[8 * h + 1]), fbits(ride[8 * h + 2]), fbits(ride[8 * h + 3]),
 					                       fbits(ride[8 * h + 4]), fbits(ride[8 * h + 5]), fbits(ride[8 * h + 6]), fbits(ride[8 * h + 7])};
+					// (Addresses and offsets below are made from the thread index and the lane's acquireindex word HERE, from values the
+					// compiler cannot trace back: made where it likes, it makes them once per kernel or per tile, far ahead, and keeps them in
+					// scratch memory for want of registers, so that every store below would wait for a scratch load first.)
+					// The thread index is counted again and the acquireindex word comes from LDS (light_ride_word) for the same reason: both would
+					// otherwise be among the values that wait in scratch memory.
+					uint32_t tid_here;
+					asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n v_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(tid_here));
+					tid_here += c.wave * 64u;
+					const uint32_t ride_here = *light_ride_word(lds, tid_here);
 					if (p.total <= VVM_LIGHT_STASH_MAX) {
 						// run_tile has left the survivors' values compacted in the unused ends of the staging slots (see there): survivor
 						// r is entry r % 512 of the end of the output's slot r / 512; 128 bits per lane and round, like a staged output
 						const float* stash = (const float*)(lds + LDS_STAGE_OFF(FULL)) + (VVM_LIGHT_STASH_SLOTS * h) * (VVM_BLOCK_THREADS * V) + VVM_LIGHT_STASH_MAX;
-						const f4a x0 = *(const f4a*)(stash + (c.tid >> 7) * (VVM_BLOCK_THREADS * V) + (c.tid & 127u) * 4u);
-						const f4a x1 = *(const f4a*)(stash + 2u * (VVM_BLOCK_THREADS * V) + (c.tid & 127u) * 4u);
+						const f4a x0 = *(const f4a*)(stash + (tid_here >> 7) * (VVM_BLOCK_THREADS * V) + (tid_here & 127u) * 4u);
+						const f4a x1 = *(const f4a*)(stash + 2u * (VVM_BLOCK_THREADS * V) + (tid_here & 127u) * 4u);
 						u32x4 y0, y1;
 						y0.x = fbits(x0.x); y0.y = fbits(x0.y); y0.z = fbits(x0.z); y0.w = fbits(x0.w);
 						y1.x = fbits(x1.x); y1.y = fbits(x1.y); y1.z = fbits(x1.z); y1.w = fbits(x1.w);
-						__builtin_amdgcn_raw_buffer_store_b128(y0, rs, (int)(c.tid * 16u), 0, AUX_STREAM_STORE);
-						__builtin_amdgcn_raw_buffer_store_b128(y1, rs, (int)((1024u + c.tid * 4u) * 4u), 0, AUX_STREAM_STORE);      // (lanes 128 and up: past the descriptor's end)
+						__builtin_amdgcn_raw_buffer_store_b128(y0, rs, (int)(tid_here * 16u), 0, AUX_STREAM_STORE);
+						__builtin_amdgcn_raw_buffer_store_b128(y1, rs, (int)((1024u + tid_here * 4u) * 4u), 0, AUX_STREAM_STORE);      // (lanes 128 and up: past the descriptor's end)
 					} else if (p.total == VVM_BLOCK_THREADS * V) {
 						u32x4 lo, hi;
 						lo.x = v[0]; lo.y = v[1]; lo.z = v[2]; lo.w = v[3];
@@ -1034,8 +1052,8 @@ template <int V, bool FULL, bool LIGHT, bool TWO> DEV void store_tile(Pending& p
 						u32x4 q4[2];
 #pragma unroll
 						for (int half = 0; half < 2; ++half) {
-							const uint32_t m = (p.ride >> (4 * half)) & 15u;
-							const uint32_t r4 = (half ? (p.ride >> 20) : ((p.ride >> 8) & 0xFFFu)) * 4u;
+							const uint32_t m = (ride_here >> (4 * half)) & 15u;
+							const uint32_t r4 = (half ? (ride_here >> 20) : ((ride_here >> 8) & 0xFFFu)) * 4u;
 							const uint32_t a0 = v[4 * half], a1 = v[4 * half + 1], a2 = v[4 * half + 2], a3 = v[4 * half + 3];
 							const bool k0 = (m & 1u) != 0, k1 = (m & 2u) != 0, k2 = (m & 4u) != 0;
 							const uint32_t w0 = k0 ? a0 : k1 ? a1 : k2 ? a2 : a3;
