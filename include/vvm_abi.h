@@ -316,6 +316,10 @@ VVM_API int vvm_exec_noalloc(vvm_exec_context* ctx, const vvm_exec_options* opt)
  * the state's own launch words (scratch = 0) or through the scratch array of the state's device (scratch = 1, what
  * vvm_exec_noalloc runs on), as if that many launches had gone before, so that a test can cross the wrap. */
 VVM_API int vvm_debug_set_launch_epoch(vvm_state* state, uint32_t epoch, int scratch);
+/* Test hook: how many times vvm_exec_batch has planned a batch (sorted its Execs into launches) in this process.  It keeps the plan of
+ * its last call and plans again only when the states, sizes, table counts or options differ from that call's, or a state has been
+ * made or released since; stream addresses and constants are read on every call. */
+VVM_API uint64_t vvm_debug_batch_plans_made(void);
 
 /* Many independent Execs (one state each, e.g. one per emitter) in one call: one kernel launch per kernel shape (a batch of 1024
  * Execs or more is cut into up to four slices that are filled and launched one after the other, so that filling the parameter

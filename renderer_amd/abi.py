@@ -315,6 +315,8 @@ class HipBackend(Backend):
         L.vvm_inspect_blob.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(ProgramInfo)]
         L.vvm_inspect_code.restype = C.c_int
         L.vvm_inspect_code.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_uint32), C.c_int32]
+        L.vvm_debug_batch_plans_made.restype = C.c_uint64
+        L.vvm_debug_batch_plans_made.argtypes = []
         L.vvm_inspect_device_code.restype = C.c_int
         L.vvm_inspect_device_code.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_uint32), C.c_int32]
         L.vvm_state_last_exec_width.restype = C.c_int32

@@ -17,6 +17,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -142,6 +143,9 @@ struct DeviceInfo {
 };
 DeviceInfo g_dev;
 std::mutex g_dev_mutex;
+// counts the states made and released so far: what is remembered about a set of states (the plan of a batch) holds only while it
+// stands still, since an address may come back as another state
+std::atomic<uint64_t> g_state_generation{0};
 hipError_t reset_launch_state(VvmLaunchState* d);
 
 // The stream of a new state on the current device: the next of the device's few, made on first use and kept for the process.
@@ -1007,6 +1011,7 @@ VVM_API void vvm_set_page_size_kb(int kb) { g_page_kb = (kb > 0 && kb <= 1 << 20
 
 VVM_API vvm_state* vvm_alloc_state(const uint8_t* blob, size_t num_bytes)
 {
+	g_state_generation.fetch_add(1, std::memory_order_relaxed);
 	vvm_state* st = new vvm_state();
 	std::string err;
 	int rc = vvm::thaw_blob(blob, num_bytes, st->script, err);
@@ -1062,6 +1067,7 @@ VVM_API vvm_state* vvm_alloc_state(const uint8_t* blob, size_t num_bytes)
 VVM_API void vvm_free_state(vvm_state* st)
 {
 	if (!st) return;
+	g_state_generation.fetch_add(1, std::memory_order_relaxed);
 	if (st->last_stream) (void)hipStreamSynchronize(st->last_stream);
 	st->ring.release();
 	if (st->d_code_wide) (void)hipFree(st->d_code_wide);
@@ -1391,8 +1397,8 @@ struct BatchWorkspace {
 	// The parameter blocks of a slice are uploaded on a stream of their own, so that the copy runs beside the kernels of the slice
 	// before; the kernels' stream waits for the slice's event.  (On one stream every upload sat between two kernels.)
 	hipStream_t upload_stream = nullptr;
-	hipEvent_t uploaded[4] = {};
-	hipEvent_t finished[4] = {};      // per slice, behind its kernels and the read-back of its counts
+	hipEvent_t uploaded[8] = {};
+	hipEvent_t finished[8] = {};      // per slice, behind its kernels and the read-back of its counts
 	int device = -1;      // the workspace belongs to the device of its first batch
 
 	void release()
@@ -1407,7 +1413,7 @@ struct BatchWorkspace {
 		if (h_counts) (void)hipHostFree(h_counts);
 		if (h_launch) (void)hipHostFree(h_launch);
 		for (VvmLaunchState*& p : d_launch) { if (p) (void)hipFree(p); p = nullptr; }
-		for (int i = 0; i < 4; ++i) {
+		for (int i = 0; i < 8; ++i) {
 			if (uploaded[i]) (void)hipEventDestroy(uploaded[i]);
 			if (finished[i]) (void)hipEventDestroy(finished[i]);
 			uploaded[i] = finished[i] = nullptr;
@@ -1448,6 +1454,33 @@ struct BatchPlan {
 };
 
 int kernel_key(const PreparedExec& pe) { return (int)pe.instances_per_lane * 4 + (pe.launch_many() ? 2 : 0) + (pe.full() ? 1 : 0); }
+
+// vvm_exec_batch keeps the plan of its last call: a caller that runs the same emitters tick after tick (same states, sizes and
+// options; stream addresses and constants are read anew on every call) pays for sorting them into launches once.  What the plan was
+// made from, per Exec:
+struct BatchCallKey {
+	const vvm_state* state; int32_t num_instances, num_datasets, num_ext_fns, num_const_tables; uint32_t flags; bool xorwow;
+	bool operator==(const BatchCallKey& o) const
+	{
+		return state == o.state && num_instances == o.num_instances && num_datasets == o.num_datasets && num_ext_fns == o.num_ext_fns &&
+		       num_const_tables == o.num_const_tables && flags == o.flags && xorwow == o.xorwow;
+	}
+};
+BatchCallKey batch_call_key(const vvm_exec_context& c, const vvm_exec_options* o)
+{
+	return BatchCallKey{c.VVMState, c.NumInstances, c.DataSets.num, c.ExtFunctionTable.num, c.ConstantTableCount, o ? o->Flags : 0u,
+	                    o && o->RandXorwowState != nullptr};
+}
+struct BatchPlanCache {
+	bool valid = false;
+	uint64_t generation = 0;
+	int num_slices = 0;
+	bool have_opts = false;
+	std::vector<BatchCallKey> keys;
+	BatchPlan plan;
+	uint64_t plans_made = 0;      // (test hook: vvm_debug_batch_plans_made)
+};
+BatchPlanCache g_batch_cache;      // (guarded by g_batch.mutex)
 
 // Tiles, ticket numbers, look-back words and buffer offsets of every Exec, from the groups' member lists and the prepared sizes.
 void batch_layout(BatchPlan& plan, const vvm_exec_context* ctxs)
@@ -1527,7 +1560,14 @@ int batch_plan(BatchWorkspace& ws, vvm_exec_context* ctxs, int n, const vvm_exec
 	plan.slices.assign((size_t)num_slices, BatchSlice());
 	// The first slice is the smallest (the GPU idles while it is filled), and each later one is as large as all before it together:
 	// filling an Exec's block takes the host about half the time the GPU needs for the Exec, so the fill stays ahead.
-	auto slice_end = [&](int sl) { return sl + 1 == num_slices ? n : (int)(((int64_t)n << sl) >> (num_slices - 1)); };      // n/8, n/4, n/2, n
+	// (five slices: n/16, n/4, n/2, 3n/4, n.  The host fills an Exec's block in about 0.11 us and needs about 30 us to upload and launch
+	// a slice; the GPU takes about 0.18 us per 16 Ki-instance Exec.  The small first slice gets the GPU going early; the equal later ones
+	// keep the wait for the last slice's fill short, which with n/8, n/4, n/2, n was 0.15 ms of idle GPU.)
+	auto slice_end = [&](int sl) {
+		if (sl + 1 == num_slices) return n;
+		if (num_slices == 5) return (int)((int64_t)n * (sl == 0 ? 1 : 4 * sl) / 16);
+		return (int)(((int64_t)n << sl) >> (num_slices - 1));      // n/8, n/4, n/2, n
+	};
 	for (int sl = 0; sl < num_slices; ++sl) {
 		BatchSlice& slice = plan.slices[(size_t)sl];
 		slice.first = sl == 0 ? 0 : slice_end(sl - 1);
@@ -1557,6 +1597,31 @@ int batch_plan(BatchWorkspace& ws, vvm_exec_context* ctxs, int n, const vvm_exec
 	return VVM_OK;
 }
 
+// Whether the remembered plan is the plan of this call; if so, what prepare() leaves in every context is written again (the
+// reference's chunking figures, which follow vm.PageSizeInKB) and its checks of the context's views are repeated.
+bool batch_plan_still_holds(BatchPlanCache& cache, vvm_exec_context* ctxs, int n, const vvm_exec_options* opts, int num_slices)
+{
+	if (!cache.valid || cache.plan.n != n || cache.num_slices != num_slices || cache.have_opts != (opts != nullptr) ||
+	    cache.generation != g_state_generation.load(std::memory_order_relaxed))
+		return false;
+	for (int i = 0; i < n; ++i) {
+		const vvm_exec_context& c = ctxs[i];
+		if (!(cache.keys[(size_t)i] == batch_call_key(c, opts ? &opts[i] : nullptr))) return false;
+		if ((c.DataSets.num > 0 && !c.DataSets.data) || (c.ConstantTableCount > 0 && (!c.ConstantTableNumBytes || !c.ConstantTableData))) return false;
+		const vvm::ThawedScript& s = c.VVMState->script;
+		if (s.num_ext_fns > 0 && !c.ExtFunctionTable.data) return false;
+		for (uint32_t f = 0; f < s.num_ext_fns; ++f) {
+			const vvm_ext_function* fn = c.ExtFunctionTable.data[f];
+			if (!fn || fn->builtin_id != ((s.ext_num_outputs[f] == 1) ? VVM_EXTFN_PERLIN3 : VVM_EXTFN_CURL_NOISE3)) return false;
+		}
+	}
+	for (int i = 0; i < n; ++i) {
+		PreparedExec& pe = cache.plan.pes[(size_t)i];
+		reference_chunking(ctxs[i].VVMState->script, &ctxs[i], pe.chunk_instances, pe.num_chunks);
+	}
+	return true;
+}
+
 // Streams, events and buffers large enough for the plan (buffers only ever grow).
 int batch_ensure_buffers(BatchWorkspace& ws, const BatchPlan& plan)
 {
@@ -1578,7 +1643,7 @@ int batch_ensure_buffers(BatchWorkspace& ws, const BatchPlan& plan)
 		ws.ride_capacity = plan.total_tiles + plan.total_tiles / 4 + 1024;
 		HIP_TRY(hipMalloc((void**)&ws.d_ride, (size_t)ws.ride_capacity * VVM_BLOCK_THREADS * 4u));
 	}
-	const size_t launch_slots = 4 * 8;      // (slices x groups)
+	const size_t launch_slots = 8 * 8;      // (slices x groups)
 	if (!ws.h_launch) HIP_TRY(hipHostMalloc((void**)&ws.h_launch, launch_slots * sizeof(VvmLaunchState), hipHostMallocDefault));
 	for (const BatchSlice& slice : plan.slices)
 		for (size_t g = 0; g < slice.groups.size(); ++g)
@@ -1761,10 +1826,23 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 	const auto t_begin = now();
 	// A slice is filled, uploaded and launched while the kernels of the slices before it run, so that most of the host's work on
 	// the parameter blocks is hidden behind the GPU.
-	const int num_slices = n >= 4096 ? 4 : n >= 1024 ? 3 : 1;
-	BatchPlan plan;
-	rc = batch_plan(ws, ctxs, n, opts, num_slices, plan);
-	if (rc != VVM_OK) return rc;
+	const int num_slices = n >= 4096 ? 5 : n >= 1024 ? 3 : 1;
+	BatchPlanCache& cache = g_batch_cache;
+	BatchPlan& plan = cache.plan;
+	if (!batch_plan_still_holds(cache, ctxs, n, opts, num_slices)) {
+		cache.valid = false;
+		++cache.plans_made;
+		rc = batch_plan(ws, ctxs, n, opts, num_slices, plan);
+		if (rc != VVM_OK) return rc;
+		cache.generation = g_state_generation.load(std::memory_order_relaxed);
+		cache.num_slices = num_slices;
+		cache.have_opts = opts != nullptr;
+		cache.keys.resize((size_t)n);
+		for (int i = 0; i < n; ++i) cache.keys[(size_t)i] = batch_call_key(ctxs[i], opts ? &opts[i] : nullptr);
+		// (a batch with Execs that take launches of their own is planned every time: what those need checked -- the ID tables'
+		// counters -- changes from call to call)
+		cache.valid = std::find(plan.single.begin(), plan.single.end(), (uint8_t)1) == plan.single.end();
+	}
 	rc = batch_settle_states(plan, ctxs);
 	if (rc != VVM_OK) return rc;
 	const auto t_prepared = now();
@@ -1794,6 +1872,12 @@ VVM_API int vvm_exec_batch(vvm_exec_context* ctxs, int32_t n, const vvm_exec_opt
 		fprintf(stderr, "vvm batch host phases (us): prepare %.0f  fill %.0f (of %.0f in %d slices, launches in between)  wait %.0f, write-back %.0f  (%d Execs, %zu parameter bytes)\n",
 		        us(t_begin, t_prepared), fill_us, us(t_prepared, t_enqueued), num_slices, wait_us, us(t_enqueued, now()) - wait_us, n, plan.total_bytes);
 	return rc;
+}
+
+VVM_API uint64_t vvm_debug_batch_plans_made(void)
+{
+	std::lock_guard<std::mutex> lock(g_batch.mutex);
+	return g_batch_cache.plans_made;
 }
 
 // --- a batch that is kept from tick to tick ------------------------------------------------------------
