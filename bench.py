@@ -121,7 +121,7 @@ def recorded_traffic(workload, particles):
     """HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE).  Counters cannot be read from inside this process;
     tools/pmc_traffic.sh collects them with rocprofv3 in separate passes of this same command and profiles/ holds the result.
     Returned only when it was taken on this workload and size."""
-    for name in ("r02_traffic.json", "r02_traffic_kill_half.json", "r01_traffic.json", "r01_traffic_kill_half.json"):
+    for name in ("r03_traffic.json", "r03_traffic_kill_half.json", "r02_traffic.json", "r02_traffic_kill_half.json", "r01_traffic.json", "r01_traffic_kill_half.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 t = json.load(f)
