@@ -15,6 +15,7 @@
 #include "../../include/vvm_abi.h"
 
 #include <algorithm>
+#include <functional>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -864,97 +865,111 @@ void Optimizer::build_io_tables()
 	}
 }
 
-// Step 16 (:2776-2853): temp registers by a linear scan from the last instruction to the first: a write frees its register, a
-// read of a value that has none takes the lowest free one.  The most registers in use at once is the script's temp count.
+// Step 16 (:2776-2853): temp registers.  Every value lives from the instruction that writes it to the last one that reads it; walking
+// the program from its end, a value's register is claimed at its last reader and handed back at its writer, and a claim always takes
+// the lowest register that is free (the numbering the reference's output has, so it is not a free choice).  The most registers
+// claimed at once is the script's temp count.
+namespace {
+// Registers 0, 1, 2, ... with "lowest free one first": those handed back wait in a min-heap, the ones never claimed lie above `fresh`.
+class LowestFreeRegister {
+public:
+	uint16_t claim()
+	{
+		uint16_t r;
+		if (!returned.empty() && returned.front() < fresh) { std::pop_heap(returned.begin(), returned.end(), std::greater<uint16_t>()); r = returned.back(); returned.pop_back(); }
+		else r = fresh++;
+		peak = std::max<uint32_t>(peak, ++claimed);
+		return r;
+	}
+	void hand_back(uint16_t r) { returned.push_back(r); std::push_heap(returned.begin(), returned.end(), std::greater<uint16_t>()); --claimed; }
+	uint32_t most_claimed() const { return peak; }
+private:
+	std::vector<uint16_t> returned;
+	uint16_t fresh = 0;
+	uint32_t claimed = 0, peak = 0;
+};
+}  // namespace
+
 void Optimizer::minimise_temps()
 {
-	std::vector<uint16_t> holder(num_ssa, NONE16), reg_of(num_ssa, NONE16);
-	int live = 0, max_live = 0;
-	for (int i = (int)ins.size() - 1; i >= 0; --i) {
-		const Ins& in = ins[i];
-		if (in.cat == C_INPUT || in.merged_into != -1 || (in.nin == 0 && in.nout == 0)) continue;
-		for (int j = 0; j < in.nout; ++j) {
-			const uint32_t at = in.regs + in.nin + j;
+	LowestFreeRegister pool;
+	std::vector<uint16_t> home(num_ssa, NONE16);      // per value: the register it occupies between its writer and its last reader
+	for (size_t back = ins.size(); back-- > 0;) {
+		const Ins& in = ins[back];
+		const bool takes_part = in.cat != C_INPUT && in.merged_into == -1 && in.nin + in.nout != 0;
+		if (!takes_part) continue;
+		// results first: the value's life starts here, so its register is free above this instruction -- also for this instruction's own
+		// operands, which is how `a = f(a)` keeps one register
+		for (uint32_t at = in.regs + in.nin, end = at + in.nout; at < end; ++at) {
 			if (cls[at] != RT_TEMP) continue;
-			const uint16_t name = ssa[at];
-			if (name != NONE16 && name < num_ssa && reg_of[name] != NONE16) {
-				reg[at] = reg_of[name];
-				--live;
-				holder[reg_of[name]] = NONE16;
-				reg_of[name] = NONE16;
-			} else {
-				reg[at] = NONE16;         // a result nothing reads (an external function's unused output)
-			}
+			const uint16_t value = ssa[at];
+			const bool read_later = value < num_ssa && home[value] != NONE16;      // (NONE16 itself is no value: it fails the first test)
+			reg[at] = read_later ? home[value] : NONE16;      // never read: e.g. an external function's unused output
+			if (read_later) { pool.hand_back(home[value]); home[value] = NONE16; }
 		}
-		for (int j = 0; j < in.nin; ++j) {
-			const uint32_t at = in.regs + j;
-			if (cls[at] != RT_TEMP) continue;
-			const uint16_t name = ssa[at];
-			if (name >= num_ssa) continue;
-			if (reg_of[name] == NONE16) {
-				for (uint16_t k = 0; k < num_ssa; ++k)
-					if (holder[k] == NONE16) { reg[at] = k; holder[k] = name; reg_of[name] = k; ++live; break; }
-			} else {
-				reg[at] = reg_of[name];
-			}
+		for (uint32_t at = in.regs, end = at + in.nin; at < end; ++at) {
+			if (cls[at] != RT_TEMP || ssa[at] >= num_ssa) continue;
+			uint16_t& r = home[ssa[at]];
+			if (r == NONE16) r = pool.claim();      // the value's last reader
+			reg[at] = r;
 		}
-		max_live = std::max(max_live, live);
 	}
-	num_temps = (uint32_t)max_live;
+	num_temps = pool.most_claimed();
 }
 
-// Step 17 (:2855-2978): scanning backwards, a temp that ends in a float / int32 output is computed straight into that output's
-// buffer, and the buffers of outputs whose source is not a temp serve as scratch for the temps above them; what is left keeps
-// a temp register and is renumbered densely.
+// Step 17 (:2855-2978): output buffers instead of temp registers.  Going through the program from its end, every temp REGISTER (not
+// value: the decision holds for everything the register carries higher up, as in the reference) ends in one of three states:
+//   - it feeds a float / int32 output instruction: from there upwards the register IS that output's buffer;
+//   - it is met in another instruction while the buffer of an output that is not fed by a temp is unclaimed: it becomes that buffer
+//     (the buffers are claimed last-found-first);
+//   - otherwise it stays a temp; the temps that stay are renumbered densely.
+// One walk, with the decisions in a table that each instruction's operands are translated through on the way up.
 void Optimizer::alias_outputs()
 {
 	const size_t n = std::max<size_t>(num_outputs_remapped, num_temps);
 	final_temp.resize(n);
 	for (size_t i = 0; i < n; ++i) final_temp[i] = (uint16_t)i;
 	if (num_outputs_remapped == 0) return;
-	std::vector<uint8_t> keep(num_temps, 0);
-	std::vector<uint16_t> available;
-	auto retarget = [&](int upto, uint16_t temp, uint16_t serial) {       // every mention of `temp` at or above `upto` becomes the output
-		for (int i = upto; i >= 0; --i)
-			for (int j = 0; j < ins[i].nin + ins[i].nout; ++j) {
-				const uint32_t at = ins[i].regs + j;
-				if (at < reg.size() && reg[at] == temp && cls[at] == RT_TEMP) { reg[at] = serial; cls[at] = RT_OUTPUT; }
-			}
+
+	enum : uint8_t { UNDECIDED, STAYS, IS_OUTPUT };
+	struct Fate { uint8_t what = UNDECIDED; uint16_t serial = 0; };
+	std::vector<Fate> fate(num_temps);
+	std::vector<uint16_t> unclaimed;      // serials of outputs whose buffers may serve as scratch, in the order found
+	auto temp_at = [&](uint32_t at) -> Fate* { return (at < reg.size() && cls[at] == RT_TEMP && reg[at] < num_temps) ? &fate[reg[at]] : nullptr; };
+	auto translate = [&](uint32_t at) {      // an operand whose register has become an output buffer names that buffer
+		if (Fate* f = temp_at(at); f && f->what == IS_OUTPUT) { reg[at] = f->serial; cls[at] = RT_OUTPUT; }
 	};
-	for (int i = (int)ins.size() - 1; i >= 0; --i) {
-		const Ins& in = ins[i];
-		if (in.merged_into != -1) continue;
+
+	for (size_t back = ins.size(); back-- > 0;) {
+		const Ins& in = ins[back];
+		const uint32_t first = in.regs, count = (uint32_t)(in.nin + in.nout);
+		for (uint32_t k = 0; k < count; ++k) translate(first + k);      // decisions made further down the program
+		if (in.merged_into != -1 || in.cat == C_INPUT) continue;
 		if (in.op == VVM_OP_outputdata_float || in.op == VVM_OP_outputdata_int32) {
-			const uint32_t src = in.regs + 1;
-			if (cls[src] == RT_TEMP) {
-				const uint16_t temp = reg[src];
-				if (temp != NONE16 && temp < num_temps && !keep[temp]) {
-					cls[src] = RT_OUTPUT; reg[src] = in.serial;
-					retarget(i - 1, temp, in.serial);
-				}
-			} else if (std::find(available.begin(), available.end(), in.serial) == available.end()) {
-				available.push_back(in.serial);
+			const uint32_t src = first + 1;
+			if (cls[src] != RT_TEMP) {      // a constant, an input, or a register that already is some output's buffer
+				if (std::find(unclaimed.begin(), unclaimed.end(), in.serial) == unclaimed.end()) unclaimed.push_back(in.serial);
+			} else if (Fate* f = temp_at(src); f && f->what == UNDECIDED) {
+				*f = Fate{IS_OUTPUT, in.serial};
+				translate(src);      // (this operand only: the instruction's other operand was looked at before the decision)
 			}
-		} else if (in.cat != C_INPUT) {
-			int count = in.nin + in.nout;
-			if (in.op == VVM_OP_acquireindex) --count;       // its result only orders instructions; nothing reads it at run time
-			for (int j = 0; j < count; ++j) {
-				const uint32_t at = in.regs + j;
-				const uint16_t temp = reg[at];
-				if (temp == NONE16 || cls[at] != RT_TEMP || temp >= num_temps || keep[temp]) continue;
-				if (!available.empty()) {
-					const uint16_t serial = available.back();
-					available.pop_back();
-					retarget(i, temp, serial);
-				} else {
-					keep[temp] = 1;
-				}
-			}
+			continue;
 		}
+		// acquireindex: its result only orders instructions, nothing reads it at run time: it takes no part in the decisions
+		const uint32_t deciding = in.op == VVM_OP_acquireindex ? count - 1 : count;
+		for (uint32_t k = 0; k < deciding; ++k) {
+			Fate* f = temp_at(first + k);
+			if (!f || f->what != UNDECIDED) { translate(first + k); continue; }
+			if (unclaimed.empty()) { f->what = STAYS; continue; }
+			*f = Fate{IS_OUTPUT, unclaimed.back()};
+			unclaimed.pop_back();
+			translate(first + k);
+		}
+		for (uint32_t k = deciding; k < count; ++k) translate(first + k);
 	}
 	uint16_t kept = 0;
-	for (uint32_t i = 0; i < num_temps; ++i)
-		if (keep[i]) final_temp[i] = kept++;
+	for (uint32_t t = 0; t < num_temps; ++t)
+		if (fate[t].what == STAYS) final_temp[t] = kept++;
 	num_temps = kept;
 }
 
