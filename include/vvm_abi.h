@@ -288,7 +288,10 @@ VVM_API void vvm_xorwow_seed(uint64_t cycles_first, uint64_t cycles_second, uint
  * DataSetAccessIndex. Several vvm_exec_async calls on one state may be queued before one finish; the
  * finish reports the counts of the LAST one.  Scripts with update_id / acquire_id are the exception: the
  * dataset's NumFreeIDs / MaxUsedID / NumSpawnedIDs are host words read at enqueue and written by the
- * finish, so a second vvm_exec_async before the finish returns VVM_E_INVALID_ARG. */
+ * finish, so a second vvm_exec_async before the finish returns VVM_E_INVALID_ARG.  A script with acquire_id AND
+ * update_id on one dataset hands IDs from chunk to chunk of the reference's chunking (VectorVMRuntime.cpp:1175,
+ * 1411-1423): its Exec runs one launch per chunk, each finished before the next, inside vvm_exec_async itself (the
+ * call is synchronous for such a script and vvm_exec_finish only reports). */
 VVM_API int vvm_exec_async(vvm_exec_context* ctx, const vvm_exec_options* opt);
 VVM_API int vvm_exec_finish(vvm_exec_context* ctx);
 

@@ -117,7 +117,10 @@ struct VvmIdDesc {
 	uint32_t  chunk_instances;   // MaxInstancesPerChunk of the reference's chunking for this Exec
 	uint32_t  num_instances;
 	uint32_t  num_chunks;
-	uint32_t  pad;
+	int32_t   push_start;        // update_id: where in FreeIDTable the Exec's first freed ID goes (= num_free_start, unless the script also
+	                             // takes IDs from this dataset: then the Exec is one chunk and they go where its own IDs came from)
+	const int32_t* free_read;    // acquire_id reads FreeIDTable through this (= free_table, unless update_id writes the same entries in
+	                             // the same launch: then a copy of them, addressed like the table)
 };
 
 // One Exec (one emitter) as the kernel sees it.  Lives in device memory.

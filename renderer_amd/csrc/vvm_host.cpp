@@ -257,6 +257,9 @@ struct vvm_state {
 	size_t    rand_words_capacity = 0; // words
 	uint32_t  rand_stride = 0;         // words from one draw's to the next draw's
 	uint32_t  last_width = 0;          // instances per lane of the kernel the last Exec ran on
+	int32_t*  d_id_snapshot = nullptr; // scripts with acquire_id and update_id on one dataset: the FreeIDTable entries the chunk's acquire_id reads
+	uint32_t  id_snapshot_capacity = 0;
+	bool      serial_done = false;     // ... and: the last Exec was run chunk after chunk, to the end, by the enqueue call
 	int       device = -1;             // ordinal of the device that holds the state's memory (the one current at vvm_alloc_state)
 };
 
@@ -360,6 +363,12 @@ struct PreparedExec {
 	uint64_t ride_addr = 0;                            // where the program leaves its per-lane acquireindex results for that kernel (0: nowhere)
 	uint32_t id_buffers = 0;                           // which piece of the state's update_id buffers this pass works in (fused passes run together)
 	bool reference_random = false;                     // the Exec's random ops read the reference generator's words (then it runs on a FULL kernel)
+	// One chunk of an Exec that is run chunk after chunk (LinkedProgram::serial_chunks): set by the caller.  The chunk's first instance
+	// within the whole Exec (advancing inputs, exec_index and the random generator's key start there) and the number of survivors the
+	// chunks before it have written (outputs and IDTable positions start there).
+	uint32_t chunk_first = 0, out_base = 0;
+	bool     serial_chunk = false;
+	const int32_t* free_read_snapshot = nullptr;       // ... and where the copy of the FreeIDTable entries lies that the chunk's acquire_id reads
 	bool full() const { return lp->full_kernel || reference_random; }
 	// what vvm_launch_exec_kernel takes as many_registers (a program with two chains runs four-wide on the kernel with 32 registers: it has the second chain)
 	bool launch_many() const { return light || lp->many_registers || (lp->num_chains > 1 && instances_per_lane == 4); }
@@ -599,6 +608,12 @@ int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, P
 	pe.bytes = align_up(pe.off_ids + pe.lp->id_uses.size() * sizeof(VvmIdDesc), 256);      // (the block itself is 256-byte aligned)
 	(void)O;
 	reference_chunking(s, ctx, pe.chunk_instances, pe.num_chunks);
+	if (pe.serial_chunk) {
+		// this Exec IS one chunk of the whole Exec's chunking (worked out anew for its own size, the chunking may cut it again: the
+		// reference sizes a chunk by the average, not by what fits)
+		pe.chunk_instances = std::max<uint32_t>(4u, ((uint32_t)ctx->NumInstances + 3u) & ~3u);
+		pe.num_chunks = ctx->NumInstances > 0 ? 1u : 0u;
+	}
 	for (const vvm::LinkedProgram::IdUse& use : pe.lp->id_uses) {
 		// update_id / acquire_id: the tables must be there, in device memory, and small enough for 32-bit byte offsets
 		if ((int)use.dataset >= ctx->DataSets.num) return fail(VVM_E_INVALID_ARG, "the script's ID instructions name a dataset the context does not provide");
@@ -608,8 +623,10 @@ int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, P
 		if (use.updates) {
 			if (!ds.IDTable || !ds.IDTable->data || !ds.MaxUsedID) return fail(VVM_E_INVALID_ARG, "update_id needs the dataset's IDTable and MaxUsedID");
 			if (ds.IDTable->num < 0 || ds.IDTable->num > (1 << 29)) return fail(VVM_E_INVALID_ARG, "IDTable->Num() out of range");
-			if ((int64_t)*ds.NumFreeIDs + ctx->NumInstances > ds.FreeIDTable->max) return fail(VVM_E_INVALID_ARG, "FreeIDTable cannot take the IDs of every instance");
-		} else {
+			// (a script that also takes its IDs from this dataset returns them to the places they came from)
+			if (!use.acquires && (int64_t)*ds.NumFreeIDs + ctx->NumInstances > ds.FreeIDTable->max) return fail(VVM_E_INVALID_ARG, "FreeIDTable cannot take the IDs of every instance");
+		}
+		if (use.acquires) {
 			if (!ds.NumSpawnedIDs) return fail(VVM_E_INVALID_ARG, "acquire_id needs the dataset's NumSpawnedIDs");
 			if (*ds.NumFreeIDs < ctx->NumInstances) return fail(VVM_E_INVALID_ARG, "fewer free IDs than instances");              // check(), RT.cpp:1415
 			if ((int64_t)*ds.NumSpawnedIDs + ctx->NumInstances > ds.FreeIDTable->max) return fail(VVM_E_INVALID_ARG, "spawned IDs do not fit FreeIDTable");   // RT.cpp:1431
@@ -683,10 +700,10 @@ int fill_params(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* op
 	d->num_instances = (uint32_t)ctx->NumInstances;
 	d->num_tiles = pe.tiles;
 	d->first_tile = first_tile;
-	d->exec_index_base = opt ? opt->ExecIndexBase : 0;
+	d->exec_index_base = (opt ? opt->ExecIndexBase : 0) + (int32_t)pe.chunk_first;
 	d->rand_seed_lo = opt ? (uint32_t)opt->RandSeed : 0;
 	d->rand_seed_hi = opt ? (uint32_t)(opt->RandSeed >> 32) : 0;
-	d->rand_instance_base = opt ? opt->RandInstanceBase : 0;
+	d->rand_instance_base = (opt ? opt->RandInstanceBase : 0) + (int32_t)pe.chunk_first;
 	d->rand_words = pe.reference_random ? st->d_rand_words : nullptr;
 	d->rand_stride = pe.reference_random ? st->rand_stride : 0;
 	d->flags = (lp.uses_perlin ? VVM_DESC_USES_PERLIN : 0) | (dev_block ? 0 : VVM_DESC_RELATIVE);
@@ -708,7 +725,7 @@ int fill_params(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* op
 		if (i < lp.input_used.size() && lp.input_used[i] && !ds.InputRegisters.data[idx])
 			return fail(VVM_E_INVALID_ARG, "an input stream the script reads is a null pointer");
 		const uint64_t stride = (in.type == 2) ? 2 : 4;
-		in_ptrs[i] = (uint64_t)(uintptr_t)ds.InputRegisters.data[idx] + (uint64_t)(int64_t)ds.InstanceOffset * stride;
+		in_ptrs[i] = (uint64_t)(uintptr_t)ds.InputRegisters.data[idx] + (uint64_t)((int64_t)ds.InstanceOffset + (in.noadvance ? 0 : (int64_t)pe.chunk_first)) * stride;
 	}
 	uint64_t* load_ptrs = (uint64_t*)(host + pe.off_load);
 	for (size_t i = 0; i < lp.load_list.size(); ++i) load_ptrs[i] = lp.load_list[i] >= 0 ? in_ptrs[lp.load_list[i]] : 0;
@@ -730,7 +747,7 @@ int fill_params(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* op
 		if ((int)idx >= ds.OutputRegisters.num || !ds.OutputRegisters.data) return fail(VVM_E_INVALID_ARG, "output register index past OutputRegisters.num");
 		const uint64_t stride = (ty == 2) ? 2 : 4;
 		if (!ds.OutputRegisters.data[idx]) continue;
-		const uint64_t addr = (uint64_t)(uintptr_t)ds.OutputRegisters.data[idx] + (uint64_t)(int64_t)ds.InstanceOffset * stride;
+		const uint64_t addr = (uint64_t)(uintptr_t)ds.OutputRegisters.data[idx] + (uint64_t)((int64_t)ds.InstanceOffset + (int64_t)pe.out_base) * stride;
 		if (addr & ~VVM_OUT_ADDR_MASK) return fail(VVM_E_INVALID_ARG, "output register address does not fit 48 bits");
 		out_list[k] = addr | (lp.out_is16[k] ? VVM_OUT_IS16 : 0) | ((k < lp.out_chain.size() && lp.out_chain[k]) ? VVM_OUT_CHAIN1 : 0);
 	}
@@ -751,8 +768,11 @@ int fill_params(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* op
 		ids->id_scratch = st->d_id_scratch ? st->d_id_scratch + (size_t)pe.id_buffers * st->id_scratch_capacity : nullptr;
 		ids->max_id = d->counts + st->num_datasets() + use.dataset;      // the dataset's word behind the survivor counts
 		ids->survivors = d->counts + use.dataset;
-		ids->instance_offset = ds.InstanceOffset;
+		ids->instance_offset = ds.InstanceOffset + (int32_t)pe.out_base;
 		ids->num_free_start = *ds.NumFreeIDs;
+		const bool both = use.updates && use.acquires;      // (then this Exec is one chunk: prepare and exec_serial_chunks see to it)
+		ids->push_start = both ? *ds.NumFreeIDs - ctx->NumInstances : *ds.NumFreeIDs;
+		ids->free_read = (both && pe.free_read_snapshot) ? pe.free_read_snapshot - ((int64_t)*ds.NumFreeIDs - ctx->NumInstances) : ds.FreeIDTable->data;
 		ids->num_spawned_start = ds.NumSpawnedIDs ? *ds.NumSpawnedIDs : 0;
 		ids->acquire_tag = ds.IDAcquireTag;
 		ids->chunk_instances = pe.chunk_instances;
@@ -1084,6 +1104,7 @@ VVM_API void vvm_free_state(vvm_state* st)
 	if (st->d_chunk_prefix) (void)hipFree(st->d_chunk_prefix);
 	if (st->d_id_scratch) (void)hipFree(st->d_id_scratch);
 	if (st->d_rand_words) (void)hipFree(st->d_rand_words);
+	if (st->d_id_snapshot) (void)hipFree(st->d_id_snapshot);
 	if (st->h_counts) (void)hipHostFree(st->h_counts);
 	for (hipEvent_t e : st->ev_start) (void)hipEventDestroy(e);
 	for (hipEvent_t e : st->ev_stop) (void)hipEventDestroy(e);
@@ -1092,10 +1113,81 @@ VVM_API void vvm_free_state(vvm_state* st)
 
 // Enqueues one Exec.  no_alloc: the Exec works in the device's scratch array instead of the state's own buffers and refuses
 // whatever would need an allocation (vvm_exec_noalloc).
-static int exec_enqueue(vvm_exec_context* ctx, const vvm_exec_options* opt, bool no_alloc)
+static int exec_enqueue(vvm_exec_context* ctx, const vvm_exec_options* opt, bool no_alloc, const PreparedExec* chunk = nullptr);
+
+// An Exec of a script that takes IDs from a dataset's free list and returns IDs to it (acquire_id and update_id on one dataset).  The
+// reference runs such a script chunk after chunk on the one list (VectorVMRuntime.cpp:1175-1181, 1411-1435): the IDs a chunk's dead
+// instances return are the first ones the next chunk takes.  That is a dependency from chunk to chunk through the data, so the Exec
+// is run the same way: one launch per chunk of the reference's chunking, each finished before the next starts (its counters are
+// what the next one starts from), outputs appended behind the survivors so far.  Within a chunk the places the returned IDs go to
+// are places the chunk's own IDs are read from, by other workgroups at other times: acquire_id reads a copy made ahead of the launch.
+// Correct, not fast: a launch and a host round trip per chunk (about 30 us), for the emitters with persistent IDs whose spawn
+// script carries the first update.  Synchronous; vvm_exec_finish then has nothing left to do.
+static int exec_serial_chunks(vvm_exec_context* ctx, const vvm_exec_options* opt)
+{
+	vvm_state* st = ctx->VVMState;
+	const vvm::ThawedScript& s = st->script;
+	if (opt && opt->RandXorwowState && !st->wide.rand_draws.empty())
+		return fail(VVM_E_UNSUPPORTED_OP, "RandXorwowState: not available to a script with update_id and acquire_id on one dataset");
+	if (ctx->NumInstances < 0) return fail(VVM_E_INVALID_ARG, "negative NumInstances");
+	uint32_t both_dataset = 0;
+	for (const vvm::LinkedProgram::IdUse& u : st->wide.id_uses) if (u.updates && u.acquires) both_dataset = u.dataset;
+	if ((int)both_dataset >= ctx->DataSets.num || !ctx->DataSets.data) return fail(VVM_E_INVALID_ARG, "the script's ID instructions name a dataset the context does not provide");
+	const vvm_dataset_meta& ds = ctx->DataSets.data[both_dataset];
+	if (!ds.FreeIDTable || !ds.FreeIDTable->data || !ds.NumFreeIDs) return fail(VVM_E_INVALID_ARG, "the script has ID instructions but the dataset has no FreeIDTable / NumFreeIDs");
+	uint32_t chunk_instances = 0, num_chunks = 0;
+	reference_chunking(s, ctx, chunk_instances, num_chunks);      // (also what the whole Exec leaves in ctx->Internal)
+	const uint32_t n = (uint32_t)ctx->NumInstances;
+	if (chunk_instances > st->id_snapshot_capacity) {
+		if (st->last_stream) HIP_TRY(hipStreamSynchronize(st->last_stream));
+		if (st->d_id_snapshot) (void)hipFree(st->d_id_snapshot);
+		st->d_id_snapshot = nullptr; st->id_snapshot_capacity = 0;
+		HIP_TRY(hipMalloc((void**)&st->d_id_snapshot, (size_t)chunk_instances * 4));
+		st->id_snapshot_capacity = chunk_instances;
+	}
+	hipStream_t stream = (opt && opt->Stream) ? (hipStream_t)opt->Stream : st->stream;
+	const size_t nd = std::min<size_t>(s.max_output_dataset, (size_t)ctx->DataSets.num);
+	std::vector<int32_t> written(nd, 0);
+	vvm_exec_context one = *ctx;      // (shares the dataset descriptions: the chunk's counters and survivor counts land in the caller's)
+	uint32_t first = 0;
+	do {
+		const uint32_t count = std::min(chunk_instances, n - first);
+		one.NumInstances = (int32_t)count;
+		PreparedExec where;
+		where.serial_chunk = true;
+		where.chunk_first = first;
+		where.out_base = st->wide.pass_dataset < nd ? (uint32_t)written[st->wide.pass_dataset] : 0u;
+		const int32_t num_free = *ds.NumFreeIDs;
+		if (num_free < (int32_t)count) return fail(VVM_E_INVALID_ARG, "fewer free IDs than instances");              // check(), RT.cpp:1415
+		if (count) {
+			if (st->last_stream && st->last_stream != stream) HIP_TRY(hipStreamSynchronize(st->last_stream));
+			HIP_TRY(hipMemcpyAsync(st->d_id_snapshot, ds.FreeIDTable->data + (num_free - (int32_t)count), (size_t)count * 4, hipMemcpyDeviceToDevice, stream));
+		}
+		where.free_read_snapshot = st->d_id_snapshot;
+		int rc = exec_enqueue(&one, opt, false, &where);
+		if (rc == VVM_OK) rc = vvm_exec_finish(&one);
+		if (rc != VVM_OK) return rc;
+		for (size_t d = 0; d < nd; ++d) written[d] += ctx->DataSets.data[d].DataSetAccessIndex + 1;
+		first += count;
+	} while (first < n);
+	for (size_t d = 0; d < nd; ++d) ctx->DataSets.data[d].DataSetAccessIndex = written[d] - 1;             // RT.cpp:2305-2308
+	st->serial_done = true;
+	return VVM_OK;
+}
+
+static int exec_enqueue(vvm_exec_context* ctx, const vvm_exec_options* opt, bool no_alloc, const PreparedExec* chunk)
 {
 	if (!ctx || !ctx->VVMState) return fail(VVM_E_INVALID_ARG, "null context or state");
 	vvm_state* st = ctx->VVMState;
+	if (!chunk && st->wide.serial_chunks) {
+		if (no_alloc) return fail(VVM_E_UNSUPPORTED_OP, "vvm_exec_noalloc: scripts with update_id / acquire_id need buffers sized per Exec");
+		{
+			int dev = -1;
+			HIP_TRY(hipGetDevice(&dev));
+			if (dev != st->device) return fail(VVM_E_INVALID_ARG, "the state was allocated on another device than the one that is current");
+		}
+		return exec_serial_chunks(ctx, opt);
+	}
 	{   // the state's code, tables and launch words live on one device: the Exec has to be issued with that device current
 		int dev = -1;
 		HIP_TRY(hipGetDevice(&dev));
@@ -1112,6 +1204,7 @@ static int exec_enqueue(vvm_exec_context* ctx, const vvm_exec_options* opt, bool
 	}
 	PreparedExec pe;
 	pe.lean_max_tiles = no_alloc ? VVM_NOALLOC_RIDE_TILES : 0;
+	if (chunk) { pe.serial_chunk = true; pe.chunk_first = chunk->chunk_first; pe.out_base = chunk->out_base; pe.free_read_snapshot = chunk->free_read_snapshot; }
 	int rc = prepare(st, ctx, opt, pe);
 	if (rc != VVM_OK) return rc;
 	if (no_alloc && pe.reference_random) return fail(VVM_E_UNSUPPORTED_OP, "vvm_exec_noalloc: RandXorwowState needs a buffer sized per Exec");
@@ -1279,6 +1372,7 @@ VVM_API int vvm_exec_finish(vvm_exec_context* ctx)
 {
 	if (!ctx || !ctx->VVMState) return fail(VVM_E_INVALID_ARG, "null context or state");
 	vvm_state* st = ctx->VVMState;
+	if (st->serial_done) { st->serial_done = false; return VVM_OK; }      // (exec_serial_chunks has finished every chunk and written the results)
 	const bool ran = ctx->NumInstances > 0;
 	if (st->last_stream) {
 		const size_t nc = st->num_datasets(), mirror = st->mirror_word();
@@ -1323,13 +1417,16 @@ VVM_API int vvm_exec_finish(vvm_exec_context* ctx)
 				if (done[use.dataset]) continue;
 				done[use.dataset] = 1;
 				vvm_dataset_meta& ds = ctx->DataSets.data[use.dataset];
-				if (use.updates) {
-					*ds.NumFreeIDs = st->id_num_free_start[use.dataset] + (ctx->NumInstances - st->h_counts[use.dataset]);
-					*ds.MaxUsedID = st->h_counts[st->num_datasets() + use.dataset];
-				} else {
-					*ds.NumFreeIDs = st->id_num_free_start[use.dataset] - ctx->NumInstances;
+				int32_t num_free = st->id_num_free_start[use.dataset];
+				if (use.acquires) {
+					num_free -= ctx->NumInstances;
 					*ds.NumSpawnedIDs = st->id_num_spawned_start[use.dataset] + ctx->NumInstances;
 				}
+				if (use.updates) {
+					num_free += ctx->NumInstances - st->h_counts[use.dataset];
+					*ds.MaxUsedID = st->h_counts[st->num_datasets() + use.dataset];
+				}
+				*ds.NumFreeIDs = num_free;
 			}
 		};
 		settle(st->wide);

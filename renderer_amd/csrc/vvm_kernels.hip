@@ -893,7 +893,7 @@ template <int V> DEV void apply_update_id(const void* idp, const float* q, uint3
 	const rsrc_t rs_free = make_rsrc(IDF_PTR(free_table), 4u * IDF_U32(free_table_max));
 	const rsrc_t rs_prefix = make_rsrc(IDF_PTR(chunk_prefix), 4u * IDF_U32(num_chunks));
 	const rsrc_t rs_scratch = make_rsrc(IDF_PTR(id_scratch), 4u * IDF_U32(num_instances));
-	const uint32_t instance_offset = IDF_U32(instance_offset), num_free_start = IDF_U32(num_free_start), chunk = IDF_U32(chunk_instances);
+	const uint32_t instance_offset = IDF_U32(instance_offset), num_free_start = IDF_U32(push_start), chunk = IDF_U32(chunk_instances);
 	const uint32_t rank = kw & 0xFFFFu, keep = (kw >> 16) & 0xFFu, exists = kw >> 24;
 #pragma unroll
 	for (int k = 0; k < V; ++k) {
@@ -1323,12 +1323,13 @@ struct KernelEnv {
 					} else { \
 						const uint32_t table_max = sload32(idp, offsetof(VvmIdDesc, free_table_max) / 4); \
 						const rsrc_t rs_free = make_rsrc(sload64(idp, offsetof(VvmIdDesc, free_table) / 8), 4u * table_max); \
+						const rsrc_t rs_read = make_rsrc(sload64(idp, offsetof(VvmIdDesc, free_read) / 8), 4u * table_max); \
 						const uint32_t num_free = sload32(idp, offsetof(VvmIdDesc, num_free_start) / 4), num_spawned = sload32(idp, offsetof(VvmIdDesc, num_spawned_start) / 4); \
 						const uint32_t chunk = sload32(idp, offsetof(VvmIdDesc, chunk_instances) / 4); \
 						_Pragma("unroll") LANES { \
 							const uint32_t g = inst_i + slot_offset<V>(k); \
 							const uint32_t ok = (uint32_t)(g < c.num_instances) & (uint32_t)(g < num_free); \
-							const uint32_t id = __builtin_amdgcn_raw_buffer_load_b32(rs_free, (int)(ok ? (num_free - 1u - g) * 4u : VVM_RSRC_NOWHERE), 0, 0); \
+							const uint32_t id = __builtin_amdgcn_raw_buffer_load_b32(rs_read, (int)(ok ? (num_free - 1u - g) * 4u : VVM_RSRC_NOWHERE), 0, 0); \
 							const uint32_t ci = g / chunk; \
 							const uint32_t chunk_end = min(c.num_instances, (ci + 1u) * chunk); \
 							uint32_t pos = table_max - (num_spawned + chunk_end) + (g - ci * chunk); \

@@ -401,18 +401,24 @@ static int link_program_as(const ThawedScript& s, bool force_narrow, LinkedProgr
 		if (g_ops[d.op].heavy) heavy = true;
 		if (d.kind == K_EXTFN) uses_perlin = true;
 		if (d.kind == K_IDS) {
-			// Any number of datasets, one direction per dataset: update_id returns IDs to the free list that acquire_id takes them
-			// from, chunk by chunk in the reference (VectorVMRuntime.cpp:1175, 1411-1423), so a script that does both to ONE dataset
-			// depends on the reference's chunk order.
+			// Any number of datasets.  update_id returns IDs to the free list that acquire_id takes them from, chunk by chunk in the
+			// reference (VectorVMRuntime.cpp:1175, 1411-1423): a script that does both to ONE dataset hands IDs from a chunk to the
+			// next, and its Exec is run chunk after chunk (serial_chunks).  Supported in the order a spawn script with a first update has
+			// them: acquire_id, then update_id.
 			const bool upd = d.op == VVM_OP_update_id;
 			bool known = false;
-			for (const LinkedProgram::IdUse& u : lp.id_uses) {
+			for (LinkedProgram::IdUse& u : lp.id_uses) {
 				if (u.dataset != d.dataset) continue;
-				if (u.updates != upd) { err = "update_id and acquire_id on one dataset in one script are not supported by the GPU executor"; return VVM_E_UNSUPPORTED_OP; }
-				if (upd) { err = "more than one update_id for a dataset is not supported by the GPU executor"; return VVM_E_UNSUPPORTED_OP; }
 				known = true;
+				if (upd) {
+					if (u.updates) { err = "more than one update_id for a dataset is not supported by the GPU executor"; return VVM_E_UNSUPPORTED_OP; }
+					u.updates = true;
+				} else {
+					if (u.updates) { err = "acquire_id behind update_id on one dataset is not supported by the GPU executor (the chunk's own freed IDs would be taken again)"; return VVM_E_UNSUPPORTED_OP; }
+					u.acquires = true;
+				}
 			}
-			if (!known) lp.id_uses.push_back(LinkedProgram::IdUse{d.dataset, upd});
+			if (!known) lp.id_uses.push_back(LinkedProgram::IdUse{d.dataset, upd, !upd});
 			if (lp.id_uses.size() > VVM_MAX_ID_USES) { err = "update_id / acquire_id on too many datasets"; return VVM_E_TOO_LARGE; }
 		}
 		if (d.kind == K_OUTPUT) {
@@ -531,6 +537,11 @@ static int link_program_as(const ThawedScript& s, bool force_narrow, LinkedProgr
 	lp.num_chains = chains ? 2 : 1;
 	lp.num_passes = chains ? 1 : std::max<uint32_t>(1, (uint32_t)lp.acquire_order.size());
 	if (pass >= lp.num_passes) { err = "pass index out of range"; return VVM_E_INVALID_ARG; }
+	for (const LinkedProgram::IdUse& u : lp.id_uses)
+		if (u.updates && u.acquires) {
+			if (lp.num_passes > 1) { err = "update_id and acquire_id on one dataset in a script that acquires several datasets are not supported by the GPU executor"; return VVM_E_UNSUPPORTED_OP; }
+			lp.serial_chunks = true;
+		}
 	const bool multi_pass = lp.num_passes > 1;
 	const uint32_t pass_dataset = lp.acquire_order.empty() ? 0 : lp.acquire_order[pass];
 	lp.pass_dataset = pass_dataset;

@@ -48,10 +48,13 @@ struct LinkedProgram {
 	// update_id / acquire_id: one entry per dataset whose ID tables this pass works on (its index is the slot of the dataset's
 	// VvmIdDesc behind the Exec descriptor); a dataset is either updated (at most one update_id, in the dataset's own pass) or
 	// acquired from
-	struct IdUse { uint32_t dataset; bool updates; };
+	// (updates and acquires both: a script that takes IDs from the dataset's free list and returns the IDs of its dead instances to it in
+	// one pass.  The reference then hands IDs from chunk to chunk, so such an Exec runs chunk after chunk: serial_chunks)
+	struct IdUse { uint32_t dataset; bool updates; bool acquires; };
 	std::vector<IdUse> id_uses;
 	bool     uses_ids = false;         // id_uses is not empty
 	bool     updates_ids = false;      // ... and has an update_id
+	bool     serial_chunks = false;    // ... and some dataset has both: the Exec is run as one launch per chunk of the reference's chunking
 	std::vector<uint8_t> acquires_dataset;   // per output dataset: the script runs acquireindex for it
 	std::vector<uint32_t> acquire_order;     // those datasets in program order
 	uint32_t num_passes = 1;                 // one pass per acquired dataset (see link_program)

@@ -130,3 +130,56 @@ def two_updates_script():
     s.output_data(FLOAT, 1, [(x, s.output(1, FLOAT, 0))])
     s.output_data(INT32, 1, [(pid1, s.output(1, INT32, 0))])
     return s.build()
+
+
+# ---- acquire_id and update_id on ONE dataset of one script ---------------------------------------------------------------------------
+def spawn_and_update_script(id_from_temp: bool = False):
+    """A spawn script that carries the new particles' first update: acquire_id -> (id, tag); keep = x < limit; acquireindex(keep);
+    update_id(id, tag) on the same dataset; outputs x, id and tag of the survivors."""
+    s = Script()
+    x = s.input(0, FLOAT, 0)
+    new_id, tag = s.temps(2)
+    s.acquire_id(new_id, tag, 0)
+    keep = s.temp()
+    s.op("cmplt", x, s.const(0), keep)
+    s.acquireindex(keep, 0)
+    id_reg = new_id
+    if id_from_temp:
+        id_reg = s.temp()
+        s.op("addi", new_id, s.const(1), id_reg)       # constant 1 holds integer 0: the temp equals the acquired ID
+    s.update_id(id_reg, tag, 0)
+    s.output_data(FLOAT, 0, [(x, s.output(0, FLOAT, 0))])
+    s.output_data(INT32, 0, [(new_id, s.output(0, INT32, 0)), (tag, s.output(0, INT32, 1))])
+    return s.build()
+
+
+def np_spawn_and_update(st: IdState, keep: np.ndarray, chunk: int, instance_offset: int = 0):
+    """The reference runs both instructions chunk after chunk on the dataset's one free list (VectorVMRuntime.cpp:1175-1181,
+    1411-1435): a chunk takes its IDs from the end of the list, which holds what the chunks before it have freed, logs them as spawned,
+    and returns the IDs of its dead instances.  Returns (state, the ID of every instance, in instance order)."""
+    st = st.copy()
+    keep = keep.astype(bool)
+    n = len(keep)
+    table_max = len(st.free_table)
+    all_ids = np.empty(n, np.int32)
+    written = 0
+    for start in range(0, n, chunk):
+        cnt = min(chunk, n - start)
+        ids = st.free_table[st.num_free - cnt:st.num_free][::-1].copy()                               # :1417-1421
+        st.num_free -= cnt
+        st.num_spawned += cnt
+        st.free_table[table_max - st.num_spawned:table_max - st.num_spawned + cnt] = ids                # :1433-1435
+        all_ids[start:start + cnt] = ids
+        k = keep[start:start + cnt]
+        rank = np.cumsum(k) - k
+        st.id_table[ids[k]] = instance_offset + written + rank[k]                                      # :1191-1193
+        dead = ids[~k]
+        st.free_table[st.num_free:st.num_free + len(dead)] = dead                                      # :1175, 1181
+        st.num_free += len(dead)
+        nout = int(k.sum())
+        if nout:
+            m = int(ids[:nout].max())                                                                  # :1141-1174
+            if m > st.max_used:
+                st.max_used = m
+        written += nout
+    return st, all_ids

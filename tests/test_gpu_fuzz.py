@@ -24,6 +24,6 @@ def test_five_hundred_random_scripts_match_the_oracle():
     assert bad == 0 and skipped == 0
     # the run did reach what it is there for
     for kind in ("fits the light kernel", "ran on the light kernel", "two chains in one pass", "inside a batch", "reference generator",
-                 "through vvm_exec_noalloc", "200 K instances or more", "has a lean form (runs when eight-wide is forced)",
+                 "through vvm_exec_noalloc", "200 K instances or more", "acquire_id and update_id on one dataset", "has a lean form (runs when eight-wide is forced)",
                  (1, True, True), (4, True, True), (4, True, False)):
         assert kinds.get(kind, 0) > 0, kind

@@ -160,15 +160,72 @@ def test_update_id_on_two_acquired_datasets(n, page_kb, flags):
     _same_tables(got1, want1)
 
 
-def test_update_id_and_acquire_id_on_one_dataset_are_refused():
-    """The reference's result then depends on its chunk order: a chunk's acquire_id pops what the chunk before it has freed."""
-    from renderer_amd.assembler import INT32, Script
+def _spawn_and_update_case(n, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.random(n).astype(f32)
+    m = 3 * n + 50
+    st = IdState(np.full(m, -1, np.int32), np.full(m, -7, np.int32), num_free=n + 20, max_used=3, num_spawned=2, tag=9)
+    st.free_table[:n + 20] = rng.permutation(m)[:n + 20]
+    return x, st
+
+
+@pytest.mark.parametrize("n,death,page_kb,from_temp,offset", [(1, 0.0, 64, False, 0), (1, 1.0, 64, False, 0), (10, 0.4, 64, False, 5), (5000, 0.4, 64, True, 0),
+                                                              (5000, 0.4, 16, False, 3), (5000, 1.0, 16, False, 0), (5000, 0.0, 16, True, 0), (20001, 0.35, 8, False, 7),
+                                                              (20001, 0.9, 2, True, 0), (0, 0.5, 64, False, 0)])
+def test_acquire_id_and_update_id_on_one_dataset(n, death, page_kb, from_temp, offset):
+    """A spawn script that carries the first update: a chunk of the reference's chunking takes the IDs the chunks before it have freed
+    (VectorVMRuntime.cpp:1175, 1411-1423).  The Exec runs chunk after chunk; tables, counters, the chunk-dependent MaxUsedID and the
+    survivors' streams equal the oracle's at one chunk and at many."""
+    x, st = _spawn_and_update_case(max(n, 1), n + page_kb)
+    limit = f32(1.0 - death)
+    script = id_cases.spawn_and_update_script(id_from_temp=from_temp)
+    consts = [id_cases.update_constants(limit)]
+    dtypes = [f32, np.int32, np.int32]
+    want, got = st.copy(), st.copy()
+    ref, ref_n, _ = run_oracle(script, consts, [x], dtypes, n, ids=want, page_kb=page_kb, instance_offset=offset)
+    out, out_n, _ = run_hip(script, consts, [x], dtypes, n, ids=got, page_kb=page_kb, instance_offset=offset)
+    assert out_n == ref_n == int((x[:n] < limit).sum())
+    for a, b in zip(out, ref):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))          # (survivors and the untouched fill around them)
+    assert np.array_equal(got.id_table, want.id_table) and np.array_equal(got.free_table, want.free_table)
+    assert (got.num_free, got.max_used, got.num_spawned) == (want.num_free, want.max_used, want.num_spawned)
+
+
+def test_acquire_id_and_update_id_on_one_dataset_twice_in_a_row():
+    """Two Execs in a row on one state: the second starts from the tables and counters the first left.  (As a member of a batch, with
+    page sizes, offsets and other instructions around it: tools/gpu_fuzz_linker.py, one script in sixteen.)"""
+    n, page_kb = 6000, 16
+    rng = np.random.default_rng(5)
+    x = rng.random(n).astype(f32)
+    st = IdState(np.full(4 * n + 100, -1, np.int32), np.full(8 * n, -7, np.int32), num_free=2 * n + 40, max_used=3, num_spawned=2, tag=9)
+    st.free_table[:2 * n + 40] = rng.permutation(4 * n + 100)[:2 * n + 40]      # (IDs for two Execs; the spawned-ID log of both fits behind them)
+    script = id_cases.spawn_and_update_script()
+    consts = [id_cases.update_constants(f32(0.5))]
+    dtypes = [f32, np.int32, np.int32]
+    want, got = st.copy(), st.copy()
+    ref, ref_n, _ = run_oracle(script, consts, [x], dtypes, n, ids=want, page_kb=page_kb)
+    ref2, ref2_n, _ = run_oracle(script, consts, [x], dtypes, n, ids=want, page_kb=page_kb)
+    out, out_n, _ = run_hip(script, consts, [x], dtypes, n, ids=got, page_kb=page_kb, repeat=2)
+    assert out_n == ref2_n
+    for a, b in zip(out, ref2):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.array_equal(got.id_table, want.id_table) and np.array_equal(got.free_table, want.free_table)
+    assert (got.num_free, got.max_used, got.num_spawned) == (want.num_free, want.max_used, want.num_spawned)
+
+
+def test_update_id_ahead_of_acquire_id_on_one_dataset_is_refused():
+    """In that order a chunk would take back the IDs its own dead instances have just returned: not built."""
+    from renderer_amd.assembler import FLOAT, INT32, Script
     s = Script()
+    x = s.input(0, FLOAT, 0)
+    pid = s.input(0, INT32, 0)
+    keep = s.temp()
+    s.op("cmplt", x, s.const(0), keep)
+    s.acquireindex(keep, 0)
+    s.update_id(pid, pid, 0)
     t0, t1 = s.temps(2)
     s.acquire_id(t0, t1, 0)
-    s.acquireindex(s.const(0), 0)
-    s.update_id(t0, t1, 0)
     s.output_data(INT32, 0, [(t0, s.output(0, INT32, 0))])
     with pytest.raises(abi.VVMError) as e:
-        run_hip(s.build(), [bytes(16)], [], [np.int32], 8)
+        run_hip(s.build(), [bytes(16)], [np.zeros(8, f32), np.zeros(8, np.int32)], [np.int32], 8)
     assert "one dataset" in str(e.value)

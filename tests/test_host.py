@@ -439,6 +439,14 @@ def test_unsupported_features_are_named():
     s.acquireindex(s.const(0), 0)
     s.update_id(t0, t1, 0)
     s.output_data(INT32, 0, [(t0, s.output(0, INT32, 0))])
+    be().inspect_blob(s.build().blob)          # acquire_id, then update_id on one dataset: accepted (such an Exec runs chunk after chunk)
+    s = Script()
+    pid = s.input(0, INT32, 0)
+    s.acquireindex(s.const(0), 0)
+    s.update_id(pid, pid, 0)
+    t0, t1 = s.temps(2)
+    s.acquire_id(t0, t1, 0)                   # the other way round
+    s.output_data(INT32, 0, [(t0, s.output(0, INT32, 0))])
     with pytest.raises(abi.VVMError) as e:
         be().inspect_blob(s.build().blob)
     assert e.value.code == abi.VVM_E_UNSUPPORTED_OP and "acquire_id" in str(e.value)

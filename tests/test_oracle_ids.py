@@ -119,3 +119,29 @@ def test_two_update_ids_on_two_datasets_match_numpy():
         assert np.array_equal(got.id_table, want.id_table) and np.array_equal(got.free_table, want.free_table)
         assert (got.num_free, got.max_used) == (want.num_free, want.max_used)
     assert surv == int((x < f32(0.7)).sum()) and more[0][1] == int((x < f32(0.2)).sum())
+
+
+def _spawn_and_update_case(n, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.random(n).astype(f32)
+    m = 3 * n + 50
+    st = IdState(np.full(m, -1, np.int32), np.full(m, -7, np.int32), num_free=n + 20, max_used=3, num_spawned=2, tag=9)
+    st.free_table[:n + 20] = rng.permutation(m)[:n + 20]
+    return x, st
+
+
+@pytest.mark.parametrize("n,death,page_kb", [(1, 0.0, 64), (1, 1.0, 64), (10, 0.4, 64), (5000, 0.4, 64), (5000, 0.4, 16), (5000, 1.0, 16), (5000, 0.0, 16),
+                                             (20001, 0.35, 8), (20001, 0.9, 2)])
+def test_acquire_id_and_update_id_on_one_dataset_match_numpy(n, death, page_kb):
+    """A chunk takes the IDs the chunks before it have freed: the result depends on the page size (VectorVMRuntime.cpp:1175, 1411-1423)."""
+    x, st = _spawn_and_update_case(n, n + page_kb)
+    limit = f32(1.0 - death)
+    got = st.copy()
+    outs, surv, frame = run_oracle(id_cases.spawn_and_update_script(), [id_cases.update_constants(limit)], [x], [f32, np.int32, np.int32], n, ids=got, page_kb=page_kb,
+                                   instance_offset=3)
+    keep = x < limit
+    want, ids = id_cases.np_spawn_and_update(st, keep, frame.ctx.Internal.MaxInstancesPerChunk, instance_offset=3)
+    assert surv == int(keep.sum())
+    assert np.array_equal(outs[0][3:3 + surv], x[keep]) and np.array_equal(outs[1][3:3 + surv], ids[keep]) and np.all(outs[2][3:3 + surv] == 9)
+    assert np.array_equal(got.id_table, want.id_table) and np.array_equal(got.free_table, want.free_table)
+    assert (got.num_free, got.max_used, got.num_spawned) == (want.num_free, want.max_used, want.num_spawned)

@@ -41,6 +41,13 @@ def gen(seed):
         nf = r.randint(17, 48)                  # every stream is in a register from the top of the tile: the big-register kernels
     fvals = [s.input(0, FLOAT, i) for i in range(nf)]
     ivals = [s.input(0, INT32, i) for i in range(ni)]
+    # one script in sixteen takes the IDs of its instances from the dataset's free list AND returns those of the dead ones (acquire_id
+    # here, update_id below): such an Exec runs chunk after chunk of the reference's chunking
+    gen.both_ids = seed % 16 == 3
+    if gen.both_ids:
+        new_id, new_tag = s.temps(2)
+        s.acquire_id(new_id, new_tag, 0)
+        ivals += [new_id, new_tag]
     if nna:
         fvals.append(s.input(0, FLOAT, nf, noadvance=True))
     hins = [s.input(0, HALF, i) for i in range(nh)]
@@ -154,7 +161,9 @@ def gen(seed):
     if not acquired:
         s.acquireindex(r.choice(masks) if masks and r.random() < 0.7 else s.const(0), 0)
     gen.with_ids = seed % 8 in (3, 5)
-    if gen.with_ids:                                # update_id over an ID stream of its own (the last int32 input)
+    if gen.both_ids:
+        s.update_id(new_id, new_tag, 0)
+    elif gen.with_ids:                              # update_id over an ID stream of its own (the last int32 input)
         s.update_id(s.input(0, INT32, ni), r.choice(ivals) if ivals else s.input(0, INT32, ni), 0)
         ni += 1
     n_out = r.randint(1, 24) if keep_alive else r.randint(1, 9)
@@ -282,7 +291,12 @@ def run(first_seed, last_seed, report_every=100):
         try:
             dts1 = gen.second_dataset
             want_ids = got_ids = None
-            if gen.with_ids:
+            if gen.both_ids:
+                m = max(n, 1)
+                want_ids = IdState(np.full(m + 7, -1, np.int32), np.full(3 * m + 40, -7, np.int32), num_free=m + 5, max_used=3, num_spawned=1, tag=11)
+                want_ids.free_table[:m + 5] = rng.permutation(m + 7)[:m + 5]
+                got_ids = want_ids.copy()
+            elif gen.with_ids:
                 m = max(n, 1)
                 ins[nf + ni - 1] = rng.permutation(m + 7)[:m].astype(np.int32)          # distinct IDs
                 want_ids = IdState(np.full(m + 7, -1, np.int32), np.full(2 * m + 16, -7, np.int32), num_free=5, max_used=3)
@@ -292,7 +306,7 @@ def run(first_seed, last_seed, report_every=100):
             ref_more, got_more = [], []
             # every eleventh script draws from the reference's own generator (vvm_exec_options.RandXorwowState) instead of the counter-based
             # one; scripts that acquire two datasets in one pass have no kernel for it and keep the counter-based generator
-            xorwow = [(seed * 2654435761 + 97 * k) & 0xFFFFFFFF for k in range(24)] if seed % 11 == 0 and not dts1 else None
+            xorwow = [(seed * 2654435761 + 97 * k) & 0xFFFFFFFF for k in range(24)] if seed % 11 == 0 and not dts1 and not gen.both_ids else None
             in_batch = seed % 13 == 0 and xorwow is None
             # every nineteenth script goes through vvm_exec_noalloc where that entry point takes it (no ID instructions, a parameter
             # block of at most 1 KB, no injected generator state); a refusal for one of those reasons sends it through vvm_exec_ex
@@ -327,6 +341,8 @@ def run(first_seed, last_seed, report_every=100):
         for bit, name in ((0x20000, "fits the light kernel"), (0x40000, "two chains in one pass"), (0x80000, "has a lean form (runs when eight-wide is forced)")):
             if info.Flags & bit:
                 shapes[name] = shapes.get(name, 0) + 1
+        if gen.both_ids:
+            shapes["acquire_id and update_id on one dataset"] = shapes.get("acquire_id and update_id on one dataset", 0) + 1
         if xorwow is not None:
             shapes["reference generator"] = shapes.get("reference generator", 0) + 1
         if in_batch:
