@@ -83,38 +83,44 @@ def pre(kind, letter):
     return p + ["v_readlane_b32 s%d, %%[uni], %s" % (s, reg), "s_mov_b32 s%d, s%d" % (s + 1, s), "s_nop 0"]
 
 
+# Instance slots per lane that a routine works on: 8 (the eight-wide kernels: a register is eight consecutive VGPRs) or 4 (the
+# four-wide kernel with 32 registers: four).  Set by main() around each of the two sets of routines; the routines of the two sets lie
+# at the same offsets, so an instruction's routine offset does not depend on the kernel it runs on (its operand bytes do).
+W = 8
+
+
 def mov4(d, s):
-    return ["v_mov_b64 %s, %s" % (r64(d, k), r64(s, k)) for k in (0, 2, 4, 6)]
+    return ["v_mov_b64 %s, %s" % (r64(d, k), r64(s, k)) for k in range(0, W, 2)]
 
 
 def pk4(op, d, p, x, mods=""):
-    return ["%s %s, %s, %s%s" % (op, r64(d, k), r64(p, k), r64(x, k), mods) for k in (0, 2, 4, 6)]
+    return ["%s %s, %s, %s%s" % (op, r64(d, k), r64(p, k), r64(x, k), mods) for k in range(0, W, 2)]
 
 
 def l8(op, d, p, x):
-    return ["%s %s, %s, %s" % (op, r32(d, k), r32(p, k), r32(x, k)) for k in range(8)]
+    return ["%s %s, %s, %s" % (op, r32(d, k), r32(p, k), r32(x, k)) for k in range(W)]
 
 
 def l8_3(op, d, p, x, y):
-    return ["%s %s, %s, %s, %s" % (op, r32(d, k), r32(p, k), r32(x, k), r32(y, k)) for k in range(8)]
+    return ["%s %s, %s, %s, %s" % (op, r32(d, k), r32(p, k), r32(x, k), r32(y, k)) for k in range(W)]
 
 
 def l8_1(op, d, p):
-    return ["%s %s, %s" % (op, r32(d, k), r32(p, k)) for k in range(8)]
+    return ["%s %s, %s" % (op, r32(d, k), r32(p, k)) for k in range(W)]
 
 
 def l8_pk(op, d, p, const):
-    return ["%s %s, %s, %s" % (op, r32(d, k), r32(p, k), const) for k in range(8)]
+    return ["%s %s, %s, %s" % (op, r32(d, k), r32(p, k), const) for k in range(W)]
 
 
 def l8_kp(op, d, const, p):
-    return ["%s %s, %s, %s" % (op, r32(d, k), const, r32(p, k)) for k in range(8)]
+    return ["%s %s, %s, %s" % (op, r32(d, k), const, r32(p, k)) for k in range(W)]
 
 
 def cmp_use8(cmp, use):
-    """four compares into the four result registers, then the four instructions that read them; twice"""
+    """four compares into the four result registers, then the four instructions that read them; once per four slots"""
     out = []
-    for base in (0, 4):
+    for base in range(0, W, 4):
         for j in range(4):
             out += cmp(base + j, MASKS[j])
         for j in range(4):
@@ -180,7 +186,10 @@ def last3(kind, letter, op, d):
     return idx(letter, "SRC2") + l8_3(op, d, d, "Q", "F") if kind == "R" else OFF + l8_3(op, d, d, "Q", S(letter))
 
 
-STORE = ["s_set_gpr_idx_on s[VT_C+7], gpr_idx(DST)"] + mov4("F", "T") + OFF
+def store():
+    return ["s_set_gpr_idx_on s[VT_C+7], gpr_idx(DST)"] + mov4("F", "T") + OFF
+
+
 NEXT = ["s_waitcnt lgkmcnt(0)", "s_load_dwordx8 s[VT_C:VT_C+7], %[prog], %[pc]", "s_add_u32 %[pc], %[pc], 32",
         "s_add_u32 s80, s[VT_NB], s[VT_N+4]", "s_addc_u32 s81, s[VT_NB+1], 0", "s_setpc_b64 s[80:81]"]
 
@@ -381,23 +390,26 @@ def main():
     # (a number that changes whenever a routine moves: the kernels' object file and the host's must have been built from the same table)
     out[out.index("@LAYOUT@")] = "#define VVM_T_LAYOUT 0x%08Xu" % zlib.crc32(("\n".join(rows) + repr(sorted(SLOT.items()))).encode())
     out.append("")
-    out.append("// the routines, placed relative to the label TBL (a string, e.g. \"7b\")")
-    out.append("#define VVM_T_ROUTINES(TBL) \\")
-    chunks = []
+    global W
     count = 0
-    for n in range(1, 6):
+    for W, macro in ((8, "VVM_T_ROUTINES"), (4, "VVM_T4_ROUTINES")):
+      out.append("// the routines for %d instance slots per lane, placed relative to the label TBL (a string, e.g. \"7b\")" % W)
+      out.append("#define %s(TBL) \\" % macro)
+      chunks = []
+      for n in range(1, 6):
         for r, (opcode, _, shape, args) in enumerate(per[n]):
             for m in range((1 << n) - 1):
                 kinds = tuple("U" if (m >> k) & 1 else "R" for k in range(n))
                 if n == 1:
                     kinds = ("R",)
-                lines = body(shape, kinds, args) + STORE + NEXT
+                lines = body(shape, kinds, args) + store() + NEXT
                 off = base[n] + (r * ((1 << n) - 1) + m) * SLOT[n]
                 chunks.append('\t".org " TBL " + %d\\n" /* %s %s */ \\\n%s' % (off, opcode, "".join(kinds), c_string(lines)))
                 count += 1
-    out.append("\n".join(chunks))
-    out.append('\t".org " TBL " + %d\\n"' % total)
-    out.append("")
+      out.append("\n".join(chunks))
+      out.append('\t".org " TBL " + %d\\n"' % total)
+      out.append("")
+    W = 8
     path = os.path.join(HERE, "vvm_threaded_gen.h")
     text = "\n".join(out) + "\n"
     if "--check" in sys.argv:
@@ -406,7 +418,7 @@ def main():
         return 0 if ok else 1
     with open(path, "w") as f:
         f.write(text)
-    print("wrote %s: %d routines, table of %d bytes per instruction buffer" % (path, count, total))
+    print("wrote %s: %d routines (two sets: eight and four instance slots per lane), table of %d bytes per instruction buffer" % (path, count, total))
     return 0
 
 

@@ -3,7 +3,9 @@
 //
 // These kernels run plain scripts (no transcendental / noise / ID instructions, every register resident): the light one, for scripts
 // of eight registers and eight outputs, three workgroups per CU; and the general one, sixteen registers, two datasets, two per CU.
-// Their register file lies in FIXED VGPRs, register-major (the eight instance slots of register i are eight consecutive VGPRs), and
+// The four-wide kernel for plain scripts of 17 to 43 registers (32 of them resident, the rest in LDS slots) has the same tile program
+// with V = 4: its file is the general one's 128 VGPRs as 32 registers of four instance slots.
+// Their register file lies in FIXED VGPRs, register-major (the V instance slots of register i are V consecutive VGPRs), and
 // runs of ordinary instructions are executed by the hand-written routines of vvm_threaded.h; everything else of a tile (stream
 // loads, acquireindex, output staging, the instructions without a routine) is the C++ below, which reaches the file through three
 // small assembly helpers.  The compiler sees the file as three or four opaque vector values that every such statement takes and
@@ -34,30 +36,40 @@ template <bool LIGHT> DEV void file_clear(File8<LIGHT>& F)
 	F.f0 = 0.0f; F.f1 = 0.0f; F.f2 = 0.0f;
 	if constexpr (!LIGHT) F.f3 = 0.0f;
 }
-// the eight instance slots of the register whose first VGPR is FILE + byte (byte = 8 x register index, wave-uniform)
-template <bool LIGHT> DEV void file_read(const File8<LIGHT>& F, uint32_t byte, float (&out)[8])
+// the V instance slots of the register whose first VGPR is FILE + byte (byte = V x register index, wave-uniform)
+template <int V, bool LIGHT> DEV void file_read(const File8<LIGHT>& F, uint32_t byte, float (&out)[V])
 {
-#define F8_READ_TEXT \
-	"s_set_gpr_idx_on %[i], gpr_idx(SRC0)\n v_mov_b32 %0, v[VT_FB+0]\n v_mov_b32 %1, v[VT_FB+1]\n v_mov_b32 %2, v[VT_FB+2]\n v_mov_b32 %3, v[VT_FB+3]\n" \
-	"v_mov_b32 %4, v[VT_FB+4]\n v_mov_b32 %5, v[VT_FB+5]\n v_mov_b32 %6, v[VT_FB+6]\n v_mov_b32 %7, v[VT_FB+7]\n s_set_gpr_idx_off\n"
-	if constexpr (LIGHT)
-		asm volatile(F8L_SET F8_READ_TEXT : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]), "=&v"(out[4]), "=&v"(out[5]), "=&v"(out[6]), "=&v"(out[7])
+#define F8_READ_TEXT4 \
+	"s_set_gpr_idx_on %[i], gpr_idx(SRC0)\n v_mov_b32 %0, v[VT_FB+0]\n v_mov_b32 %1, v[VT_FB+1]\n v_mov_b32 %2, v[VT_FB+2]\n v_mov_b32 %3, v[VT_FB+3]\n"
+#define F8_READ_TEXT8 F8_READ_TEXT4 "v_mov_b32 %4, v[VT_FB+4]\n v_mov_b32 %5, v[VT_FB+5]\n v_mov_b32 %6, v[VT_FB+6]\n v_mov_b32 %7, v[VT_FB+7]\n"
+	if constexpr (V == 4) {
+		static_assert(!LIGHT, "four instance slots: the general file only");
+		asm volatile(F8G_SET F8_READ_TEXT4 "s_set_gpr_idx_off\n" : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]) : [i] "s"(byte), F8G_RO(F) : "scc");
+	} else if constexpr (LIGHT)
+		asm volatile(F8L_SET F8_READ_TEXT8 "s_set_gpr_idx_off\n" : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]), "=&v"(out[4]), "=&v"(out[5]), "=&v"(out[6]), "=&v"(out[7])
 		             : [i] "s"(byte), F8L_RO(F) : "scc");
 	else
-		asm volatile(F8G_SET F8_READ_TEXT : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]), "=&v"(out[4]), "=&v"(out[5]), "=&v"(out[6]), "=&v"(out[7])
+		asm volatile(F8G_SET F8_READ_TEXT8 "s_set_gpr_idx_off\n" : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]), "=&v"(out[4]), "=&v"(out[5]), "=&v"(out[6]), "=&v"(out[7])
 		             : [i] "s"(byte), F8G_RO(F) : "scc");
-#undef F8_READ_TEXT
+#undef F8_READ_TEXT4
+#undef F8_READ_TEXT8
 }
-template <bool LIGHT> DEV void file_write(File8<LIGHT>& F, uint32_t byte, const float (&in)[8])
+template <int V, bool LIGHT> DEV void file_write(File8<LIGHT>& F, uint32_t byte, const float (&in)[V])
 {
-#define F8_WRITE_TEXT \
-	"s_set_gpr_idx_on %[i], gpr_idx(DST)\n v_mov_b32 v[VT_FB+0], %[a0]\n v_mov_b32 v[VT_FB+1], %[a1]\n v_mov_b32 v[VT_FB+2], %[a2]\n v_mov_b32 v[VT_FB+3], %[a3]\n" \
-	"v_mov_b32 v[VT_FB+4], %[a4]\n v_mov_b32 v[VT_FB+5], %[a5]\n v_mov_b32 v[VT_FB+6], %[a6]\n v_mov_b32 v[VT_FB+7], %[a7]\n s_set_gpr_idx_off\n"
-#define F8_WRITE_IN [i] "s"(byte), [a0] "v"(in[0]), [a1] "v"(in[1]), [a2] "v"(in[2]), [a3] "v"(in[3]), [a4] "v"(in[4]), [a5] "v"(in[5]), [a6] "v"(in[6]), [a7] "v"(in[7])
-	if constexpr (LIGHT) asm volatile(F8L_SET F8_WRITE_TEXT : F8L_RW(F) : F8_WRITE_IN : "scc");
-	else asm volatile(F8G_SET F8_WRITE_TEXT : F8G_RW(F) : F8_WRITE_IN : "scc");
-#undef F8_WRITE_TEXT
-#undef F8_WRITE_IN
+#define F8_WRITE_TEXT4 \
+	"s_set_gpr_idx_on %[i], gpr_idx(DST)\n v_mov_b32 v[VT_FB+0], %[a0]\n v_mov_b32 v[VT_FB+1], %[a1]\n v_mov_b32 v[VT_FB+2], %[a2]\n v_mov_b32 v[VT_FB+3], %[a3]\n"
+#define F8_WRITE_TEXT8 F8_WRITE_TEXT4 "v_mov_b32 v[VT_FB+4], %[a4]\n v_mov_b32 v[VT_FB+5], %[a5]\n v_mov_b32 v[VT_FB+6], %[a6]\n v_mov_b32 v[VT_FB+7], %[a7]\n"
+#define F8_WRITE_IN4 [i] "s"(byte), [a0] "v"(in[0]), [a1] "v"(in[1]), [a2] "v"(in[2]), [a3] "v"(in[3])
+	if constexpr (V == 4) {
+		static_assert(!LIGHT, "four instance slots: the general file only");
+		asm volatile(F8G_SET F8_WRITE_TEXT4 "s_set_gpr_idx_off\n" : F8G_RW(F) : F8_WRITE_IN4 : "scc");
+	} else if constexpr (LIGHT)
+		asm volatile(F8L_SET F8_WRITE_TEXT8 "s_set_gpr_idx_off\n" : F8L_RW(F) : F8_WRITE_IN4, [a4] "v"(in[4]), [a5] "v"(in[5]), [a6] "v"(in[6]), [a7] "v"(in[7]) : "scc");
+	else
+		asm volatile(F8G_SET F8_WRITE_TEXT8 "s_set_gpr_idx_off\n" : F8G_RW(F) : F8_WRITE_IN4, [a4] "v"(in[4]), [a5] "v"(in[5]), [a6] "v"(in[6]), [a7] "v"(in[7]) : "scc");
+#undef F8_WRITE_TEXT4
+#undef F8_WRITE_TEXT8
+#undef F8_WRITE_IN4
 }
 
 // Runs the program from byte offset `pc` on: every ordinary instruction that has a routine (vvm_threaded.h), until one that has
@@ -69,7 +81,7 @@ template <bool LIGHT> DEV void file_write(File8<LIGHT>& F, uint32_t byte, const 
 #define F8_LEAVE(C) \
 	"s_mov_b32 %[x0], s[" C "+0]\n s_mov_b32 %[x1], s[" C "+1]\n s_mov_b32 %[x2], s[" C "+2]\n s_mov_b32 %[x3], s[" C "+3]\n" \
 	"s_getpc_b64 s[80:81]\n 2:\n s_add_u32 s80, s80, 9f - 2b\n s_addc_u32 s81, s81, 0\n s_setpc_b64 s[80:81]\n"
-#define F8_RUN_TEXT \
+#define F8_RUN_TEXT(ROUTINES) \
 	"s_getpc_b64 s[76:77]\n 1:\n" \
 	"s_add_u32 s78, s76, 8f - 1b\n s_addc_u32 s79, s77, 0\n" \
 	"s_add_u32 s76, s76, 7f - 1b\n s_addc_u32 s77, s77, 0\n" \
@@ -78,39 +90,68 @@ template <bool LIGHT> DEV void file_write(File8<LIGHT>& F, uint32_t byte, const 
 	"s_waitcnt lgkmcnt(0)\n" \
 	"s_add_u32 s80, s76, s64\n s_addc_u32 s81, s77, 0\n s_setpc_b64 s[80:81]\n" \
 	".p2align 8\n 7:\n" F8_LEAVE("60") \
-	".set VT_C, 60\n .set VT_N, 68\n .set VT_NB, 78\n" VVM_T_ROUTINES("7b") \
+	".set VT_C, 60\n .set VT_N, 68\n .set VT_NB, 78\n" ROUTINES("7b") \
 	".p2align 8\n 8:\n" F8_LEAVE("68") \
-	".set VT_C, 68\n .set VT_N, 60\n .set VT_NB, 76\n" VVM_T_ROUTINES("8b") \
+	".set VT_C, 68\n .set VT_N, 60\n .set VT_NB, 76\n" ROUTINES("8b") \
 	"9:\n s_waitcnt lgkmcnt(0)\n s_sub_u32 %[pc], %[pc], 32\n"
-template <bool LIGHT> DEV void run_ordinary8(File8<LIGHT>& F, const void* prog, uint32_t& pc, uint32_t uni, uint32_t (&x)[4])
+template <int V, bool LIGHT> DEV void run_ordinary8(File8<LIGHT>& F, const void* prog, uint32_t& pc, uint32_t uni, uint32_t (&x)[4])
 {
-	if constexpr (LIGHT)
-		asm volatile(F8L_SET F8_RUN_TEXT : [pc] "+s"(pc), [x0] "=&s"(x[0]), [x1] "=&s"(x[1]), [x2] "=&s"(x[2]), [x3] "=&s"(x[3]), F8L_RW(F)
+	if constexpr (V == 4)
+		asm volatile(F8G_SET F8_RUN_TEXT(VVM_T4_ROUTINES) : [pc] "+s"(pc), [x0] "=&s"(x[0]), [x1] "=&s"(x[1]), [x2] "=&s"(x[2]), [x3] "=&s"(x[3]), F8G_RW(F)
+		             : [prog] "s"(prog), [uni] "v"(uni) : F8G_TEMPS, F8_SGPRS, "memory");
+	else if constexpr (LIGHT)
+		asm volatile(F8L_SET F8_RUN_TEXT(VVM_T_ROUTINES) : [pc] "+s"(pc), [x0] "=&s"(x[0]), [x1] "=&s"(x[1]), [x2] "=&s"(x[2]), [x3] "=&s"(x[3]), F8L_RW(F)
 		             : [prog] "s"(prog), [uni] "v"(uni) : F8L_TEMPS, F8_SGPRS, "memory");
 	else
-		asm volatile(F8G_SET F8_RUN_TEXT : [pc] "+s"(pc), [x0] "=&s"(x[0]), [x1] "=&s"(x[1]), [x2] "=&s"(x[2]), [x3] "=&s"(x[3]), F8G_RW(F)
+		asm volatile(F8G_SET F8_RUN_TEXT(VVM_T_ROUTINES) : [pc] "+s"(pc), [x0] "=&s"(x[0]), [x1] "=&s"(x[1]), [x2] "=&s"(x[2]), [x3] "=&s"(x[3]), F8G_RW(F)
 		             : [prog] "s"(prog), [uni] "v"(uni) : F8G_TEMPS, F8_SGPRS, "memory");
 }
 
+// Registers of a four-wide program beyond the 32 of the file live in LDS slots, [slot][thread] (the compiled kernels' reg_read /
+// reg_spill): instructions that touch one have no routine.  (A program of at most sixteen registers that runs four-wide, for its
+// second chain, keeps the eight VGPRs per register it is encoded with and uses four of them: Ctx::reg_shift.)
+#define VVM_FILE4_REGS 32u
 // operand fetch for the C++ side (the class and the index are wave-uniform)
-template <bool LIGHT> DEV void fetch8(const File8<LIGHT>& F, uint32_t uni, const Ctx& c, uint32_t o, float (&out)[8])
+template <int V, bool LIGHT> DEV void fetch8(const File8<LIGHT>& F, uint32_t uni, const Ctx& c, uint32_t o, float (&out)[V])
 {
 	if (o < (1u << 13)) {                       // VVM_OPC_VREG
-		file_read<LIGHT>(F, (o & 31u) * 8u, out);
+		if constexpr (V == 8) {
+			file_read<8, LIGHT>(F, (o & 31u) * 8u, out);
+		} else {
+			if (o < VVM_FILE4_REGS) {
+				file_read<4, LIGHT>(F, o << c.reg_shift, out);
+			} else {
+				const f4a v = *(const f4a*)(c.spill + ((o - VVM_FILE4_REGS) * VVM_BLOCK_THREADS + c.tid) * 4u);
+				out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+			}
+		}
 	} else if (o < (2u << 13)) {                // VVM_OPC_UNIF
 		const float v = bitsf((uint32_t)__builtin_amdgcn_readlane((int)uni, (int)(o & 63u)));
 #pragma unroll
-		for (int k = 0; k < 8; ++k) out[k] = v;
+		for (int k = 0; k < V; ++k) out[k] = v;
 	} else {
-		fetch_slow<8>(c, o, out);
+		fetch_slow<V>(c, o, out);
+	}
+}
+// the V values of a result to register `idx` of the program
+template <int V, bool LIGHT> DEV void store8(File8<LIGHT>& F, const Ctx& c, uint32_t idx, const float (&in)[V])
+{
+	if constexpr (V == 8) {
+		file_write<8, LIGHT>(F, (idx & 31u) * 8u, in);
+	} else {
+		if (idx < VVM_FILE4_REGS) {
+			file_write<4, LIGHT>(F, idx << c.reg_shift, in);
+		} else {
+			f4a v; v.x = in[0]; v.y = in[1]; v.z = in[2]; v.w = in[3];
+			*(f4a*)(c.spill + ((idx - VVM_FILE4_REGS) * VVM_BLOCK_THREADS + c.tid) * 4u) = v;
+		}
 	}
 }
 
 // One ordinary instruction that has no routine (an op without one, or an operand that is neither a register of the file nor a uniform
 // register), by the same cases as the other kernels' interpreter loop.
-template <bool LIGHT> DEV void exec_ordinary8(File8<LIGHT>& F, uint32_t uni, const Ctx& c, const uint32_t (&w)[4])
+template <int V, bool LIGHT> DEV void exec_ordinary8(File8<LIGHT>& F, uint32_t uni, const Ctx& c, const uint32_t (&w)[4])
 {
-	constexpr int V = 8;
 	constexpr bool FULL = false;
 	const uint32_t op = w[0] & 0xFFu, nin = (w[0] >> 8) & 7u, aux = (w[0] >> 16) & 0xFFu, aux2 = w[0] >> 24;
 	const uint32_t o[5] = {w[1] & 0xFFFFu, w[1] >> 16, w[2] & 0xFFFFu, w[2] >> 16, w[3] & 0xFFFFu};
@@ -119,11 +160,11 @@ template <bool LIGHT> DEV void exec_ordinary8(File8<LIGHT>& F, uint32_t uni, con
 	float a[V], b[V], cc[V], dd[V], ee[V], r[V];
 #pragma unroll
 	for (int k = 0; k < V; ++k) { a[k] = b[k] = cc[k] = dd[k] = ee[k] = 0.0f; r[k] = 0.0f; }
-	if (nin >= 1) fetch8<LIGHT>(F, uni, c, o[0], a);
-	if (nin >= 2) fetch8<LIGHT>(F, uni, c, o[1], b);
-	if (nin >= 3) fetch8<LIGHT>(F, uni, c, o[2], cc);
-	if (nin >= 4) fetch8<LIGHT>(F, uni, c, o[3], dd);
-	if (nin >= 5) fetch8<LIGHT>(F, uni, c, o[4], ee);
+	if (nin >= 1) fetch8<V, LIGHT>(F, uni, c, o[0], a);
+	if (nin >= 2) fetch8<V, LIGHT>(F, uni, c, o[1], b);
+	if (nin >= 3) fetch8<V, LIGHT>(F, uni, c, o[2], cc);
+	if (nin >= 4) fetch8<V, LIGHT>(F, uni, c, o[3], dd);
+	if (nin >= 5) fetch8<V, LIGHT>(F, uni, c, o[4], ee);
 	uint32_t inst_i = c.inst0;
 	asm volatile("" : "+v"(inst_i));
 #define LANES for (int k = 0; k < V; ++k)
@@ -162,18 +203,20 @@ template <bool LIGHT> DEV void exec_ordinary8(File8<LIGHT>& F, uint32_t uni, con
 #undef SETF
 #undef SETI
 #undef SETM
-	file_write<LIGHT>(F, (VVM_OPND_IDX(dst) & 31u) * 8u, r);
+	store8<V, LIGHT>(F, c, VVM_OPND_IDX(dst), r);
 }
 
 // One tile of eight instances per lane: two halves of 1024 instances, lane t holding instances [4 t, 4 t + 4) of each (slots 0..3 and
-// 4..7), so that every stream access is a 128-bit access of four consecutive instances.  Same steps as run_tile.
-template <bool LIGHT>
+// 4..7), so that every stream access is a 128-bit access of four consecutive instances.  Same steps as run_tile.  (V = 4: one such
+// half, the tile of the four-wide kernels.)
+template <int V, bool LIGHT>
 DEV void run_tile8(const void* prog_in, gu64* status, bool last_tile, const Ctx& c, unsigned char* lds, uint32_t tile_local, uint32_t tag, VvmLaunchState* ls, uint32_t dbg, Pending& pend,
                    uint32_t& resolves, const u64 (&pre)[VVM_LB_WORDS_PER_LANE], bool have_pre, File8<LIGHT>& F)
 {
-	constexpr int V = 8;
+	static_assert(V == 8 || (V == 4 && !LIGHT), "eight instance slots, or four on the general file");
 	constexpr bool FULL = false;
-	constexpr bool TWO = !LIGHT;      // the general kernel runs two acquired datasets in one pass
+	constexpr bool TWO = !LIGHT;      // the general kernels run two acquired datasets in one pass
+	constexpr int HALVES = V == 8 ? 2 : 1;
 	// (the program's address as a value of unknown origin: otherwise the compiler, short of scalar registers, loads it from the Exec's
 	// descriptor again in front of every entry into the routines and waits for that load)
 	const void* prog = prog_in;
@@ -236,7 +279,7 @@ DEV void run_tile8(const void* prog_in, gu64* status, bool last_tile, const Ctx&
 			}
 			// (slots past the count write zeros to the last used slot's register, from the last one down: plain writes, no branch)
 #pragma unroll
-			for (int j = 7; j >= 0; --j) file_write<LIGHT>(F, ((first_reg + min((uint32_t)j, cnt - 1u)) & 31u) * 8u, st[j]);
+			for (int j = 7; j >= 0; --j) store8<V, LIGHT>(F, c, first_reg + min((uint32_t)j, cnt - 1u), st[j]);
 		}
 	}
 
@@ -255,15 +298,12 @@ DEV void run_tile8(const void* prog_in, gu64* status, bool last_tile, const Ctx&
 	}
 	const u64 tl1 = (dbg & 128u) ? __builtin_amdgcn_s_memtime() : 0;
 	uint32_t pc = pc0 * VVM_INS_STRIDE;
-	// The stream loads are waited for HERE, once.  Left to the compiler, the wait lands in front of the routines' entry inside the loop
-	// below (the file is their operand), where it also runs after an acquireindex, when the only vector memory operations in flight are
-	// the previous tile's output stores, issued a moment ago: the tile would stand still until those have drained.
 	for (;;) {
 		uint32_t x[4];
-		run_ordinary8<LIGHT>(F, prog, pc, uni, x);
+		run_ordinary8<V, LIGHT>(F, prog, pc, uni, x);
 		const uint32_t op = x[0] & 0xFFu, aux = (x[0] >> 16) & 0xFFu, aux2 = x[0] >> 24;
 		if (((x[0] >> 8) & 7u) != VVM_NIN_SPECIAL) {
-			exec_ordinary8<LIGHT>(F, uni, c, x);
+			exec_ordinary8<V, LIGHT>(F, uni, c, x);
 			continue;
 		}
 		const uint32_t o0 = x[1] & 0xFFFFu, o1 = x[1] >> 16, o2 = x[2] & 0xFFFFu, o4 = x[3] & 0xFFFFu, o5 = x[3] >> 16;
@@ -272,10 +312,10 @@ DEV void run_tile8(const void* prog_in, gu64* status, bool last_tile, const Ctx&
 			// sign bit of the predicate = keep (VectorVMRuntime.cpp:838-841); instances past the end never survive (:846-857).  aux2 != 0: the
 			// compare that made the predicate is folded in: keep = o0 <cmp> o1
 			float p[V];
-			fetch8<LIGHT>(F, uni, c, o0, p);
+			fetch8<V, LIGHT>(F, uni, c, o0, p);
 			if (aux2 != VVM_ACQ_SIGN) {
 				float q[V];
-				fetch8<LIGHT>(F, uni, c, o1, q);
+				fetch8<V, LIGHT>(F, uni, c, o1, q);
 #define ACQ_CMP(expr) { _Pragma("unroll") for (int k = 0; k < V; ++k) { const float A = p[k], B = q[k]; const int32_t IA = (int32_t)fbits(A), IB = (int32_t)fbits(B); (void)IA; (void)IB; p[k] = mask(expr); } } break
 				switch (aux2) {
 				case VVM_ACQ_LT: ACQ_CMP(A < B);
@@ -298,7 +338,7 @@ DEV void run_tile8(const void* prog_in, gu64* status, bool last_tile, const Ctx&
 			for (int k = 0; k < V; ++k)
 				kb |= ((fbits(p[k]) >> 31) & ((c.inst0 + slot_offset<V>(k) < c.num_instances) ? 1u : 0u)) << k;
 			const uint32_t chain = TWO ? aux : 0u;
-			const uint3 rt = acquire_rank_and_publish<2>(kb, c, lds_ctrl, status + (size_t)chain * exec_tiles, tile_local, tag, dbg, chain);
+			const uint3 rt = acquire_rank_and_publish<HALVES>(kb, c, lds_ctrl, status + (size_t)chain * exec_tiles, tile_local, tag, dbg, chain);
 			if (TWO && chain) { u_keep = kb; u_rank = rt.x; u_rank_b = rt.y; u_total = SCALAR(rt.z); u_pending = true; }
 			else if constexpr (LIGHT) { kw_new = kb | (rt.x << 8) | (rt.y << 20); t_total = SCALAR(rt.z); t_pending = true; }
 			else { t_keep = kb; t_rank = rt.x; t_rank_b = rt.y; t_total = SCALAR(rt.z); t_pending = true; }
@@ -366,7 +406,7 @@ DEV void run_tile8(const void* prog_in, gu64* status, bool last_tile, const Ctx&
 			uint64_t srcs = (uint64_t)o0 | ((uint64_t)o1 << 16) | ((uint64_t)o2 << 32);
 			for (uint32_t j = 0; j < aux; ++j, srcs >>= 16, slot += VVM_BLOCK_THREADS * V) {
 				float v[V];
-				fetch8<LIGHT>(F, uni, c, (uint32_t)srcs & 0xFFFFu, v);
+				fetch8<V, LIGHT>(F, uni, c, (uint32_t)srcs & 0xFFFFu, v);
 				if (kind & 1u) {
 					if (kind == 1) {
 #pragma unroll
@@ -378,13 +418,13 @@ DEV void run_tile8(const void* prog_in, gu64* status, bool last_tile, const Ctx&
 				}
 				if (all_alive) {
 					{ f4a q; q.x = v[0]; q.y = v[1]; q.z = v[2]; q.w = v[3]; *(f4a*)(slot + c.tid * 4) = q; }
-					{ f4a q; q.x = v[4]; q.y = v[5]; q.z = v[6]; q.w = v[7]; *(f4a*)(slot + VVM_HALF_TILE + c.tid * 4) = q; }
+					if constexpr (V == 8) { f4a q; q.x = v[4]; q.y = v[5]; q.z = v[6]; q.w = v[7]; *(f4a*)(slot + VVM_HALF_TILE + c.tid * 4) = q; }
 				} else {
 					// survivor j of the lane goes to rank + j; a dead instance's value goes to the thread's sink dword (no per-lane branch)
 					uint32_t r = o_rank;
 #pragma unroll
 					for (int k = 0; k < V; ++k) {
-						if (k == 4) r = o_rank_b;
+						if (V == 8 && k == 4) r = o_rank_b;
 						const bool keep = (o_keep >> k) & 1u;
 						float* q = keep ? (slot + r) : sink;
 						*q = v[k];
@@ -406,9 +446,9 @@ DEV void run_tile8(const void* prog_in, gu64* status, bool last_tile, const Ctx&
 	pend.unresolved = t_pending; pend.total = t_total; pend.base = t_base; pend.stage_end = stage_end; pend.last = last_tile;
 	pend.tile_local = tile_local; pend.status = status; pend.out_list = c.out_list;
 	pend.ride = LIGHT ? 0u : (t_keep | (t_rank << 8) | (t_rank_b << 20));
-	if constexpr (!LIGHT) {
+	if constexpr (!LIGHT && V == 8) {
 		// the lane's acquireindex result for vvm_through_kernel, straight from the tile that made it (the light kernel keeps the word for
-		// its riding outputs and stores it in store_tile)
+		// its riding outputs and stores it in store_tile; a four-wide program of many registers hands no streams through)
 		const uint64_t ride_base = sload64(c.out_list - 3, 0);
 		if (ride_base != 0) {
 			const rsrc_t rr = make_rsrc(ride_base + (uint64_t)tile_local * (VVM_BLOCK_THREADS * 4u), VVM_BLOCK_THREADS * 4u);

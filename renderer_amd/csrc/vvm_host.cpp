@@ -268,11 +268,13 @@ namespace {
 // The program as it lies in device memory (VvmDevIns): the linker's instructions, each followed by what the hand-written core of the
 // eight-wide kernels executes from (vvm_threaded.h): the routine for the instruction's op and operand kinds, and its operands as bytes.
 // An instruction gets a routine when it is an ordinary one whose op has routines, whose operands are per-lane registers of the file
-// (light program: eight registers and the two riding ones; otherwise sixteen) or uniform registers, not all of them uniform, and
+// (light program: eight registers and the two riding ones; a program of many registers: 32; otherwise sixteen) or uniform registers, not all of them uniform, and
 // whose destination is a register of the file.  The other kernels read the linker's four words only.
 void encode_device_program(const vvm::LinkedProgram& lp, std::vector<VvmDevIns>& out)
 {
-	const uint32_t file_regs = lp.light ? VVM_LIGHT_RIDE_REG + 2u : 16u;
+	// (a program of more than sixteen registers runs four instances per lane: its registers are four VGPRs each, VVM_DESC_REGS_OF_4)
+	const uint32_t file_regs = lp.light ? VVM_LIGHT_RIDE_REG + 2u : lp.many_registers ? 32u : 16u;
+	const uint32_t vgprs_per_reg = lp.many_registers ? 4u : 8u;
 	out.clear();
 	out.reserve(lp.code.size() + 1);
 	for (const VvmIns& k : lp.code) {
@@ -284,7 +286,7 @@ void encode_device_program(const vvm::LinkedProgram& lp, std::vector<VvmDevIns>&
 			bool ok = VVM_OPND_CLS(o[5]) == VVM_OPC_VREG && VVM_OPND_IDX(o[5]) < file_regs;
 			for (uint32_t i = 0; i < nin && ok; ++i) {
 				const uint32_t cls = VVM_OPND_CLS(o[i]), idx = VVM_OPND_IDX(o[i]);
-				if (cls == VVM_OPC_VREG && idx < file_regs) byte[i] = idx * 8u;
+				if (cls == VVM_OPC_VREG && idx < file_regs) byte[i] = idx * vgprs_per_reg;
 				else if (cls == VVM_OPC_UNIF && idx < VVM_MAX_UNIFORMS) { byte[i] = idx; uniform_mask |= 1u << i; }
 				else ok = false;
 			}
@@ -293,7 +295,7 @@ void encode_device_program(const vvm::LinkedProgram& lp, std::vector<VvmDevIns>&
 				d.routine = routine;
 				d.opnds = byte[0] | byte[2] << 8 | byte[3] << 16 | byte[4] << 24;
 				d.opnd_b = byte[1];
-				d.dst = VVM_OPND_IDX(o[5]) * 8u;
+				d.dst = VVM_OPND_IDX(o[5]) * vgprs_per_reg;
 			}
 		}
 		out.push_back(d);
@@ -706,7 +708,7 @@ int fill_params(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* op
 	d->rand_instance_base = (opt ? opt->RandInstanceBase : 0) + (int32_t)pe.chunk_first;
 	d->rand_words = pe.reference_random ? st->d_rand_words : nullptr;
 	d->rand_stride = pe.reference_random ? st->rand_stride : 0;
-	d->flags = (lp.uses_perlin ? VVM_DESC_USES_PERLIN : 0) | (dev_block ? 0 : VVM_DESC_RELATIVE);
+	d->flags = (lp.uses_perlin ? VVM_DESC_USES_PERLIN : 0) | (dev_block ? 0 : VVM_DESC_RELATIVE) | (lp.many_registers ? VVM_DESC_REGS_OF_4 : 0);
 	d->num_unif = std::min<uint32_t>((s.num_consts + (uint32_t)lp.derived.size() + 3u) & ~3u, VVM_MAX_UNIFORMS);
 
 	uint32_t* consts = (uint32_t*)(host + pe.off_consts);

@@ -555,6 +555,7 @@ struct Ctx {
 	uint32_t tile_first;          // index of the tile's first instance
 	uint32_t valid;               // instances of the tile that exist (the Exec's last tile may be partial)
 	uint32_t phase;               // tiles this workgroup has started; its parity selects the LDS word of double-buffered exchanges
+	uint32_t reg_shift;           // four-wide kernel with the hand-written routines: log2 of the VGPRs per register of the Exec's program (VVM_DESC_REGS_OF_4)
 };
 
 // The 32 random bits of draw `ordinal` for instance `inst` of the Exec: from the words laid out by vvm_xorwow_fill_kernel when the
@@ -1696,8 +1697,9 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (IS_LIGHT(V, SPILL) ? 3 : V
 	float* lds_spill = (float*)(lds + LDS_SPILL_OFF(V, FULL, IS_LIGHT(V, SPILL)));
 	// (eight instances per lane: the register file, in fixed VGPRs from here to the end of the kernel; the light kernel's riding outputs
 	// wait in it from one tile to the next)
+	constexpr bool THREADED = V == 8 || (V == 4 && SPILL && !FULL);      // the kernels whose tile program is run_tile8
 	File8<IS_LIGHT(V, SPILL)> file8;
-	if constexpr (V == 8) file_clear<IS_LIGHT(V, SPILL)>(file8);
+	if constexpr (THREADED) file_clear<IS_LIGHT(V, SPILL)>(file8);
 	Pending pend;
 	pend.active = false; pend.unresolved = false; pend.last = false; pend.total = 0; pend.base = 0; pend.stage_end = 0; pend.tile_local = 0;
 	pend.status = nullptr; pend.out_list = nullptr; pend.ride = 0;
@@ -1801,9 +1803,10 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (IS_LIGHT(V, SPILL) ? 3 : V
 		c.tile_first = tile_first;
 		c.valid = min(num_instances - tile_first, (uint32_t)(VVM_BLOCK_THREADS * V));
 		c.phase = FULL ? started++ : phase;      // (tiles this workgroup has started: with fused passes more than one per ticket)
+		c.reg_shift = (THREADED && V == 4 && (DESC_U32(dp, flags) & VVM_DESC_REGS_OF_4)) ? 2u : 3u;
 		if (!(dbgw & 1u)) {
-			if constexpr (V == 8)
-				run_tile8<IS_LIGHT(V, SPILL)>((const void*)DESC_PTR(dp, prog), (gu64*)DESC_PTR(dp, status), last_tile, c, lds, tile_local, tag, env.ls, dbgw, pend, resolves, pre, have_pre && first_pass, file8);
+			if constexpr (THREADED)
+				run_tile8<V, IS_LIGHT(V, SPILL)>((const void*)DESC_PTR(dp, prog), (gu64*)DESC_PTR(dp, status), last_tile, c, lds, tile_local, tag, env.ls, dbgw, pend, resolves, pre, have_pre && first_pass, file8);
 			else
 				run_tile<V, SPILL, FULL, RIDE>((const VvmIns*)DESC_PTR(dp, prog), (gu64*)DESC_PTR(dp, status), last_tile, c, lds, tile_local, tag, env.ls, dbgw, pend, resolves, pre, have_pre && first_pass);
 		}
@@ -1813,7 +1816,7 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (IS_LIGHT(V, SPILL) ? 3 : V
 	if (pend.active) {
 		Ctx c;
 		c.dp = nullptr; c.rel = 0; c.consts = nullptr; c.out_list = nullptr; c.spill = lds_spill;
-		c.tid = tid; c.wave = wave; c.inst0 = 0; c.num_instances = 0; c.tile_first = 0; c.valid = 0; c.phase = 0;
+		c.tid = tid; c.wave = wave; c.inst0 = 0; c.num_instances = 0; c.tile_first = 0; c.valid = 0; c.phase = 0; c.reg_shift = 3u;
 		const u64 none[VVM_LB_WORDS_PER_LANE] = {};
 		resolve_tile<V, HAS_TWO_CHAINS(V, SPILL, FULL)>(pend, c, lds_ctrl, resolves, tag, env.ls, dbgw, none, false);
 		float ride[16];

@@ -1,6 +1,7 @@
-"""Every hand-written routine of the eight-wide kernels against the oracle: each op that has routines, with every combination of
-operand kinds (per-lane register / uniform register) a routine exists for, executed from both instruction buffers, on the general
-eight-wide kernel and, where the script fits it, on the light one.  Bit for bit (NaN payloads aside)."""
+"""Every hand-written routine of the kernels that have them against the oracle: each op that has routines, with every combination
+of operand kinds (per-lane register / uniform register) a routine exists for, executed from both instruction buffers, on the general
+eight-wide kernel and, where the script fits it, on the light one; and the routines for four instance slots per register, on the
+four-wide kernel that scripts of more than sixteen registers run on.  Bit for bit (NaN payloads aside)."""
 import importlib.util
 import os
 import struct
@@ -12,7 +13,8 @@ from op_cases import operand_streams
 from renderer_amd import abi, opcodes
 from renderer_amd.assembler import FLOAT, Script
 from renderer_amd.opcodes import INT_OPS, OPS
-from test_gpu_eight_wide import _check8
+from test_gpu_eight_wide import _check8, _compare8
+from vm_harness import run_hip, run_oracle
 
 pytestmark = pytest.mark.gpu
 f32 = np.float32
@@ -39,7 +41,10 @@ def constants(name, which):
     return struct.pack("<I", 0xFFFFFFFF) + vals + struct.pack("<I", 0xFFFFFFFF if which == 0 else 0) + bytes(4)
 
 
-def script_for(name, nin, mask):
+PADS = 18      # values kept alive across the tested instructions: more than the sixteen registers of the eight-wide file
+
+
+def script_for(name, nin, mask, many=False):
     s = Script()
     ones = s.const(0)
     operands, streams = [], 0
@@ -51,10 +56,24 @@ def script_for(name, nin, mask):
             operands.append(s.input(0, FLOAT, streams))
             streams += 1
     s.acquireindex(ones, 0)
+    pads = []
+    if many:
+        first_stream = next(o for k, o in enumerate(operands) if not (mask >> k) & 1)
+        pads = s.temps(PADS)
+        for i, p in enumerate(pads):
+            s.op("bit_xor", first_stream if i == 0 else pads[i - 1], s.const(1 + i % 5), p)
     t = s.temps(2)
     s.op(name, *operands, t[0])
     s.op(name, *operands, t[1])      # (the second one executes from the other instruction buffer)
-    s.output_data(FLOAT, 0, [(t[0], s.output(0, FLOAT, 0)), (t[1], s.output(0, FLOAT, 1))])
+    pairs = [(t[0], s.output(0, FLOAT, 0)), (t[1], s.output(0, FLOAT, 1))]
+    if many:
+        acc = pads[0]
+        for p in pads[1:]:
+            nxt = s.temp()
+            s.op("bit_or", acc, p, nxt)
+            acc = nxt
+        pairs.append((acc, s.output(0, FLOAT, 2)))
+    s.output_data(FLOAT, 0, pairs)
     return s.build(), streams
 
 
@@ -73,3 +92,25 @@ def test_every_routine_of_the_op(name, nin):
         ins = operand_streams(name, streams, n, seed=11 + mask)
         for which in (0, 1):
             _check8(built, [constants(name, which)], ins, [f32, f32], n)
+
+
+@pytest.mark.parametrize("name,nin", routine_ops(), ids=[n for n, _ in routine_ops()])
+def test_every_routine_of_the_op_four_slots(name, nin):
+    """the same with eighteen more values alive across the tested instructions: the script runs four instances per lane on the
+    kernel with 32 registers, whose routines work on four VGPRs per register"""
+    be = abi.load_hip_backend()
+    code_of_op = opcodes.CODE[name]
+    n = 1300      # two tiles of the four-wide kernels, the second one partial
+    for mask in range((1 << nin) - 1):
+        built, streams = script_for(name, nin, mask, many=True)
+        dev = be.inspect_device_code(built.blob, 0)
+        with_routine = [d for d in dev if (d[0] & 0xFF) == code_of_op and ((d[0] >> 8) & 7) == nin and d[4] != 0]
+        assert len(with_routine) >= 2, "%s mask %d: the program does not run the op in a routine twice" % (name, mask)      # (the fill uses two of the ops itself)
+        assert max(d[7] for d in with_routine) >= 4 * 16, "the results lie in the registers the eight-wide file has as well"
+        ins = operand_streams(name, streams, n, seed=11 + mask)
+        for which in (0, 1):
+            consts = [constants(name, which)]
+            ref, ref_n, _ = run_oracle(built, consts, ins, [f32] * 3, n)
+            got, got_n, info = run_hip(built, consts, ins, [f32] * 3, n)
+            assert info.InstancesPerLane == 4 and info.NumVirtualRegisters > 16 and info.LdsSpillRegisters == 0
+            _compare8(got, got_n, ref, ref_n, n, {})

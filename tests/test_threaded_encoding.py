@@ -46,11 +46,33 @@ def test_routines_fit_their_slots_and_do_not_overlap():
     assert all(off % 4 == 0 for off, _ in spans)
 
 
+def many_register_script(n_temps):
+    """more values alive at once than the sixteen registers of the eight-wide file: such a program runs four instances per lane on
+    32 registers of four VGPRs each (n_temps > 31: some registers in LDS slots, instructions that touch one have no routine)"""
+    from renderer_amd.assembler import FLOAT, Script
+    s = Script()
+    s.acquireindex(s.const(0), 0)
+    x = s.input(0, FLOAT, 0)
+    ts = s.temps(n_temps)
+    for i, t in enumerate(ts):
+        s.op("mad", x if i == 0 else ts[i - 1], s.const(1), s.const(2), t)
+    acc = s.temp()
+    s.op("add", ts[0], ts[1], acc)
+    for t in ts[2:]:
+        nxt = s.temp()
+        s.op("mul_add", acc, s.const(3), t, nxt)
+        acc = nxt
+    s.output_data(FLOAT, 0, [(acc, s.output(0, FLOAT, 0)), (ts[5], s.output(0, FLOAT, 1))])
+    return s.build()
+
+
 def programs():
     out = [("fountain", scripts.fountain().script), ("fountain_unmerged", scripts.fountain(merged=False).script),
            ("transcendental", scripts.transcendental().script)]
     for v in (1, 7, 22, 63):
         out.append(("fountain_v%d" % v, scripts.fountain(variant=v).script))
+    out.append(("registers_24", many_register_script(24)))
+    out.append(("registers_40", many_register_script(40)))
     return out
 
 
@@ -68,7 +90,9 @@ def test_device_program_names_the_right_routines(name, script, narrow):
     plain = be.inspect_code(blob, narrow)
     g = generator()
     first, slot, total = routine_offsets(g)
-    file_regs = 10 if narrow == 2 else 16
+    many = name.startswith("registers_")
+    file_regs = 10 if narrow == 2 else 32 if many else 16
+    vgprs = 4 if many else 8      # VGPRs per register: the instance slots of the kernel the program runs on
     assert len(dev) == len(plain) + 1
     assert [d[:4] for d in dev[:-1]] == [tuple(p) for p in plain]
     assert dev[-1][0] & 0xFF == opcodes.CODE["done"] and (dev[-1][0] >> 8) & 7 == 7 and dev[-1][4] == 0
@@ -89,9 +113,11 @@ def test_device_program_names_the_right_routines(name, script, narrow):
         mask = sum(1 << k for k in range(nin) if kinds[k][0] == 1)
         assert routine == first[key] + mask * slot[nin], (key, mask)
         assert 256 <= routine < total
-        byte = [(i if c == 1 else 8 * i) for c, i in kinds[:nin]] + [0] * (5 - nin)
+        byte = [(i if c == 1 else vgprs * i) for c, i in kinds[:nin]] + [0] * (5 - nin)
         assert opnds == byte[0] | byte[2] << 8 | byte[3] << 16 | byte[4] << 24
         assert opnd_b == byte[1]
-        assert dst == 8 * kinds[5][1]
+        assert dst == vgprs * kinds[5][1]
     if name.startswith("fountain"):
         assert threaded >= 4
+    if many:
+        assert threaded >= 40
