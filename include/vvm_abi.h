@@ -404,7 +404,7 @@ typedef struct vvm_program_info {
 	uint32_t NumInstructions;       /* linked device instructions */
 	uint32_t NumVirtualRegisters;   /* per-lane registers the kernel needs (temps + output-aliased) */
 	uint32_t InstancesPerLane;      /* 4 = 128-bit stream access, 1 = narrow fallback */
-	uint32_t LdsSpillRegisters;     /* registers living in LDS */
+	uint32_t LdsSpillRegisters;     /* registers living in LDS, on the kernel the script is linked for */
 	uint32_t BytesInPerInstance, BytesOutPerInstance; /* algorithmic stream bytes */
 	uint32_t Flags;
 } vvm_program_info;

@@ -84,7 +84,7 @@ def pre(kind, letter):
 
 
 # Instance slots per lane that a routine works on: 8 (the eight-wide kernels: a register is eight consecutive VGPRs) or 4 (the
-# four-wide kernel with 32 registers: four).  Set by main() around each of the two sets of routines; the routines of the two sets lie
+# four-wide kernel of 44 registers: four).  Set by main() around each of the two sets of routines; the routines of the two sets lie
 # at the same offsets, so an instruction's routine offset does not depend on the kernel it runs on (its operand bytes do).
 W = 8
 

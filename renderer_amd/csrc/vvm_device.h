@@ -153,7 +153,7 @@ enum : uint32_t {
 	VVM_DESC_USES_PERLIN = 1u << 0,
 	VVM_DESC_RELATIVE    = 1u << 1,    // consts, in_ptrs, load_ptrs, out_list hold byte offsets from the descriptor, not addresses
 	VVM_DESC_REGS_OF_4   = 1u << 2     // the program's routine operands count four VGPRs per register (a program of more than sixteen
-	                                   // registers, for the four-wide kernel whose file is 32 registers of four instance slots); otherwise
+	                                   // registers, for the four-wide kernel whose file is 44 registers of four instance slots); otherwise
 	                                   // eight, which that kernel runs as well: sixteen registers, the upper four slots of each unused
 };
 // Largest parameter block (descriptor + tables) that is handed to the kernel as a kernel argument instead of through device memory.

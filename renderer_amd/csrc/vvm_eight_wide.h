@@ -3,8 +3,8 @@
 //
 // These kernels run plain scripts (no transcendental / noise / ID instructions, every register resident): the light one, for scripts
 // of eight registers and eight outputs, three workgroups per CU; and the general one, sixteen registers, two datasets, two per CU.
-// The four-wide kernel for plain scripts of 17 to 43 registers (32 of them resident, the rest in LDS slots) has the same tile program
-// with V = 4: its file is the general one's 128 VGPRs as 32 registers of four instance slots.
+// The four-wide kernel for plain scripts of 17 to 43 registers has the same tile program with V = 4: its file is 176 VGPRs, 44
+// registers of four instance slots (the compiled four-wide kernels keep 32 and the rest in LDS slots).
 // Their register file lies in FIXED VGPRs, register-major (the V instance slots of register i are V consecutive VGPRs), and
 // runs of ordinary instructions are executed by the hand-written routines of vvm_threaded.h; everything else of a tile (stream
 // loads, acquireindex, output staging, the instructions without a routine) is the C++ below, which reaches the file through three
@@ -14,9 +14,18 @@
 
 // LIGHT:   registers 0..7 and the two riding ones (VVM_LIGHT_RIDE_REG, +1) = v72..v151, temporaries v152..v167 (budget: 168 VGPRs)
 // general: registers 0..15 = v112..v239, temporaries v240..v255 (budget: 256 VGPRs)
+// V = 4:   registers 0..43 = v64..v239, temporaries v240..v255 (budget: 256 VGPRs; the C++ side has a tile's stream loads of four
+//          values per lane in flight where the eight-wide kernels have eight, and gets by with the 64 registers below the file)
 template <bool LIGHT> struct File8;
 template <> struct File8<true> { vec32f f0, f1; vec16f f2; };
 template <> struct File8<false> { vec32f f0, f1, f2, f3; };
+struct File4 { vec32f f0, f1, f2, f3, f4; vec16f f5; };
+template <int V, bool LIGHT> struct FileFor { typedef File8<LIGHT> type; };
+template <> struct FileFor<4, false> { typedef File4 type; };
+template <int V, bool LIGHT> using FileOf = typename FileFor<V, LIGHT>::type;
+#define F4_SET ".set VT_FB, 64\n .set VT_T, 240\n .set VT_Q, 248\n"
+#define F4_RW(F) "+{v[64:95]}"((F).f0), "+{v[96:127]}"((F).f1), "+{v[128:159]}"((F).f2), "+{v[160:191]}"((F).f3), "+{v[192:223]}"((F).f4), "+{v[224:239]}"((F).f5)
+#define F4_RO(F) "{v[64:95]}"((F).f0), "{v[96:127]}"((F).f1), "{v[128:159]}"((F).f2), "{v[160:191]}"((F).f3), "{v[192:223]}"((F).f4), "{v[224:239]}"((F).f5)
 #define F8L_SET ".set VT_FB, 72\n .set VT_T, 152\n .set VT_Q, 160\n"
 #define F8G_SET ".set VT_FB, 112\n .set VT_T, 240\n .set VT_Q, 248\n"
 #define F8L_RW(F) "+{v[72:103]}"((F).f0), "+{v[104:135]}"((F).f1), "+{v[136:151]}"((F).f2)
@@ -36,15 +45,15 @@ template <bool LIGHT> DEV void file_clear(File8<LIGHT>& F)
 	F.f0 = 0.0f; F.f1 = 0.0f; F.f2 = 0.0f;
 	if constexpr (!LIGHT) F.f3 = 0.0f;
 }
+DEV void file_clear(File4& F) { F.f0 = 0.0f; F.f1 = 0.0f; F.f2 = 0.0f; F.f3 = 0.0f; F.f4 = 0.0f; F.f5 = 0.0f; }
 // the V instance slots of the register whose first VGPR is FILE + byte (byte = V x register index, wave-uniform)
-template <int V, bool LIGHT> DEV void file_read(const File8<LIGHT>& F, uint32_t byte, float (&out)[V])
+template <int V, bool LIGHT> DEV void file_read(const FileOf<V, LIGHT>& F, uint32_t byte, float (&out)[V])
 {
 #define F8_READ_TEXT4 \
 	"s_set_gpr_idx_on %[i], gpr_idx(SRC0)\n v_mov_b32 %0, v[VT_FB+0]\n v_mov_b32 %1, v[VT_FB+1]\n v_mov_b32 %2, v[VT_FB+2]\n v_mov_b32 %3, v[VT_FB+3]\n"
 #define F8_READ_TEXT8 F8_READ_TEXT4 "v_mov_b32 %4, v[VT_FB+4]\n v_mov_b32 %5, v[VT_FB+5]\n v_mov_b32 %6, v[VT_FB+6]\n v_mov_b32 %7, v[VT_FB+7]\n"
 	if constexpr (V == 4) {
-		static_assert(!LIGHT, "four instance slots: the general file only");
-		asm volatile(F8G_SET F8_READ_TEXT4 "s_set_gpr_idx_off\n" : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]) : [i] "s"(byte), F8G_RO(F) : "scc");
+		asm volatile(F4_SET F8_READ_TEXT4 "s_set_gpr_idx_off\n" : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]) : [i] "s"(byte), F4_RO(F) : "scc");
 	} else if constexpr (LIGHT)
 		asm volatile(F8L_SET F8_READ_TEXT8 "s_set_gpr_idx_off\n" : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]), "=&v"(out[4]), "=&v"(out[5]), "=&v"(out[6]), "=&v"(out[7])
 		             : [i] "s"(byte), F8L_RO(F) : "scc");
@@ -54,15 +63,14 @@ template <int V, bool LIGHT> DEV void file_read(const File8<LIGHT>& F, uint32_t 
 #undef F8_READ_TEXT4
 #undef F8_READ_TEXT8
 }
-template <int V, bool LIGHT> DEV void file_write(File8<LIGHT>& F, uint32_t byte, const float (&in)[V])
+template <int V, bool LIGHT> DEV void file_write(FileOf<V, LIGHT>& F, uint32_t byte, const float (&in)[V])
 {
 #define F8_WRITE_TEXT4 \
 	"s_set_gpr_idx_on %[i], gpr_idx(DST)\n v_mov_b32 v[VT_FB+0], %[a0]\n v_mov_b32 v[VT_FB+1], %[a1]\n v_mov_b32 v[VT_FB+2], %[a2]\n v_mov_b32 v[VT_FB+3], %[a3]\n"
 #define F8_WRITE_TEXT8 F8_WRITE_TEXT4 "v_mov_b32 v[VT_FB+4], %[a4]\n v_mov_b32 v[VT_FB+5], %[a5]\n v_mov_b32 v[VT_FB+6], %[a6]\n v_mov_b32 v[VT_FB+7], %[a7]\n"
 #define F8_WRITE_IN4 [i] "s"(byte), [a0] "v"(in[0]), [a1] "v"(in[1]), [a2] "v"(in[2]), [a3] "v"(in[3])
 	if constexpr (V == 4) {
-		static_assert(!LIGHT, "four instance slots: the general file only");
-		asm volatile(F8G_SET F8_WRITE_TEXT4 "s_set_gpr_idx_off\n" : F8G_RW(F) : F8_WRITE_IN4 : "scc");
+		asm volatile(F4_SET F8_WRITE_TEXT4 "s_set_gpr_idx_off\n" : F4_RW(F) : F8_WRITE_IN4 : "scc");
 	} else if constexpr (LIGHT)
 		asm volatile(F8L_SET F8_WRITE_TEXT8 "s_set_gpr_idx_off\n" : F8L_RW(F) : F8_WRITE_IN4, [a4] "v"(in[4]), [a5] "v"(in[5]), [a6] "v"(in[6]), [a7] "v"(in[7]) : "scc");
 	else
@@ -94,10 +102,10 @@ template <int V, bool LIGHT> DEV void file_write(File8<LIGHT>& F, uint32_t byte,
 	".p2align 8\n 8:\n" F8_LEAVE("68") \
 	".set VT_C, 68\n .set VT_N, 60\n .set VT_NB, 76\n" ROUTINES("8b") \
 	"9:\n s_waitcnt lgkmcnt(0)\n s_sub_u32 %[pc], %[pc], 32\n"
-template <int V, bool LIGHT> DEV void run_ordinary8(File8<LIGHT>& F, const void* prog, uint32_t& pc, uint32_t uni, uint32_t (&x)[4])
+template <int V, bool LIGHT> DEV void run_ordinary8(FileOf<V, LIGHT>& F, const void* prog, uint32_t& pc, uint32_t uni, uint32_t (&x)[4])
 {
 	if constexpr (V == 4)
-		asm volatile(F8G_SET F8_RUN_TEXT(VVM_T4_ROUTINES) : [pc] "+s"(pc), [x0] "=&s"(x[0]), [x1] "=&s"(x[1]), [x2] "=&s"(x[2]), [x3] "=&s"(x[3]), F8G_RW(F)
+		asm volatile(F4_SET F8_RUN_TEXT(VVM_T4_ROUTINES) : [pc] "+s"(pc), [x0] "=&s"(x[0]), [x1] "=&s"(x[1]), [x2] "=&s"(x[2]), [x3] "=&s"(x[3]), F4_RW(F)
 		             : [prog] "s"(prog), [uni] "v"(uni) : F8G_TEMPS, F8_SGPRS, "memory");
 	else if constexpr (LIGHT)
 		asm volatile(F8L_SET F8_RUN_TEXT(VVM_T_ROUTINES) : [pc] "+s"(pc), [x0] "=&s"(x[0]), [x1] "=&s"(x[1]), [x2] "=&s"(x[2]), [x3] "=&s"(x[3]), F8L_RW(F)
@@ -107,12 +115,12 @@ template <int V, bool LIGHT> DEV void run_ordinary8(File8<LIGHT>& F, const void*
 		             : [prog] "s"(prog), [uni] "v"(uni) : F8G_TEMPS, F8_SGPRS, "memory");
 }
 
-// Registers of a four-wide program beyond the 32 of the file live in LDS slots, [slot][thread] (the compiled kernels' reg_read /
-// reg_spill): instructions that touch one have no routine.  (A program of at most sixteen registers that runs four-wide, for its
-// second chain, keeps the eight VGPRs per register it is encoded with and uses four of them: Ctx::reg_shift.)
-#define VVM_FILE4_REGS 32u
+// Registers of a four-wide program beyond the 44 of the file live in LDS slots, [slot][thread] (as the compiled kernels' reg_read /
+// reg_spill have them): up to eleven, and instructions that touch one have no routine.  (A program of at most sixteen registers that
+// runs four-wide, for its second chain, keeps the eight VGPRs per register it is encoded with and uses four of them: Ctx::reg_shift.)
+#define VVM_FILE4_REGS 44u
 // operand fetch for the C++ side (the class and the index are wave-uniform)
-template <int V, bool LIGHT> DEV void fetch8(const File8<LIGHT>& F, uint32_t uni, const Ctx& c, uint32_t o, float (&out)[V])
+template <int V, bool LIGHT> DEV void fetch8(const FileOf<V, LIGHT>& F, uint32_t uni, const Ctx& c, uint32_t o, float (&out)[V])
 {
 	if (o < (1u << 13)) {                       // VVM_OPC_VREG
 		if constexpr (V == 8) {
@@ -134,7 +142,7 @@ template <int V, bool LIGHT> DEV void fetch8(const File8<LIGHT>& F, uint32_t uni
 	}
 }
 // the V values of a result to register `idx` of the program
-template <int V, bool LIGHT> DEV void store8(File8<LIGHT>& F, const Ctx& c, uint32_t idx, const float (&in)[V])
+template <int V, bool LIGHT> DEV void store8(FileOf<V, LIGHT>& F, const Ctx& c, uint32_t idx, const float (&in)[V])
 {
 	if constexpr (V == 8) {
 		file_write<8, LIGHT>(F, (idx & 31u) * 8u, in);
@@ -150,7 +158,7 @@ template <int V, bool LIGHT> DEV void store8(File8<LIGHT>& F, const Ctx& c, uint
 
 // One ordinary instruction that has no routine (an op without one, or an operand that is neither a register of the file nor a uniform
 // register), by the same cases as the other kernels' interpreter loop.
-template <int V, bool LIGHT> DEV void exec_ordinary8(File8<LIGHT>& F, uint32_t uni, const Ctx& c, const uint32_t (&w)[4])
+template <int V, bool LIGHT> DEV void exec_ordinary8(FileOf<V, LIGHT>& F, uint32_t uni, const Ctx& c, const uint32_t (&w)[4])
 {
 	constexpr bool FULL = false;
 	const uint32_t op = w[0] & 0xFFu, nin = (w[0] >> 8) & 7u, aux = (w[0] >> 16) & 0xFFu, aux2 = w[0] >> 24;
@@ -211,7 +219,7 @@ template <int V, bool LIGHT> DEV void exec_ordinary8(File8<LIGHT>& F, uint32_t u
 // half, the tile of the four-wide kernels.)
 template <int V, bool LIGHT>
 DEV void run_tile8(const void* prog_in, gu64* status, bool last_tile, const Ctx& c, unsigned char* lds, uint32_t tile_local, uint32_t tag, VvmLaunchState* ls, uint32_t dbg, Pending& pend,
-                   uint32_t& resolves, const u64 (&pre)[VVM_LB_WORDS_PER_LANE], bool have_pre, File8<LIGHT>& F)
+                   uint32_t& resolves, const u64 (&pre)[VVM_LB_WORDS_PER_LANE], bool have_pre, FileOf<V, LIGHT>& F)
 {
 	static_assert(V == 8 || (V == 4 && !LIGHT), "eight instance slots, or four on the general file");
 	constexpr bool FULL = false;

@@ -268,12 +268,12 @@ namespace {
 // The program as it lies in device memory (VvmDevIns): the linker's instructions, each followed by what the hand-written core of the
 // eight-wide kernels executes from (vvm_threaded.h): the routine for the instruction's op and operand kinds, and its operands as bytes.
 // An instruction gets a routine when it is an ordinary one whose op has routines, whose operands are per-lane registers of the file
-// (light program: eight registers and the two riding ones; a program of many registers: 32; otherwise sixteen) or uniform registers, not all of them uniform, and
+// (light program: eight registers and the two riding ones; a program of many registers: 44; otherwise sixteen) or uniform registers, not all of them uniform, and
 // whose destination is a register of the file.  The other kernels read the linker's four words only.
 void encode_device_program(const vvm::LinkedProgram& lp, std::vector<VvmDevIns>& out)
 {
 	// (a program of more than sixteen registers runs four instances per lane: its registers are four VGPRs each, VVM_DESC_REGS_OF_4)
-	const uint32_t file_regs = lp.light ? VVM_LIGHT_RIDE_REG + 2u : lp.many_registers ? 32u : 16u;
+	const uint32_t file_regs = lp.light ? VVM_LIGHT_RIDE_REG + 2u : lp.many_registers ? 44u : 16u;
 	const uint32_t vgprs_per_reg = lp.many_registers ? 4u : 8u;
 	out.clear();
 	out.reserve(lp.code.size() + 1);
@@ -374,6 +374,9 @@ struct PreparedExec {
 	bool full() const { return lp->full_kernel || reference_random; }
 	// what vvm_launch_exec_kernel takes as many_registers (a program with two chains runs four-wide on the kernel with 32 registers: it has the second chain)
 	bool launch_many() const { return light || lp->many_registers || (lp->num_chains > 1 && instances_per_lane == 4); }
+	// registers in LDS slots on the kernel the Exec runs on (a plain program of many registers on a kernel with the transcendental
+	// functions, for the reference generator's words or as one of several fused passes: 32 resident ones there, not 44)
+	uint32_t lds_slots() const { return full() ? lp->lds_slots_with_32_resident() : lp->lds_spill_slots; }
 };
 
 int g_page_kb = 64;      // vm.PageSizeInKB, VectorVMRuntime.cpp:44-50
@@ -578,7 +581,7 @@ int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, P
 		if (pe.in_batch) return fail(VVM_E_UNSUPPORTED_OP, "RandXorwowState: not available to the members of a batch");
 		if (pe.lp->num_chains > 1) return fail(VVM_E_UNSUPPORTED_OP, "RandXorwowState: not available to a script that acquires two datasets in one pass (set VVM_NO_CHAINS)");
 		// (the random ops of the FULL kernels read the words; a program linked for the plain kernels runs on them as it is, given the LDS)
-		if ((size_t)vvm_kernel_lds_fixed_bytes((int)pe.instances_per_lane, 1) + (size_t)pe.lp->lds_spill_slots * VVM_BLOCK_THREADS * 4u * pe.instances_per_lane > (size_t)(160 * 1024 - 64))
+		if ((size_t)vvm_kernel_lds_fixed_bytes((int)pe.instances_per_lane, 1) + (size_t)pe.lds_slots() * VVM_BLOCK_THREADS * 4u * pe.instances_per_lane > (size_t)(160 * 1024 - 64))
 			return fail(VVM_E_UNSUPPORTED_OP, "RandXorwowState: the script's registers leave no room in the LDS of the kernels that read the generator's words");
 	}
 	{
@@ -940,7 +943,7 @@ int enqueue_fused_passes(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_op
 		if (rc != VVM_OK) return rc;
 		if (pes[k].instances_per_lane != pes[0].instances_per_lane || pes[k].instances_per_lane == 8) return VVM_OK;      // (the FULL kernels run four or one)
 		many = many || pes[k].launch_many();
-		spill = std::max(spill, pes[k].lp->lds_spill_slots);
+		spill = std::max(spill, pes[k].lp->lds_slots_with_32_resident());      // (every pass runs on the FULL kernel)
 		ids = ids || pes[k].lp->updates_ids;
 		pes[k].id_buffers = k;
 	}
@@ -1338,7 +1341,7 @@ static int exec_enqueue(vvm_exec_context* ctx, const vvm_exec_options* opt, bool
 		EpochMirror& epoch = no_alloc ? g_dev.scratch_epoch[st->device] : st->epoch;
 		HIP_TRY(epoch.before_launch(d_status, st->cur_status_words, stream));
 		const int lrc = vvm_launch_exec_kernel((int)pe.instances_per_lane, inline_block ? nullptr : (const VvmExecDesc*)st->ring.dev[slot], 1, pe.tiles, d_launch,
-		                                       pe.launch_many() ? 1 : 0, pe.lp->lds_spill_slots, pe.full() ? ((pe.lean && pe.instances_per_lane == 4) ? 2 : 1) : 0,
+		                                       pe.launch_many() ? 1 : 0, pe.lds_slots(), pe.full() ? ((pe.lean && pe.instances_per_lane == 4) ? 2 : 1) : 0,
 		                                       grid_for(pe.tiles, pe.instances_per_lane, pe.full(), pe.launch_many()), stream,
 		                                       inline_block ? local_block : nullptr, inline_block ? (uint32_t)pe.bytes : 0u, 0u, 0);
 		if (lrc != 0) return hip_fail((hipError_t)lrc, "kernel launch");
@@ -1616,7 +1619,7 @@ void batch_layout(BatchPlan& plan, const vvm_exec_context* ctxs)
 				const_off += pe.off_in - pe.off_consts;
 				plan.status_off[(size_t)i] = status_off;
 				plan.first_tile[(size_t)i] = first_tile;
-				grp.spill = std::max(grp.spill, pe.lp->lds_spill_slots);
+				grp.spill = std::max(grp.spill, pe.lds_slots());
 				desc_off += sizeof(VvmExecDesc);
 				table_off += pe.bytes;
 				status_off += pe.tiles;

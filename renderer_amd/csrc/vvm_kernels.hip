@@ -1698,8 +1698,8 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (IS_LIGHT(V, SPILL) ? 3 : V
 	// (eight instances per lane: the register file, in fixed VGPRs from here to the end of the kernel; the light kernel's riding outputs
 	// wait in it from one tile to the next)
 	constexpr bool THREADED = V == 8 || (V == 4 && SPILL && !FULL);      // the kernels whose tile program is run_tile8
-	File8<IS_LIGHT(V, SPILL)> file8;
-	if constexpr (THREADED) file_clear<IS_LIGHT(V, SPILL)>(file8);
+	FileOf<(THREADED ? V : 8), IS_LIGHT(V, SPILL)> file8;
+	if constexpr (THREADED) file_clear(file8);
 	Pending pend;
 	pend.active = false; pend.unresolved = false; pend.last = false; pend.total = 0; pend.base = 0; pend.stage_end = 0; pend.tile_local = 0;
 	pend.status = nullptr; pend.out_list = nullptr; pend.ride = 0;

@@ -208,6 +208,8 @@ static int decode(const ThawedScript& s, std::vector<Decoded>& out, std::string&
 // ---- linker ------------------------------------------------------------------------------------------
 static const uint32_t kMaxSpillWide = 11;      // LDS register slots of the 4-instances-per-lane kernel (4 KB each per workgroup; two
                                                // workgroups per CU must fit: 2 x (36 KB + 11 x 4 KB) = 160 KB; exactly: fixed part 35 712 bytes, 36 480 with the noise tables)
+static const uint32_t kFileWidePlain = 44;     // registers in VGPRs on the four-wide kernel of plain scripts (the file of its hand-written routines:
+                                               // VVM_FILE4_REGS of the kernels); the four-wide kernel with the transcendental functions keeps 32
 static const uint32_t kMaxSpillNarrow = 128;   // 1 KB each
 
 // Packs the per-lane registers of a linked program by live range.  The program is straight-line code that every tile runs from
@@ -926,11 +928,11 @@ static int link_program_as(const ThawedScript& s, bool force_narrow, LinkedProgr
 	lp.code.push_back(VvmIns{VVM_INS_W0(VVM_OP_done, 0, 0, 0, 0), 0, 0, 0});
 	lp.code.push_back(VvmIns{VVM_INS_W0(VVM_OP_done, 0, 0, 0, 0), 0, 0, 0});   // the kernel fetches one instruction ahead
 	// pack the per-lane registers, then choose the kernel shape: up to 16 registers: everything in VGPRs at full occupancy
-	// (four or eight instances per lane); up to 32 + LDS slots: the four-wide kernel with 32 resident registers; beyond: one
-	// instance per lane.  Registers past the resident ones live in LDS slots.
+	// (four or eight instances per lane); up to 44 (plain scripts) or 32 resident registers + LDS slots: the four-wide kernels with
+	// many registers; beyond: one instance per lane.  Registers past the resident ones live in LDS slots.
 	const uint32_t packed = reallocate_registers(lp.code, num_loaded, num_loaded + nv + 2, light ? first_ride : 0xFFFFFFFFu);
 	uint32_t V = 4, RV = 16;
-	if (packed > 16) RV = 32;
+	if (packed > 16) RV = lp.full_kernel ? 32 : kFileWidePlain;
 	if (force_narrow || packed > RV + kMaxSpillWide) { V = 1; RV = 32; }
 	if (packed > RV + (V == 4 ? kMaxSpillWide : kMaxSpillNarrow)) {
 		snprintf(msg, sizeof(msg), "script needs %u per-lane registers; the executor holds at most %u", packed, RV + kMaxSpillNarrow);
@@ -958,7 +960,7 @@ static int link_program_as(const ThawedScript& s, bool force_narrow, LinkedProgr
 	lp.num_vregs = packed;
 	lp.instances_per_lane = V;
 	lp.resident_regs = RV;
-	lp.many_registers = (RV == 32 && V == 4) || packed > RV;
+	lp.many_registers = (RV > 16 && V == 4) || packed > RV;
 	lp.lds_spill_slots = packed > RV ? packed - RV : 0;
 	for (VvmIns& k : lp.code) {
 		const uint32_t op = k.w0 & 0xFFu;

@@ -38,9 +38,14 @@ struct LinkedProgram {
 	std::vector<InputInfo> inputs;
 	uint32_t num_vregs = 0;            // per-lane registers used
 	uint32_t instances_per_lane = 4;   // 4 or 1
-	uint32_t resident_regs = 16;
-	uint32_t lds_spill_slots = 0;
-	bool     many_registers = false;   // runs on the kernels with 32 resident registers (and LDS register slots)
+	uint32_t resident_regs = 16;       // registers in VGPRs on the kernel the program is linked for: 16, or (many_registers) 44 on the four-wide
+	                                   // kernel of plain scripts, 32 on the four-wide kernel with the transcendental / noise / ID instructions
+	                                   // and on the one-instance-per-lane kernels
+	uint32_t lds_spill_slots = 0;      // ... and the registers beyond them, in LDS slots
+	bool     many_registers = false;   // runs on the kernels with more than 16 resident registers (and LDS register slots)
+	// A plain four-wide program can be sent to the kernel with the transcendental functions as it is (an Exec that reads the reference
+	// generator's words): there 32 registers are resident.
+	uint32_t lds_slots_with_32_resident() const { return num_vregs > 32 ? num_vregs - 32 : 0; }
 	bool     light = false;            // linked for the light eight-wide kernel (eight resident registers, six staged outputs and up to
 	                                   // two that wait in registers VVM_LIGHT_RIDE_REG, +1)
 	bool     full_kernel = false;      // needs the transcendental / noise kernel

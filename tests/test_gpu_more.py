@@ -477,11 +477,11 @@ def test_two_datasets_match_the_oracle(n, secondary_first, many, mode, monkeypat
 
 
 def test_a_later_pass_with_smaller_tiles_gets_its_own_look_back_words():
-    """Dataset 0 needs two values, dataset 1 fifty at once: the first program runs four instances per lane, the second one, so the
-    second pass has four times the tiles.  Its look-back words are sized for it (sized for the first pass they ended 148 words short
-    here, and the words past the end landed in whatever lay behind the array)."""
+    """Dataset 0 needs two values, dataset 1 sixty at once: the first program runs four instances per lane, the second one, so the
+    second pass has four times the tiles.  Its look-back words are sized for it (sized for the first pass they end short, and the
+    words past the end land in whatever lies behind the array)."""
     s = Script()
-    xs = [s.input(0, FLOAT, i) for i in range(50)]
+    xs = [s.input(0, FLOAT, i) for i in range(60)]
     k0, k1 = s.temps(2)
     s.op("cmplt", xs[0], s.const(1), k0)
     s.acquireindex(k0, 0)
@@ -497,11 +497,11 @@ def test_a_later_pass_with_smaller_tiles_gets_its_own_look_back_words():
     s.op("add", prods[0], prods[1], acc)
     for t in prods[2:]:
         s.op("add", acc, t, acc)
-    s.output_data(FLOAT, 1, [(acc, s.output(1, FLOAT, 0)), (prods[49], s.output(1, FLOAT, 1))])
+    s.output_data(FLOAT, 1, [(acc, s.output(1, FLOAT, 0)), (prods[59], s.output(1, FLOAT, 1))])
     built = s.build()
     n = 300_000
     rng = np.random.default_rng(5)
-    ins = [rng.random(n).astype(f32) for _ in range(50)]
+    ins = [rng.random(n).astype(f32) for _ in range(60)]
     consts = [ALL_ONES[:4] + np.array([0.5, 0.7, 1.25], f32).tobytes()]
     for flags in (0, abi.VVM_EXEC_SEPARATE_PASSES):
         ref_more, got_more, widths = [], [], []

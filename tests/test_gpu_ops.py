@@ -175,9 +175,9 @@ def test_noadvance_inputs_and_many_constants():
         np.testing.assert_array_equal(got[0][off:off + n].view(np.uint32), ref[0][off:off + n].view(np.uint32))
 
 
-@pytest.mark.parametrize("n_temps,lds_registers", [(22, 0), (30, 0), (38, 6), (43, 11)])
+@pytest.mark.parametrize("n_temps,lds_registers", [(22, 0), (30, 0), (38, 0), (43, 0), (44, 0), (45, 1), (50, 6), (55, 11)])
 def test_many_live_registers(n_temps, lds_registers):
-    """More live temps than the 16 registers of the plain kernel: the 4-instances-per-lane kernel with 32 resident registers,
+    """More live temps than the 16 registers of the plain kernel: the 4-instances-per-lane kernel with 44 resident registers,
     and LDS slots for the ones beyond."""
     s = Script()
     s.acquireindex(s.const(0), 0)

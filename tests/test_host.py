@@ -267,10 +267,14 @@ def test_many_registers_spill_to_lds_then_narrow_kernel():
         return s.build()
     small = be().inspect_blob(chain(10).blob)
     assert small.InstancesPerLane == 4 and small.LdsSpillRegisters == 0
-    mid = be().inspect_blob(chain(22).blob)                 # more than 16: the four-wide kernel with 32 resident registers
+    mid = be().inspect_blob(chain(22).blob)                 # more than 16: the four-wide kernel with 44 resident registers
     assert mid.InstancesPerLane == 4 and mid.LdsSpillRegisters == 0 and mid.NumVirtualRegisters == 22
-    more = be().inspect_blob(chain(36).blob)                # more than 32: the rest in LDS slots
-    assert more.InstancesPerLane == 4 and more.LdsSpillRegisters == 4
+    more = be().inspect_blob(chain(36).blob)
+    assert more.InstancesPerLane == 4 and more.LdsSpillRegisters == 0
+    most = be().inspect_blob(chain(48).blob)                # more than 44: the rest in LDS slots
+    assert most.InstancesPerLane == 4 and most.LdsSpillRegisters == 4 and most.NumVirtualRegisters == 48
+    assert be().inspect_blob(chain(55).blob).InstancesPerLane == 4
+    assert be().inspect_blob(chain(56).blob).InstancesPerLane == 1
     big = be().inspect_blob(chain(60).blob)
     assert big.InstancesPerLane == 1
     with pytest.raises(abi.VVMError) as e:

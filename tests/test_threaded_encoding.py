@@ -48,7 +48,7 @@ def test_routines_fit_their_slots_and_do_not_overlap():
 
 def many_register_script(n_temps):
     """more values alive at once than the sixteen registers of the eight-wide file: such a program runs four instances per lane on
-    32 registers of four VGPRs each (n_temps > 31: some registers in LDS slots, instructions that touch one have no routine)"""
+    44 registers of four VGPRs each"""
     from renderer_amd.assembler import FLOAT, Script
     s = Script()
     s.acquireindex(s.const(0), 0)
@@ -73,6 +73,7 @@ def programs():
         out.append(("fountain_v%d" % v, scripts.fountain(variant=v).script))
     out.append(("registers_24", many_register_script(24)))
     out.append(("registers_40", many_register_script(40)))
+    out.append(("registers_50", many_register_script(50)))      # (some registers in LDS slots: instructions that touch one have no routine)
     return out
 
 
@@ -91,7 +92,7 @@ def test_device_program_names_the_right_routines(name, script, narrow):
     g = generator()
     first, slot, total = routine_offsets(g)
     many = name.startswith("registers_")
-    file_regs = 10 if narrow == 2 else 32 if many else 16
+    file_regs = 10 if narrow == 2 else 44 if many else 16
     vgprs = 4 if many else 8      # VGPRs per register: the instance slots of the kernel the program runs on
     assert len(dev) == len(plain) + 1
     assert [d[:4] for d in dev[:-1]] == [tuple(p) for p in plain]

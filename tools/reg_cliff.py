@@ -54,7 +54,7 @@ def main():
     ins = scripts.fountain_streams_torch(0, n, dev, pad=64)[:4]
     outs = [torch.zeros(n + 64, dtype=torch.float32, device=dev) for _ in range(4)]
     consts = struct.pack("<I2f", 0xFFFFFFFF, 1.0009765625, 0.125) + bytes(4)
-    for live in (4, 8, 12, 20, 28, 40, 64):
+    for live in (4, 8, 12, 16, 20, 28, 40, 44, 48, 55, 64):
         built = script(64, live)
         st = VectorVMState(built.blob, be)
         info = st.info()
