@@ -16,13 +16,15 @@
 // general: registers 0..15 = v112..v239, temporaries v240..v255 (budget: 256 VGPRs)
 // V = 4:   registers 0..43 = v64..v239, temporaries v240..v255 (budget: 256 VGPRs; the C++ side has a tile's stream loads of four
 //          values per lane in flight where the eight-wide kernels have eight, and gets by with the 64 registers below the file)
+// V = 4 with the transcendental / noise / ID instructions (FULL): registers 0..31 = v112..v239 (the general file, four VGPRs per
+//          register): those functions are C++ and need the registers below
 template <bool LIGHT> struct File8;
 template <> struct File8<true> { vec32f f0, f1; vec16f f2; };
 template <> struct File8<false> { vec32f f0, f1, f2, f3; };
 struct File4 { vec32f f0, f1, f2, f3, f4; vec16f f5; };
-template <int V, bool LIGHT> struct FileFor { typedef File8<LIGHT> type; };
-template <> struct FileFor<4, false> { typedef File4 type; };
-template <int V, bool LIGHT> using FileOf = typename FileFor<V, LIGHT>::type;
+template <int V, bool LIGHT, bool FULL> struct FileFor { typedef File8<LIGHT> type; };      // (V = 4, FULL: the general file as 32 registers of four slots)
+template <> struct FileFor<4, false, false> { typedef File4 type; };
+template <int V, bool LIGHT, bool FULL> using FileOf = typename FileFor<V, LIGHT, FULL>::type;
 #define F4_SET ".set VT_FB, 64\n .set VT_T, 240\n .set VT_Q, 248\n"
 #define F4_RW(F) "+{v[64:95]}"((F).f0), "+{v[96:127]}"((F).f1), "+{v[128:159]}"((F).f2), "+{v[160:191]}"((F).f3), "+{v[192:223]}"((F).f4), "+{v[224:239]}"((F).f5)
 #define F4_RO(F) "{v[64:95]}"((F).f0), "{v[96:127]}"((F).f1), "{v[128:159]}"((F).f2), "{v[160:191]}"((F).f3), "{v[192:223]}"((F).f4), "{v[224:239]}"((F).f5)
@@ -47,13 +49,14 @@ template <bool LIGHT> DEV void file_clear(File8<LIGHT>& F)
 }
 DEV void file_clear(File4& F) { F.f0 = 0.0f; F.f1 = 0.0f; F.f2 = 0.0f; F.f3 = 0.0f; F.f4 = 0.0f; F.f5 = 0.0f; }
 // the V instance slots of the register whose first VGPR is FILE + byte (byte = V x register index, wave-uniform)
-template <int V, bool LIGHT> DEV void file_read(const FileOf<V, LIGHT>& F, uint32_t byte, float (&out)[V])
+template <int V, bool LIGHT, bool FULL> DEV void file_read(const FileOf<V, LIGHT, FULL>& F, uint32_t byte, float (&out)[V])
 {
 #define F8_READ_TEXT4 \
 	"s_set_gpr_idx_on %[i], gpr_idx(SRC0)\n v_mov_b32 %0, v[VT_FB+0]\n v_mov_b32 %1, v[VT_FB+1]\n v_mov_b32 %2, v[VT_FB+2]\n v_mov_b32 %3, v[VT_FB+3]\n"
 #define F8_READ_TEXT8 F8_READ_TEXT4 "v_mov_b32 %4, v[VT_FB+4]\n v_mov_b32 %5, v[VT_FB+5]\n v_mov_b32 %6, v[VT_FB+6]\n v_mov_b32 %7, v[VT_FB+7]\n"
 	if constexpr (V == 4) {
-		asm volatile(F4_SET F8_READ_TEXT4 "s_set_gpr_idx_off\n" : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]) : [i] "s"(byte), F4_RO(F) : "scc");
+		if constexpr (FULL) asm volatile(F8G_SET F8_READ_TEXT4 "s_set_gpr_idx_off\n" : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]) : [i] "s"(byte), F8G_RO(F) : "scc");
+		else asm volatile(F4_SET F8_READ_TEXT4 "s_set_gpr_idx_off\n" : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]) : [i] "s"(byte), F4_RO(F) : "scc");
 	} else if constexpr (LIGHT)
 		asm volatile(F8L_SET F8_READ_TEXT8 "s_set_gpr_idx_off\n" : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]), "=&v"(out[4]), "=&v"(out[5]), "=&v"(out[6]), "=&v"(out[7])
 		             : [i] "s"(byte), F8L_RO(F) : "scc");
@@ -63,14 +66,15 @@ template <int V, bool LIGHT> DEV void file_read(const FileOf<V, LIGHT>& F, uint3
 #undef F8_READ_TEXT4
 #undef F8_READ_TEXT8
 }
-template <int V, bool LIGHT> DEV void file_write(FileOf<V, LIGHT>& F, uint32_t byte, const float (&in)[V])
+template <int V, bool LIGHT, bool FULL> DEV void file_write(FileOf<V, LIGHT, FULL>& F, uint32_t byte, const float (&in)[V])
 {
 #define F8_WRITE_TEXT4 \
 	"s_set_gpr_idx_on %[i], gpr_idx(DST)\n v_mov_b32 v[VT_FB+0], %[a0]\n v_mov_b32 v[VT_FB+1], %[a1]\n v_mov_b32 v[VT_FB+2], %[a2]\n v_mov_b32 v[VT_FB+3], %[a3]\n"
 #define F8_WRITE_TEXT8 F8_WRITE_TEXT4 "v_mov_b32 v[VT_FB+4], %[a4]\n v_mov_b32 v[VT_FB+5], %[a5]\n v_mov_b32 v[VT_FB+6], %[a6]\n v_mov_b32 v[VT_FB+7], %[a7]\n"
 #define F8_WRITE_IN4 [i] "s"(byte), [a0] "v"(in[0]), [a1] "v"(in[1]), [a2] "v"(in[2]), [a3] "v"(in[3])
 	if constexpr (V == 4) {
-		asm volatile(F4_SET F8_WRITE_TEXT4 "s_set_gpr_idx_off\n" : F4_RW(F) : F8_WRITE_IN4 : "scc");
+		if constexpr (FULL) asm volatile(F8G_SET F8_WRITE_TEXT4 "s_set_gpr_idx_off\n" : F8G_RW(F) : F8_WRITE_IN4 : "scc");
+		else asm volatile(F4_SET F8_WRITE_TEXT4 "s_set_gpr_idx_off\n" : F4_RW(F) : F8_WRITE_IN4 : "scc");
 	} else if constexpr (LIGHT)
 		asm volatile(F8L_SET F8_WRITE_TEXT8 "s_set_gpr_idx_off\n" : F8L_RW(F) : F8_WRITE_IN4, [a4] "v"(in[4]), [a5] "v"(in[5]), [a6] "v"(in[6]), [a7] "v"(in[7]) : "scc");
 	else
@@ -102,9 +106,12 @@ template <int V, bool LIGHT> DEV void file_write(FileOf<V, LIGHT>& F, uint32_t b
 	".p2align 8\n 8:\n" F8_LEAVE("68") \
 	".set VT_C, 68\n .set VT_N, 60\n .set VT_NB, 76\n" ROUTINES("8b") \
 	"9:\n s_waitcnt lgkmcnt(0)\n s_sub_u32 %[pc], %[pc], 32\n"
-template <int V, bool LIGHT> DEV void run_ordinary8(FileOf<V, LIGHT>& F, const void* prog, uint32_t& pc, uint32_t uni, uint32_t (&x)[4])
+template <int V, bool LIGHT, bool FULL> DEV void run_ordinary8(FileOf<V, LIGHT, FULL>& F, const void* prog, uint32_t& pc, uint32_t uni, uint32_t (&x)[4])
 {
-	if constexpr (V == 4)
+	if constexpr (V == 4 && FULL)
+		asm volatile(F8G_SET F8_RUN_TEXT(VVM_T4_ROUTINES) : [pc] "+s"(pc), [x0] "=&s"(x[0]), [x1] "=&s"(x[1]), [x2] "=&s"(x[2]), [x3] "=&s"(x[3]), F8G_RW(F)
+		             : [prog] "s"(prog), [uni] "v"(uni) : F8G_TEMPS, F8_SGPRS, "memory");
+	else if constexpr (V == 4)
 		asm volatile(F4_SET F8_RUN_TEXT(VVM_T4_ROUTINES) : [pc] "+s"(pc), [x0] "=&s"(x[0]), [x1] "=&s"(x[1]), [x2] "=&s"(x[2]), [x3] "=&s"(x[3]), F4_RW(F)
 		             : [prog] "s"(prog), [uni] "v"(uni) : F8G_TEMPS, F8_SGPRS, "memory");
 	else if constexpr (LIGHT)
@@ -115,21 +122,21 @@ template <int V, bool LIGHT> DEV void run_ordinary8(FileOf<V, LIGHT>& F, const v
 		             : [prog] "s"(prog), [uni] "v"(uni) : F8G_TEMPS, F8_SGPRS, "memory");
 }
 
-// Registers of a four-wide program beyond the 44 of the file live in LDS slots, [slot][thread] (as the compiled kernels' reg_read /
-// reg_spill have them): up to eleven, and instructions that touch one have no routine.  (A program of at most sixteen registers that
+// Registers of a four-wide program beyond the 44 of the file (FULL: 32) live in LDS slots, [slot][thread] (as the compiled kernels'
+// reg_read / reg_spill have them), and instructions that touch one have no routine.  (A program of at most sixteen registers that
 // runs four-wide, for its second chain, keeps the eight VGPRs per register it is encoded with and uses four of them: Ctx::reg_shift.)
-#define VVM_FILE4_REGS 44u
+#define VVM_FILE4_REGS(FULL) ((FULL) ? 32u : 44u)
 // operand fetch for the C++ side (the class and the index are wave-uniform)
-template <int V, bool LIGHT> DEV void fetch8(const FileOf<V, LIGHT>& F, uint32_t uni, const Ctx& c, uint32_t o, float (&out)[V])
+template <int V, bool LIGHT, bool FULL> DEV void fetch8(const FileOf<V, LIGHT, FULL>& F, uint32_t uni, const Ctx& c, uint32_t o, float (&out)[V])
 {
 	if (o < (1u << 13)) {                       // VVM_OPC_VREG
 		if constexpr (V == 8) {
-			file_read<8, LIGHT>(F, (o & 31u) * 8u, out);
+			file_read<8, LIGHT, FULL>(F, (o & 31u) * 8u, out);
 		} else {
-			if (o < VVM_FILE4_REGS) {
-				file_read<4, LIGHT>(F, o << c.reg_shift, out);
+			if (o < VVM_FILE4_REGS(FULL)) {
+				file_read<4, LIGHT, FULL>(F, o << c.reg_shift, out);
 			} else {
-				const f4a v = *(const f4a*)(c.spill + ((o - VVM_FILE4_REGS) * VVM_BLOCK_THREADS + c.tid) * 4u);
+				const f4a v = *(const f4a*)(c.spill + ((o - VVM_FILE4_REGS(FULL)) * VVM_BLOCK_THREADS + c.tid) * 4u);
 				out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
 			}
 		}
@@ -142,25 +149,24 @@ template <int V, bool LIGHT> DEV void fetch8(const FileOf<V, LIGHT>& F, uint32_t
 	}
 }
 // the V values of a result to register `idx` of the program
-template <int V, bool LIGHT> DEV void store8(FileOf<V, LIGHT>& F, const Ctx& c, uint32_t idx, const float (&in)[V])
+template <int V, bool LIGHT, bool FULL> DEV void store8(FileOf<V, LIGHT, FULL>& F, const Ctx& c, uint32_t idx, const float (&in)[V])
 {
 	if constexpr (V == 8) {
-		file_write<8, LIGHT>(F, (idx & 31u) * 8u, in);
+		file_write<8, LIGHT, FULL>(F, (idx & 31u) * 8u, in);
 	} else {
-		if (idx < VVM_FILE4_REGS) {
-			file_write<4, LIGHT>(F, idx << c.reg_shift, in);
+		if (idx < VVM_FILE4_REGS(FULL)) {
+			file_write<4, LIGHT, FULL>(F, idx << c.reg_shift, in);
 		} else {
 			f4a v; v.x = in[0]; v.y = in[1]; v.z = in[2]; v.w = in[3];
-			*(f4a*)(c.spill + ((idx - VVM_FILE4_REGS) * VVM_BLOCK_THREADS + c.tid) * 4u) = v;
+			*(f4a*)(c.spill + ((idx - VVM_FILE4_REGS(FULL)) * VVM_BLOCK_THREADS + c.tid) * 4u) = v;
 		}
 	}
 }
 
 // One ordinary instruction that has no routine (an op without one, or an operand that is neither a register of the file nor a uniform
 // register), by the same cases as the other kernels' interpreter loop.
-template <int V, bool LIGHT> DEV void exec_ordinary8(FileOf<V, LIGHT>& F, uint32_t uni, const Ctx& c, const uint32_t (&w)[4])
+template <int V, bool LIGHT, bool FULL> DEV void exec_ordinary8(FileOf<V, LIGHT, FULL>& F, uint32_t uni, const Ctx& c, const uint32_t (&w)[4])
 {
-	constexpr bool FULL = false;
 	const uint32_t op = w[0] & 0xFFu, nin = (w[0] >> 8) & 7u, aux = (w[0] >> 16) & 0xFFu, aux2 = w[0] >> 24;
 	const uint32_t o[5] = {w[1] & 0xFFFFu, w[1] >> 16, w[2] & 0xFFFFu, w[2] >> 16, w[3] & 0xFFFFu};
 	const uint32_t dst = w[3] >> 16;
@@ -168,11 +174,11 @@ template <int V, bool LIGHT> DEV void exec_ordinary8(FileOf<V, LIGHT>& F, uint32
 	float a[V], b[V], cc[V], dd[V], ee[V], r[V];
 #pragma unroll
 	for (int k = 0; k < V; ++k) { a[k] = b[k] = cc[k] = dd[k] = ee[k] = 0.0f; r[k] = 0.0f; }
-	if (nin >= 1) fetch8<V, LIGHT>(F, uni, c, o[0], a);
-	if (nin >= 2) fetch8<V, LIGHT>(F, uni, c, o[1], b);
-	if (nin >= 3) fetch8<V, LIGHT>(F, uni, c, o[2], cc);
-	if (nin >= 4) fetch8<V, LIGHT>(F, uni, c, o[3], dd);
-	if (nin >= 5) fetch8<V, LIGHT>(F, uni, c, o[4], ee);
+	if (nin >= 1) fetch8<V, LIGHT, FULL>(F, uni, c, o[0], a);
+	if (nin >= 2) fetch8<V, LIGHT, FULL>(F, uni, c, o[1], b);
+	if (nin >= 3) fetch8<V, LIGHT, FULL>(F, uni, c, o[2], cc);
+	if (nin >= 4) fetch8<V, LIGHT, FULL>(F, uni, c, o[3], dd);
+	if (nin >= 5) fetch8<V, LIGHT, FULL>(F, uni, c, o[4], ee);
 	uint32_t inst_i = c.inst0;
 	asm volatile("" : "+v"(inst_i));
 #define LANES for (int k = 0; k < V; ++k)
@@ -211,19 +217,18 @@ template <int V, bool LIGHT> DEV void exec_ordinary8(FileOf<V, LIGHT>& F, uint32
 #undef SETF
 #undef SETI
 #undef SETM
-	store8<V, LIGHT>(F, c, VVM_OPND_IDX(dst), r);
+	store8<V, LIGHT, FULL>(F, c, VVM_OPND_IDX(dst), r);
 }
 
 // One tile of eight instances per lane: two halves of 1024 instances, lane t holding instances [4 t, 4 t + 4) of each (slots 0..3 and
 // 4..7), so that every stream access is a 128-bit access of four consecutive instances.  Same steps as run_tile.  (V = 4: one such
 // half, the tile of the four-wide kernels.)
-template <int V, bool LIGHT>
+template <int V, bool LIGHT, bool FULL, bool RIDE = false>
 DEV void run_tile8(const void* prog_in, gu64* status, bool last_tile, const Ctx& c, unsigned char* lds, uint32_t tile_local, uint32_t tag, VvmLaunchState* ls, uint32_t dbg, Pending& pend,
-                   uint32_t& resolves, const u64 (&pre)[VVM_LB_WORDS_PER_LANE], bool have_pre, FileOf<V, LIGHT>& F)
+                   uint32_t& resolves, const u64 (&pre)[VVM_LB_WORDS_PER_LANE], bool have_pre, FileOf<V, LIGHT, FULL>& F)
 {
-	static_assert(V == 8 || (V == 4 && !LIGHT), "eight instance slots, or four on the general file");
-	constexpr bool FULL = false;
-	constexpr bool TWO = !LIGHT;      // the general kernels run two acquired datasets in one pass
+	static_assert((V == 8 && !FULL) || (V == 4 && !LIGHT), "eight instance slots, or four (there also with the transcendental / noise / ID instructions)");
+	constexpr bool TWO = !LIGHT && !FULL;      // the general kernels of plain scripts run two acquired datasets in one pass
 	constexpr int HALVES = V == 8 ? 2 : 1;
 	// (the program's address as a value of unknown origin: otherwise the compiler, short of scalar registers, loads it from the Exec's
 	// descriptor again in front of every entry into the routines and waits for that load)
@@ -287,7 +292,7 @@ DEV void run_tile8(const void* prog_in, gu64* status, bool last_tile, const Ctx&
 			}
 			// (slots past the count write zeros to the last used slot's register, from the last one down: plain writes, no branch)
 #pragma unroll
-			for (int j = 7; j >= 0; --j) store8<V, LIGHT>(F, c, first_reg + min((uint32_t)j, cnt - 1u), st[j]);
+			for (int j = 7; j >= 0; --j) store8<V, LIGHT, FULL>(F, c, first_reg + min((uint32_t)j, cnt - 1u), st[j]);
 		}
 	}
 
@@ -308,10 +313,10 @@ DEV void run_tile8(const void* prog_in, gu64* status, bool last_tile, const Ctx&
 	uint32_t pc = pc0 * VVM_INS_STRIDE;
 	for (;;) {
 		uint32_t x[4];
-		run_ordinary8<V, LIGHT>(F, prog, pc, uni, x);
+		run_ordinary8<V, LIGHT, FULL>(F, prog, pc, uni, x);
 		const uint32_t op = x[0] & 0xFFu, aux = (x[0] >> 16) & 0xFFu, aux2 = x[0] >> 24;
 		if (((x[0] >> 8) & 7u) != VVM_NIN_SPECIAL) {
-			exec_ordinary8<V, LIGHT>(F, uni, c, x);
+			exec_ordinary8<V, LIGHT, FULL>(F, uni, c, x);
 			continue;
 		}
 		const uint32_t o0 = x[1] & 0xFFFFu, o1 = x[1] >> 16, o2 = x[2] & 0xFFFFu, o4 = x[3] & 0xFFFFu, o5 = x[3] >> 16;
@@ -320,10 +325,10 @@ DEV void run_tile8(const void* prog_in, gu64* status, bool last_tile, const Ctx&
 			// sign bit of the predicate = keep (VectorVMRuntime.cpp:838-841); instances past the end never survive (:846-857).  aux2 != 0: the
 			// compare that made the predicate is folded in: keep = o0 <cmp> o1
 			float p[V];
-			fetch8<V, LIGHT>(F, uni, c, o0, p);
+			fetch8<V, LIGHT, FULL>(F, uni, c, o0, p);
 			if (aux2 != VVM_ACQ_SIGN) {
 				float q[V];
-				fetch8<V, LIGHT>(F, uni, c, o1, q);
+				fetch8<V, LIGHT, FULL>(F, uni, c, o1, q);
 #define ACQ_CMP(expr) { _Pragma("unroll") for (int k = 0; k < V; ++k) { const float A = p[k], B = q[k]; const int32_t IA = (int32_t)fbits(A), IB = (int32_t)fbits(B); (void)IA; (void)IB; p[k] = mask(expr); } } break
 				switch (aux2) {
 				case VVM_ACQ_LT: ACQ_CMP(A < B);
@@ -394,6 +399,22 @@ DEV void run_tile8(const void* prog_in, gu64* status, bool last_tile, const Ctx&
 			continue;
 		}
 
+		if (FULL && op == VVM_DOP_UPDATE_ID) {
+			// the ID register of every instance of the tile goes to a staging slot as it is, with the lane's acquireindex result next to it;
+			// apply_update_id does the rest once the tile's output position is known
+			const uint32_t slot_index = o4 | (o5 << 16);
+			float v[V];
+			fetch8<V, LIGHT, FULL>(F, uni, c, o0, v);
+			float* slot = (float*)(lds + LDS_STAGE_OFF(FULL)) + (slot_index & (VVM_STAGE_SLOTS - 1u)) * (VVM_BLOCK_THREADS * V) + c.tid * V;
+			{ f4a q; q.x = v[0]; q.y = v[1]; q.z = v[2]; q.w = v[3]; *(f4a*)slot = q; }
+			uint32_t exists = 0;
+#pragma unroll
+			for (int k = 0; k < V; ++k) exists |= ((c.inst0 + slot_offset<V>(k) < c.num_instances) ? 1u : 0u) << k;
+			((uint32_t*)(lds + LDS_STAGE_KEEP_OFF(V, FULL, LIGHT)))[c.tid] = t_rank | (t_keep << 16) | (exists << 24);
+			stage_end = max(stage_end, slot_index + 1u);      // (the group's last slot: outputs staged after this one lie below it)
+			continue;
+		}
+
 		// Output instruction: aux = pair count (1..3), sources o0..o2, w3 = output-list index of the first pair; the pair's staging slot is
 		// that index modulo VVM_STAGE_SLOTS.  Without an acquireindex before it nothing survives (VectorVMRuntime.cpp:565, 769).
 		{
@@ -414,7 +435,7 @@ DEV void run_tile8(const void* prog_in, gu64* status, bool last_tile, const Ctx&
 			uint64_t srcs = (uint64_t)o0 | ((uint64_t)o1 << 16) | ((uint64_t)o2 << 32);
 			for (uint32_t j = 0; j < aux; ++j, srcs >>= 16, slot += VVM_BLOCK_THREADS * V) {
 				float v[V];
-				fetch8<V, LIGHT>(F, uni, c, (uint32_t)srcs & 0xFFFFu, v);
+				fetch8<V, LIGHT, FULL>(F, uni, c, (uint32_t)srcs & 0xFFFFu, v);
 				if (kind & 1u) {
 					if (kind == 1) {
 #pragma unroll
@@ -454,9 +475,9 @@ DEV void run_tile8(const void* prog_in, gu64* status, bool last_tile, const Ctx&
 	pend.unresolved = t_pending; pend.total = t_total; pend.base = t_base; pend.stage_end = stage_end; pend.last = last_tile;
 	pend.tile_local = tile_local; pend.status = status; pend.out_list = c.out_list;
 	pend.ride = LIGHT ? 0u : (t_keep | (t_rank << 8) | (t_rank_b << 20));
-	if constexpr (!LIGHT && V == 8) {
+	if constexpr ((!LIGHT && V == 8) || RIDE) {
 		// the lane's acquireindex result for vvm_through_kernel, straight from the tile that made it (the light kernel keeps the word for
-		// its riding outputs and stores it in store_tile; a four-wide program of many registers hands no streams through)
+		// its riding outputs and stores it in store_tile; four-wide: the instantiation that lean programs with transcendental functions run on)
 		const uint64_t ride_base = sload64(c.out_list - 3, 0);
 		if (ride_base != 0) {
 			const rsrc_t rr = make_rsrc(ride_base + (uint64_t)tile_local * (VVM_BLOCK_THREADS * 4u), VVM_BLOCK_THREADS * 4u);

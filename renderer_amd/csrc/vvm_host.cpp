@@ -268,12 +268,16 @@ namespace {
 // The program as it lies in device memory (VvmDevIns): the linker's instructions, each followed by what the hand-written core of the
 // eight-wide kernels executes from (vvm_threaded.h): the routine for the instruction's op and operand kinds, and its operands as bytes.
 // An instruction gets a routine when it is an ordinary one whose op has routines, whose operands are per-lane registers of the file
-// (light program: eight registers and the two riding ones; a program of many registers: 44; otherwise sixteen) or uniform registers, not all of them uniform, and
+// (light program: eight registers and the two riding ones; a program of many registers: 44 or 32; otherwise sixteen) or uniform registers, not all of them uniform, and
 // whose destination is a register of the file.  The other kernels read the linker's four words only.
 void encode_device_program(const vvm::LinkedProgram& lp, std::vector<VvmDevIns>& out)
 {
-	// (a program of more than sixteen registers runs four instances per lane: its registers are four VGPRs each, VVM_DESC_REGS_OF_4)
-	const uint32_t file_regs = lp.light ? VVM_LIGHT_RIDE_REG + 2u : lp.many_registers ? 44u : 16u;
+	// (a program of more than sixteen registers runs four instances per lane: its registers are four VGPRs each, VVM_DESC_REGS_OF_4.
+	// The kernel of plain scripts has 44 of them in its file, the one with the transcendental / noise / ID instructions 32: a plain
+	// program that can be sent there too -- as one of several passes, or for the reference generator's words -- gets routines for
+	// what both have in their files; the rest of its instructions run without one on either.)
+	const bool both_kernels = lp.full_kernel || lp.num_passes > 1 || !lp.rand_draws.empty();
+	const uint32_t file_regs = lp.light ? VVM_LIGHT_RIDE_REG + 2u : lp.many_registers ? (both_kernels ? 32u : 44u) : 16u;
 	const uint32_t vgprs_per_reg = lp.many_registers ? 4u : 8u;
 	out.clear();
 	out.reserve(lp.code.size() + 1);
@@ -350,6 +354,17 @@ int resolve_maps(vvm_state* st, const vvm_exec_context* ctx)
 	return VVM_OK;
 }
 
+// A four-wide program of at most sixteen registers that needs a kernel with the transcendental / noise / ID instructions has two to
+// choose from: the one with the compiled interpreter loop (three workgroups per CU) and the one of many registers, which runs
+// ordinary instructions through the hand-written routines (two per CU): see LinkedProgram::prefers_routines.
+// VVM_FULL_ROUTINES=0 / 1: never / always the latter (to measure the choice).
+bool full_prefers_routines(const vvm::LinkedProgram& lp)
+{
+	static const char* forced = getenv("VVM_FULL_ROUTINES");
+	if (forced && (forced[0] == '0' || forced[0] == '1')) return forced[0] == '1';
+	return lp.prefers_routines;
+}
+
 struct PreparedExec {
 	const vvm::LinkedProgram* lp = nullptr;
 	const VvmIns* d_code = nullptr;
@@ -373,7 +388,7 @@ struct PreparedExec {
 	const int32_t* free_read_snapshot = nullptr;       // ... and where the copy of the FreeIDTable entries lies that the chunk's acquire_id reads
 	bool full() const { return lp->full_kernel || reference_random; }
 	// what vvm_launch_exec_kernel takes as many_registers (a program with two chains runs four-wide on the kernel with 32 registers: it has the second chain)
-	bool launch_many() const { return light || lp->many_registers || (lp->num_chains > 1 && instances_per_lane == 4); }
+	bool launch_many() const { return light || lp->many_registers || (lp->num_chains > 1 && instances_per_lane == 4) || (full() && instances_per_lane == 4 && full_prefers_routines(*lp)); }
 	// registers in LDS slots on the kernel the Exec runs on (a plain program of many registers on a kernel with the transcendental
 	// functions, for the reference generator's words or as one of several fused passes: 32 resident ones there, not 44)
 	uint32_t lds_slots() const { return full() ? lp->lds_slots_with_32_resident() : lp->lds_spill_slots; }

@@ -1697,8 +1697,8 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (IS_LIGHT(V, SPILL) ? 3 : V
 	float* lds_spill = (float*)(lds + LDS_SPILL_OFF(V, FULL, IS_LIGHT(V, SPILL)));
 	// (eight instances per lane: the register file, in fixed VGPRs from here to the end of the kernel; the light kernel's riding outputs
 	// wait in it from one tile to the next)
-	constexpr bool THREADED = V == 8 || (V == 4 && SPILL && !FULL);      // the kernels whose tile program is run_tile8
-	FileOf<(THREADED ? V : 8), IS_LIGHT(V, SPILL)> file8;
+	constexpr bool THREADED = V == 8 || (V == 4 && SPILL);      // the kernels whose tile program is run_tile8
+	FileOf<(THREADED ? V : 8), IS_LIGHT(V, SPILL), THREADED && FULL> file8;
 	if constexpr (THREADED) file_clear(file8);
 	Pending pend;
 	pend.active = false; pend.unresolved = false; pend.last = false; pend.total = 0; pend.base = 0; pend.stage_end = 0; pend.tile_local = 0;
@@ -1806,7 +1806,7 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (IS_LIGHT(V, SPILL) ? 3 : V
 		c.reg_shift = (THREADED && V == 4 && (DESC_U32(dp, flags) & VVM_DESC_REGS_OF_4)) ? 2u : 3u;
 		if (!(dbgw & 1u)) {
 			if constexpr (THREADED)
-				run_tile8<V, IS_LIGHT(V, SPILL)>((const void*)DESC_PTR(dp, prog), (gu64*)DESC_PTR(dp, status), last_tile, c, lds, tile_local, tag, env.ls, dbgw, pend, resolves, pre, have_pre && first_pass, file8);
+				run_tile8<V, IS_LIGHT(V, SPILL), FULL, RIDE>((const void*)DESC_PTR(dp, prog), (gu64*)DESC_PTR(dp, status), last_tile, c, lds, tile_local, tag, env.ls, dbgw, pend, resolves, pre, have_pre && first_pass, file8);
 			else
 				run_tile<V, SPILL, FULL, RIDE>((const VvmIns*)DESC_PTR(dp, prog), (gu64*)DESC_PTR(dp, status), last_tile, c, lds, tile_local, tag, env.ls, dbgw, pend, resolves, pre, have_pre && first_pass);
 		}
@@ -2115,7 +2115,8 @@ extern "C" int vvm_launch_exec_kernel(int instances_per_lane, const VvmExecDesc*
 		else VVM_LAUNCH(8, false, false);
 	} else if (instances_per_lane == 4) {
 		if (full) {
-			if (spill) VVM_LAUNCH(4, true, true);
+			if (spill && full == 2) hipLaunchKernelGGL((vvm_exec_kernel<4, true, true, false, true>), dim3(grid), dim3(VVM_BLOCK_THREADS), lds_bytes, stream, env);      // (leaves ride words)
+			else if (spill) VVM_LAUNCH(4, true, true);
 			else if (full == 2) hipLaunchKernelGGL((vvm_exec_kernel<4, false, true, false, true>), dim3(grid), dim3(VVM_BLOCK_THREADS), lds_bytes, stream, env);      // (leaves ride words)
 			else VVM_LAUNCH(4, false, true);
 		}
@@ -2136,6 +2137,7 @@ extern "C" int vvm_kernel_max_dynamic_lds(void)
 	// raises the dynamic-LDS limit of the kernels that use more than the default 64 KB, on the current device
 #ifndef VVM_EXPERIMENT_ONE_KERNEL
 	(void)hipFuncSetAttribute((const void*)vvm_exec_kernel<4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+	(void)hipFuncSetAttribute((const void*)vvm_exec_kernel<4, true, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
 	(void)hipFuncSetAttribute((const void*)vvm_exec_kernel<1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
 	(void)hipFuncSetAttribute((const void*)vvm_exec_kernel<4, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
 	(void)hipFuncSetAttribute((const void*)vvm_exec_kernel<1, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);

@@ -962,6 +962,23 @@ static int link_program_as(const ThawedScript& s, bool force_narrow, LinkedProgr
 	lp.resident_regs = RV;
 	lp.many_registers = (RV > 16 && V == 4) || packed > RV;
 	lp.lds_spill_slots = packed > RV ? packed - RV : 0;
+	{
+		// Which of the two four-wide kernels with the transcendental / noise / ID instructions a program of at most sixteen registers
+		// runs on.  Measured on 16 Mi instances (tools/full_kernel_choice.py): the kernel of many registers saves about 4 us per ordinary
+		// instruction (its hand-written routines) and, with two workgroups per CU instead of three, loses 10 to 16 us per transcendental
+		// function or perlin3 call and over 100 us per curl_noise3 call.  In ordinary instructions:
+		uint32_t ordinary_ins = 0, heavy_weight = 0;
+		for (const VvmIns& k : lp.code) {
+			const uint32_t op = k.w0 & 0xFFu;
+			if (op == VVM_OP_done || op >= VVM_DOP_LOADN16) continue;
+			if (op == VVM_OP_external_func_call) heavy_weight += ((k.w0 >> 16) & 0xFFu) == VVM_EXTFN_CURL_NOISE3 ? 16u : 5u;      // (one instruction per output of the call)
+			else if (op == VVM_OP_fmod || op == VVM_OP_fmod_add) heavy_weight += 2u;
+			else if (op == VVM_OP_pow || op == VVM_OP_atan2 || op == VVM_OP_asin || op == VVM_OP_acos || op == VVM_OP_atan || op == VVM_OP_tan) heavy_weight += 4u;
+			else if (g_ops[op].heavy) heavy_weight += 3u;
+			else ++ordinary_ins;
+		}
+		lp.prefers_routines = V == 4 && ordinary_ins >= heavy_weight;
+	}
 	for (VvmIns& k : lp.code) {
 		const uint32_t op = k.w0 & 0xFFu;
 		if (op == VVM_OP_done || op >= VVM_DOP_LOADN16) k.w0 = (k.w0 & ~(7u << 8)) | (VVM_NIN_SPECIAL << 8);

@@ -44,7 +44,7 @@ def constants(name, which):
 PADS = 18      # values kept alive across the tested instructions: more than the sixteen registers of the eight-wide file
 
 
-def script_for(name, nin, mask, many=False):
+def script_for(name, nin, mask, many=False, trig=False):
     s = Script()
     ones = s.const(0)
     operands, streams = [], 0
@@ -62,6 +62,8 @@ def script_for(name, nin, mask, many=False):
         pads = s.temps(PADS)
         for i, p in enumerate(pads):
             s.op("bit_xor", first_stream if i == 0 else pads[i - 1], s.const(1 + i % 5), p)
+        if trig:      # (an instruction of the kernels with the transcendental functions: the whole script runs there)
+            s.op("sin", s.const(1), pads[0])
     t = s.temps(2)
     s.op(name, *operands, t[0])
     s.op(name, *operands, t[1])      # (the second one executes from the other instruction buffer)
@@ -94,15 +96,17 @@ def test_every_routine_of_the_op(name, nin):
             _check8(built, [constants(name, which)], ins, [f32, f32], n)
 
 
+@pytest.mark.parametrize("trig", [False, True], ids=["plain", "with_sin"])
 @pytest.mark.parametrize("name,nin", routine_ops(), ids=[n for n, _ in routine_ops()])
-def test_every_routine_of_the_op_four_slots(name, nin):
+def test_every_routine_of_the_op_four_slots(name, nin, trig):
     """the same with eighteen more values alive across the tested instructions: the script runs four instances per lane on the
-    kernel with 32 registers, whose routines work on four VGPRs per register"""
+    kernel of many registers, whose routines work on four VGPRs per register; with a sine in the script, on the kernel of many
+    registers that has the transcendental functions"""
     be = abi.load_hip_backend()
     code_of_op = opcodes.CODE[name]
     n = 1300      # two tiles of the four-wide kernels, the second one partial
     for mask in range((1 << nin) - 1):
-        built, streams = script_for(name, nin, mask, many=True)
+        built, streams = script_for(name, nin, mask, many=True, trig=trig)
         dev = be.inspect_device_code(built.blob, 0)
         with_routine = [d for d in dev if (d[0] & 0xFF) == code_of_op and ((d[0] >> 8) & 7) == nin and d[4] != 0]
         assert len(with_routine) >= 2, "%s mask %d: the program does not run the op in a routine twice" % (name, mask)      # (the fill uses two of the ops itself)
@@ -113,4 +117,5 @@ def test_every_routine_of_the_op_four_slots(name, nin):
             ref, ref_n, _ = run_oracle(built, consts, ins, [f32] * 3, n)
             got, got_n, info = run_hip(built, consts, ins, [f32] * 3, n)
             assert info.InstancesPerLane == 4 and info.NumVirtualRegisters > 16 and info.LdsSpillRegisters == 0
+            assert bool(info.Flags & 0x10000) == trig      # (the script needs the kernels with the transcendental functions)
             _compare8(got, got_n, ref, ref_n, n, {})

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """How the kernel shapes compare on one arithmetic script as the number of live registers grows: all registers in VGPRs (eight or
 four instances per lane), some in LDS (four per lane), one instance per lane.  4 streams in / 4 out, 64 dependent instructions
-over `live` accumulators."""
+over `live` accumulators.  --trig: two of the instructions are sines (the script then runs on the kernels that have the transcendental
+functions)."""
 import json
 import os
 import struct
@@ -12,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def script(n_ops, live):
+def script(n_ops, live, trig=False):
     from renderer_amd.assembler import FLOAT, Script
     s = Script()
     ins = [s.input(0, FLOAT, i) for i in range(4)]
@@ -25,7 +26,9 @@ def script(n_ops, live):
     for k in range(n_ops):
         t = s.temp()
         a, b = acc[k % live], acc[(k + 1) % live]
-        if k % 3 == 0:
+        if trig and k in (20, 41):
+            s.op("sin", a, t)
+        elif k % 3 == 0:
             s.op("mad", a, s.const(1), b, t)
         elif k % 3 == 1:
             s.op("mul", a, b, t)
@@ -55,7 +58,7 @@ def main():
     outs = [torch.zeros(n + 64, dtype=torch.float32, device=dev) for _ in range(4)]
     consts = struct.pack("<I2f", 0xFFFFFFFF, 1.0009765625, 0.125) + bytes(4)
     for live in (4, 8, 12, 16, 20, 28, 40, 44, 48, 55, 64):
-        built = script(64, live)
+        built = script(64, live, "--trig" in sys.argv)
         st = VectorVMState(built.blob, be)
         info = st.info()
         frame = st.frame([abi.DataSet([t.data_ptr() for t in ins], [t.data_ptr() for t in outs], 0)], n, [consts])
