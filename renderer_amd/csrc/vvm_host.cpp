@@ -354,13 +354,13 @@ int resolve_maps(vvm_state* st, const vvm_exec_context* ctx)
 	return VVM_OK;
 }
 
-// A four-wide program of at most sixteen registers that needs a kernel with the transcendental / noise / ID instructions has two to
-// choose from: the one with the compiled interpreter loop (three workgroups per CU) and the one of many registers, which runs
-// ordinary instructions through the hand-written routines (two per CU): see LinkedProgram::prefers_routines.
-// VVM_FULL_ROUTINES=0 / 1: never / always the latter (to measure the choice).
-bool full_prefers_routines(const vvm::LinkedProgram& lp)
+// A four-wide program of at most sixteen registers has two kernels to choose from: the one with the compiled interpreter loop (four
+// workgroups per CU; with the transcendental / noise / ID instructions three) and the one of many registers, which runs ordinary
+// instructions through the hand-written routines (two per CU): see LinkedProgram::prefers_routines.
+// VVM_FOUR_WIDE_ROUTINES=0 / 1: never / always the latter (to measure the choice).
+bool four_wide_prefers_routines(const vvm::LinkedProgram& lp)
 {
-	static const char* forced = getenv("VVM_FULL_ROUTINES");
+	static const char* forced = getenv("VVM_FOUR_WIDE_ROUTINES");
 	if (forced && (forced[0] == '0' || forced[0] == '1')) return forced[0] == '1';
 	return lp.prefers_routines;
 }
@@ -388,7 +388,7 @@ struct PreparedExec {
 	const int32_t* free_read_snapshot = nullptr;       // ... and where the copy of the FreeIDTable entries lies that the chunk's acquire_id reads
 	bool full() const { return lp->full_kernel || reference_random; }
 	// what vvm_launch_exec_kernel takes as many_registers (a program with two chains runs four-wide on the kernel with 32 registers: it has the second chain)
-	bool launch_many() const { return light || lp->many_registers || (lp->num_chains > 1 && instances_per_lane == 4) || (full() && instances_per_lane == 4 && full_prefers_routines(*lp)); }
+	bool launch_many() const { return light || lp->many_registers || (instances_per_lane == 4 && (lp->num_chains > 1 || four_wide_prefers_routines(*lp))); }
 	// registers in LDS slots on the kernel the Exec runs on (a plain program of many registers on a kernel with the transcendental
 	// functions, for the reference generator's words or as one of several fused passes: 32 resident ones there, not 44)
 	uint32_t lds_slots() const { return full() ? lp->lds_slots_with_32_resident() : lp->lds_spill_slots; }

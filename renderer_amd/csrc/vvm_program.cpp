@@ -963,10 +963,11 @@ static int link_program_as(const ThawedScript& s, bool force_narrow, LinkedProgr
 	lp.many_registers = (RV > 16 && V == 4) || packed > RV;
 	lp.lds_spill_slots = packed > RV ? packed - RV : 0;
 	{
-		// Which of the two four-wide kernels with the transcendental / noise / ID instructions a program of at most sixteen registers
-		// runs on.  Measured on 16 Mi instances (tools/full_kernel_choice.py): the kernel of many registers saves about 4 us per ordinary
-		// instruction (its hand-written routines) and, with two workgroups per CU instead of three, loses 10 to 16 us per transcendental
-		// function or perlin3 call and over 100 us per curl_noise3 call.  In ordinary instructions:
+		// Which of the two four-wide kernels a program of at most sixteen registers runs on.  Measured (tools/full_kernel_choice.py,
+		// tools/reg_cliff.py --four-wide): the kernel of many registers saves about 4 us per ordinary instruction at 16 Mi instances
+		// (its hand-written routines; 0.1 us at 64 Ki instances, where the 9 instructions of a short script run 0.4 us slower on it)
+		// and, with two workgroups per CU instead of three, loses 10 to 16 us per transcendental function or perlin3 call and over
+		// 100 us per curl_noise3 call.  In ordinary instructions:
 		uint32_t ordinary_ins = 0, heavy_weight = 0;
 		for (const VvmIns& k : lp.code) {
 			const uint32_t op = k.w0 & 0xFFu;
@@ -977,7 +978,7 @@ static int link_program_as(const ThawedScript& s, bool force_narrow, LinkedProgr
 			else if (g_ops[op].heavy) heavy_weight += 3u;
 			else ++ordinary_ins;
 		}
-		lp.prefers_routines = V == 4 && ordinary_ins >= heavy_weight;
+		lp.prefers_routines = V == 4 && ordinary_ins >= heavy_weight + 12u;
 	}
 	for (VvmIns& k : lp.code) {
 		const uint32_t op = k.w0 & 0xFFu;

@@ -49,9 +49,10 @@ struct LinkedProgram {
 	bool     light = false;            // linked for the light eight-wide kernel (eight resident registers, six staged outputs and up to
 	                                   // two that wait in registers VVM_LIGHT_RIDE_REG, +1)
 	bool     full_kernel = false;      // needs the transcendental / noise kernel
-	bool     prefers_routines = false; // ... and, with at most sixteen registers, is expected to run faster on the four-wide kernel of many
-	                                   // registers (ordinary instructions through hand-written routines, two workgroups per CU) than on
-	                                   // the one with the compiled loop (three per CU): many ordinary instructions per heavy one
+	bool     prefers_routines = false; // a four-wide program of at most sixteen registers that is expected to run faster on the four-wide kernel
+	                                   // of many registers (ordinary instructions through hand-written routines, two workgroups per CU) than
+	                                   // on the one with the compiled loop (more workgroups per CU): enough ordinary instructions, and many
+	                                   // of them per transcendental / noise instruction
 	bool     uses_perlin = false;
 	// update_id / acquire_id: one entry per dataset whose ID tables this pass works on (its index is the slot of the dataset's
 	// VvmIdDesc behind the Exec descriptor); a dataset is either updated (at most one update_id, in the dataset's own pass) or

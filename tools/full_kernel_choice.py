@@ -2,7 +2,7 @@
 """Which four-wide kernel a script with transcendental / noise instructions and at most sixteen registers is faster on: the one with
 the compiled interpreter loop (three workgroups per CU) or the one that runs ordinary instructions through the hand-written
 routines (two per CU).  One script per mix of ordinary instructions and heavy ones, 16 Mi instances, 4 streams in / 4 out.
-Run twice, with VVM_FULL_ROUTINES=0 and =1 (the library reads it once), and compare the lines."""
+Run twice, with VVM_FOUR_WIDE_ROUTINES=0 and =1 (the library reads it once), and compare the lines."""
 import json
 import os
 import struct
@@ -90,7 +90,7 @@ def main():
             st.finish(frame)
             ms, launches = st.collect_kernel_ms()
             print(json.dumps({"heavy": heavy, "ordinary": n_ordinary, "heavy_count": n_heavy, "registers": int(info.NumVirtualRegisters),
-                              "routines": os.environ.get("VVM_FULL_ROUTINES", "default"), "kernel_ms": round(ms / launches, 4)}), flush=True)
+                              "routines": os.environ.get("VVM_FOUR_WIDE_ROUTINES", "default"), "kernel_ms": round(ms / launches, 4)}), flush=True)
             st.close()
 
 

@@ -2,7 +2,8 @@
 """How the kernel shapes compare on one arithmetic script as the number of live registers grows: all registers in VGPRs (eight or
 four instances per lane), some in LDS (four per lane), one instance per lane.  4 streams in / 4 out, 64 dependent instructions
 over `live` accumulators.  --trig: two of the instructions are sines (the script then runs on the kernels that have the transcendental
-functions)."""
+functions).  --four-wide: no eight-wide kernels (scripts of at most sixteen registers run four instances per lane, as small Execs do).
+--instances N."""
 import json
 import os
 import struct
@@ -53,7 +54,8 @@ def main():
     from renderer_amd.runtime import VectorVMState
     dev = torch.device("cuda", 0)
     be = abi.load_hip_backend()
-    n = 16 * 1024 * 1024
+    n = int(sys.argv[sys.argv.index("--instances") + 1]) if "--instances" in sys.argv else 16 * 1024 * 1024
+    opt = abi.ExecOptions(Flags=abi.VVM_EXEC_NO_EIGHT_WIDE) if "--four-wide" in sys.argv else None
     ins = scripts.fountain_streams_torch(0, n, dev, pad=64)[:4]
     outs = [torch.zeros(n + 64, dtype=torch.float32, device=dev) for _ in range(4)]
     consts = struct.pack("<I2f", 0xFFFFFFFF, 1.0009765625, 0.125) + bytes(4)
@@ -63,10 +65,10 @@ def main():
         info = st.info()
         frame = st.frame([abi.DataSet([t.data_ptr() for t in ins], [t.data_ptr() for t in outs], 0)], n, [consts])
         for _ in range(2):
-            st.exec(frame)
+            st.exec(frame, opt)
         st.enable_timing(True)
         for _ in range(5):
-            st.exec_async(frame)
+            st.exec_async(frame, opt)
         st.finish(frame)
         ms, launches = st.collect_kernel_ms()
         n_ins = 64 + live + sum(len(range(i + 4, live, 4)) for i in range(4))
