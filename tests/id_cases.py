@@ -15,14 +15,19 @@ from renderer_amd.assembler import FLOAT, INT32, Script
 from vm_harness import IdState
 
 
-def update_script(extra_outputs: int = 0, id_from_temp: bool = False):
-    """keep = x < limit; acquireindex(keep); update_id(id); outputs x and id (and extra copies of x)."""
+def update_script(extra_outputs: int = 0, id_from_temp: bool = False, live_values: int = 0):
+    """keep = x < limit; acquireindex(keep); update_id(id); outputs x and id (and extra copies of x).
+    live_values: that many more values are alive across the ID instruction (the kernels of many registers); their sum is one more
+    output."""
     s = Script()
     x = s.input(0, FLOAT, 0)
     pid = s.input(0, INT32, 0)
     keep = s.temp()
     s.op("cmplt", x, s.const(0), keep)
     s.acquireindex(keep, 0)
+    held = s.temps(live_values) if live_values else []
+    for i, t in enumerate(held):
+        s.op("mad", x if i == 0 else held[i - 1], s.const(2), s.const(2), t)
     id_reg = pid
     if id_from_temp:
         id_reg = s.temp()
@@ -33,6 +38,13 @@ def update_script(extra_outputs: int = 0, id_from_temp: bool = False):
         t = s.temp()
         s.op("add", x, s.const(2), t)
         pairs.append((t, s.output(0, FLOAT, 1 + i)))
+    if held:
+        acc = held[0]
+        for t in held[1:]:
+            nxt = s.temp()
+            s.op("add", acc, t, nxt)
+            acc = nxt
+        pairs.append((acc, s.output(0, FLOAT, 1 + extra_outputs)))
     s.output_data(FLOAT, 0, pairs)
     s.output_data(INT32, 0, [(pid, s.output(0, INT32, 0))])
     return s.build()

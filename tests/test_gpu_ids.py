@@ -40,6 +40,27 @@ def test_update_id_matches_the_oracle(n, death, page_kb, extra, from_temp):
     assert (got.num_free, got.max_used) == (want.num_free, want.max_used)
 
 
+@pytest.mark.parametrize("n,death,page_kb,live,from_temp", [(5, 0.5, 64, 20, False), (4099, 0.3, 2, 20, True), (70001, 0.5, 64, 28, False),
+                                                         (70001, 0.9, 2, 36, True), (300000, 0.02, 64, 40, False)])
+def test_update_id_with_many_live_values(n, death, page_kb, live, from_temp):
+    """the same on the four-wide kernel of many registers that has the ID instructions: ordinary instructions through the hand-written
+    routines, 32 registers in VGPRs, the rest (live = 36, 40) in LDS slots"""
+    x, ids, st, limit = _update_case(n, death, 11 + n)
+    script = id_cases.update_script(id_from_temp=from_temp, live_values=live)
+    consts = [id_cases.update_constants(limit)]
+    dtypes = [f32, f32, np.int32]
+    want, got = st.copy(), st.copy()
+    ref, ref_n, _ = run_oracle(script, consts, [x, ids], dtypes, n, ids=want, page_kb=page_kb)
+    out, out_n, info = run_hip(script, consts, [x, ids], dtypes, n, ids=got, page_kb=page_kb)
+    assert info.InstancesPerLane == 4 and info.NumVirtualRegisters > 16 and info.LdsSpillRegisters == max(0, info.NumVirtualRegisters - 32)
+    assert out_n == ref_n
+    for a, b in zip(out, ref):
+        assert np.array_equal(a[:out_n].view(np.uint32), b[:ref_n].view(np.uint32))
+    assert np.array_equal(got.id_table, want.id_table)
+    assert np.array_equal(got.free_table, want.free_table)
+    assert (got.num_free, got.max_used) == (want.num_free, want.max_used)
+
+
 def test_update_id_with_instance_offset():
     n, off = 5000, 37
     x, ids, st, limit = _update_case(n, 0.4, 3)
