@@ -1042,13 +1042,9 @@ template <int V, bool FULL, bool LIGHT, bool TWO> DEV void store_tile(Pending& p
 						hi.x = v[4]; hi.y = v[5]; hi.z = v[6]; hi.w = v[7];
 						__builtin_amdgcn_raw_buffer_store_b128(lo, rs, (int)(a.i0 * 4u), 0, AUX_STREAM_STORE);
 						__builtin_amdgcn_raw_buffer_store_b128(hi, rs, (int)((VVM_HALF_TILE + a.i0) * 4u), 0, AUX_STREAM_STORE);
+#ifdef VVM_EXPERIMENT_RIDE_WITHIN_LANE
 					} else {
-						// A tile that keeps more than three quarters of its instances: the survivors among the lane's four instances of a half
-						// lie next to each other in the output (ranks r, r+1, ..).  Compacted within the lane they go out as one 128-bit store
-						// (all four alive, the common case when few particles die), or as a 64-bit and / or a 32-bit one; the address
-						// arithmetic comes first and the six stores follow each other without anything scheduled in between.  (One 32-bit
-						// store per survivor at its rank, each behind its own address arithmetic, measured 0.96 ms against 0.75 ms for the
-						// 64 Mi-instance fountain Exec with 1 % of the particles dying.)
+						// (the path this kernel had before the one below, kept to measure against)
 						uint32_t off[6], w1v[2], wsv[2];
 						u32x4 q4[2];
 #pragma unroll
@@ -1077,6 +1073,36 @@ template <int V, bool FULL, bool LIGHT, bool TWO> DEV void store_tile(Pending& p
 						}
 						__builtin_amdgcn_sched_barrier(0);
 					}
+#else
+					} else {
+						// A tile that keeps more than three quarters of its instances, but not all: the staging slots had no room for these
+						// values when the tile ran; they have now (every staged value has been read above), so the survivors' values go
+						// through the output's own slot like a staged output's (two more barriers; all conditions up to here are the same for
+						// every thread of the workgroup) and leave with 128 bits per lane and half.  (Before: compacted within the lane and
+						// stored as one 128-, 64- and / or 32-bit store per half: six store instructions per lane and output, most of them
+						// to nowhere.)
+						float* const slot = (float*)(lds + LDS_STAGE_OFF(FULL)) + h * (VVM_BLOCK_THREADS * V);
+						float* const sink = (float*)(lds + LDS_STAGE_SINK_OFF(V, FULL, true)) + tid_here;
+						__syncthreads();
+						uint32_t r = (ride_here >> 8) & 0xFFFu;
+#pragma unroll
+						for (int k = 0; k < 8; ++k) {
+							if (k == 4) r = ride_here >> 20;
+							const bool keep = (ride_here >> k) & 1u;
+							float* q = keep ? (slot + r) : sink;
+							*q = ride[8 * h + k];
+							r += keep ? 1u : 0u;
+						}
+						__syncthreads();
+						const f4a x0 = *(const f4a*)(slot + tid_here * 4u);
+						const f4a x1 = *(const f4a*)(slot + VVM_HALF_TILE + tid_here * 4u);
+						u32x4 y0, y1;
+						y0.x = fbits(x0.x); y0.y = fbits(x0.y); y0.z = fbits(x0.z); y0.w = fbits(x0.w);
+						y1.x = fbits(x1.x); y1.y = fbits(x1.y); y1.z = fbits(x1.z); y1.w = fbits(x1.w);
+						__builtin_amdgcn_raw_buffer_store_b128(y0, rs, (int)(tid_here * 16u), 0, AUX_STREAM_STORE);
+						__builtin_amdgcn_raw_buffer_store_b128(y1, rs, (int)((VVM_HALF_TILE + tid_here * 4u) * 4u), 0, AUX_STREAM_STORE);
+					}
+#endif
 				}
 			}
 		}
