@@ -291,7 +291,15 @@ VVM_API void vvm_xorwow_seed(uint64_t cycles_first, uint64_t cycles_second, uint
  * finish, so a second vvm_exec_async before the finish returns VVM_E_INVALID_ARG.  A script with acquire_id AND
  * update_id on one dataset hands IDs from chunk to chunk of the reference's chunking (VectorVMRuntime.cpp:1175,
  * 1411-1423): its Exec runs one launch per chunk, each finished before the next, inside vvm_exec_async itself (the
- * call is synchronous for such a script and vvm_exec_finish only reports). */
+ * call is synchronous for such a script and vvm_exec_finish only reports).
+ *
+ * Under HIP graph capture: a vvm_exec_async whose vvm_exec_options.Stream is being captured adds kernel nodes to the graph and
+ * nothing else, provided that (a) the state's last Exec ran on that same stream with at least as many instances (its buffers
+ * are sized and no other stream has to be waited for), (b) the parameter block travels as a kernel argument (no ID
+ * instructions, at most 1 KB of constants and stream addresses, no VVM_EXEC_PARAMS_IN_MEMORY), (c) RandXorwowState is not set
+ * and kernel timing is off.  Every replay of the graph is then that Exec again, on the stream addresses, constants and
+ * NumInstances it was captured with; vvm_exec_finish, called once the replays have been waited for, reports the last one's
+ * counts (or leave them on the device: DeviceCounts).  tests/test_gpu_graph_capture.py. */
 VVM_API int vvm_exec_async(vvm_exec_context* ctx, const vvm_exec_options* opt);
 VVM_API int vvm_exec_finish(vvm_exec_context* ctx);
 

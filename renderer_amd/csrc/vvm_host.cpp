@@ -1412,6 +1412,17 @@ VVM_API int vvm_exec_finish(vvm_exec_context* ctx)
 		}
 		HIP_TRY(hipStreamSynchronize(st->last_stream));
 		if (pending && st->cur_counts_in_launch && !with_caller) memcpy(st->h_counts, (const uint8_t*)(st->h_counts + mirror) + offsetof(VvmLaunchState, reserved), with_ids * 4);
+		if (pending && ran && st->cur_launch) {
+			// The epoch word as the device holds it now.  It equals the host's twin unless launches went through these words that the
+			// host did not issue itself: replays of a graph that an enqueue was captured into.  The twin follows the device; a value
+			// below the twin's means that the count has gone round, and the next launch clears the look-back words first.
+			const uint32_t on_device = ((const VvmLaunchState*)(st->h_counts + mirror))->epoch & 0x3FFFFFFFu;
+			EpochMirror& twin = st->cur_launch == st->d_launch ? st->epoch : g_dev.scratch_epoch[st->device];
+			if (on_device != 0 && on_device != twin.next) {
+				if (on_device < twin.next) twin.wrapped = true;
+				twin.next = on_device;
+			}
+		}
 	}
 	st->results_pending = false;
 	st->in_flight = false;

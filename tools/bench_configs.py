@@ -312,7 +312,38 @@ def main():
     if "one_million" in which:
         n = 1024 * 1024
         w = scripts.fountain()
-        run_single("fountain 1Mi", w, scripts.fountain_streams_torch(0, n, dev, pad=PAD), 8, n)
+        ins1m = scripts.fountain_streams_torch(0, n, dev, pad=PAD)
+        run_single("fountain 1Mi", w, ins1m, 8, n)
+        # the same Exec as nodes of a HIP graph: two states that hand the particles back and forth (A's outputs are B's inputs), sixteen
+        # ticks of the pair captured once and replayed; no host work per Exec, so what is left is the kernel and the gap between kernels
+        from renderer_amd import hip
+        mid = [torch.zeros(n + PAD, dtype=torch.float32, device=dev) for _ in range(8)]
+        back = [torch.zeros(n + PAD, dtype=torch.float32, device=dev) for _ in range(8)]
+        torch.cuda.synchronize()
+        stream = hip.Stream()
+        sa, sb = VectorVMState(w.script.blob, be), VectorVMState(w.script.blob, be)
+        fa = sa.frame([abi.DataSet([t.data_ptr() for t in ins1m], [t.data_ptr() for t in mid], 0)], n, [w.constants])
+        fb = sb.frame([abi.DataSet([t.data_ptr() for t in mid], [t.data_ptr() for t in back], 0)], n, [w.constants])
+        o = abi.ExecOptions(0, 0, 0, stream.value, 0)
+        for _ in range(3):
+            sa.exec(fa, o); sb.exec(fb, o)
+        per_graph = 32
+        stream.begin_capture(hip.hipStreamCaptureModeGlobal)
+        for _ in range(per_graph // 2):
+            sa.exec_async(fa, o); sb.exec_async(fb, o)
+        graph = stream.end_capture()
+        graph.launch(stream); stream.synchronize()
+        replays = max(args.steps, 10)
+        t0 = time.perf_counter()
+        for _ in range(replays):
+            graph.launch(stream)
+        stream.synchronize()
+        el = time.perf_counter() - t0
+        surv = (sa.finish(fa), sb.finish(fb))
+        assert surv == (n, n), surv
+        print(json.dumps({"config": "fountain 1Mi, %d Execs captured into a HIP graph (%d nodes), %d replays" % (per_graph, graph.num_nodes(), replays),
+                          "particles": n, "us_per_exec": el / (replays * per_graph) * 1e6, "updates_per_s": n * replays * per_graph / el}), flush=True)
+        graph.destroy(); sa.close(); sb.close(); stream.destroy()
     if "batch_wide" in which:
         # 4096 emitters x 16 Ki particles whose records carry sixteen attributes that the script hands through (24 streams each way)
         import struct
