@@ -435,7 +435,7 @@ int link_more_passes(const vvm::ThawedScript& s, bool narrow, const vvm::LinkedP
 	d_code.assign(first.num_passes - 1, nullptr);
 	for (uint32_t k = 1; k < first.num_passes; ++k) {
 		std::string err;
-		int rc = vvm::link_program(s, narrow, more[k - 1], err, k);
+		int rc = vvm::link_program(s, narrow, more[k - 1], err, k, false, nullptr, first.paired ? 1 : 0);
 		if (rc != VVM_OK) return fail(rc, err);
 		rc = upload_code(more[k - 1], &d_code[k - 1]);
 		if (rc != VVM_OK) return rc;
@@ -957,6 +957,7 @@ int enqueue_fused_passes(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_op
 		const int rc = prepare(st, ctx, &o, pes[k], k);
 		if (rc != VVM_OK) return rc;
 		if (pes[k].instances_per_lane != pes[0].instances_per_lane || pes[k].instances_per_lane == 8) return VVM_OK;      // (the FULL kernels run four or one)
+		if (pes[k].lp->num_chains > 1) return VVM_OK;      // (... and one chain: passes of two datasets each are launched one after the other)
 		many = many || pes[k].launch_many();
 		spill = std::max(spill, pes[k].lp->lds_slots_with_32_resident());      // (every pass runs on the FULL kernel)
 		ids = ids || pes[k].lp->updates_ids;
@@ -2171,7 +2172,7 @@ static void fill_info(const vvm::ThawedScript& s, const vvm::LinkedProgram& lp, 
 	out->LdsSpillRegisters = lp.lds_spill_slots;
 	out->BytesInPerInstance = lp.bytes_in_per_instance;
 	out->BytesOutPerInstance = lp.bytes_out_per_instance;
-	out->Flags = s.flags | (lp.full_kernel ? 0x10000u : 0u) | (lp.num_chains > 1 ? 0x40000u : 0u);      // (vvm_state_info adds 0x20000: a program for the light eight-wide kernel exists; 0x40000: two acquired datasets in one pass)
+	out->Flags = s.flags | (lp.full_kernel ? 0x10000u : 0u) | (lp.num_chains > 1 ? 0x40000u : 0u) | std::min<uint32_t>(lp.num_passes, 15u) << 20;      // (vvm_state_info adds 0x20000: a program for the light eight-wide kernel exists; 0x40000: two acquired datasets in the first pass; [20:24): passes, i.e. launches, per Exec)
 }
 
 VVM_API int vvm_state_info(const vvm_state* st, vvm_program_info* out)

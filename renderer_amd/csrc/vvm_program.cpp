@@ -332,19 +332,32 @@ template <typename F> static void fold_compares_into_acquires(std::vector<Decode
 static int link_program_as(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, std::string& err, uint32_t pass, bool light, bool allow_chains, bool& chains_failed,
                            const std::vector<uint8_t>* out_select);
 
-int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, std::string& err, uint32_t pass, bool light, const std::vector<uint8_t>* out_select)
+int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, std::string& err, uint32_t pass, bool light, const std::vector<uint8_t>* out_select, int pairing)
 {
-	// first as one pass with two chains, where the script has two acquired datasets; if the program then needs a kernel that
-	// has no second chain, as one pass per dataset
-	const bool try_chains = !light && !force_narrow && pass == 0 && !getenv("VVM_NO_CHAINS");
+	// A script with several acquired datasets: first with the datasets taken two to a pass (each pass a program with two chains, the
+	// last one of an odd number alone); if one of those programs needs a kernel that has no second chain, one pass per dataset.
+	// What pass k means follows from that choice, so it is made once, when pass 0 is linked, for all passes of the script
+	// (LinkedProgram::paired of pass 0 says which; the caller hands it back for the passes behind it).
+	const bool may_pair = !light && !force_narrow && !getenv("VVM_NO_CHAINS");
 	bool chains_failed = false;
-	int rc = link_program_as(s, force_narrow, lp, err, pass, light, try_chains, chains_failed, out_select);
-	if (chains_failed) {
+	if (pairing >= 0 || pass != 0) return link_program_as(s, force_narrow, lp, err, pass, light, may_pair && pairing == 1, chains_failed, out_select);
+	if (may_pair) {
+		int rc = link_program_as(s, force_narrow, lp, err, 0, light, true, chains_failed, out_select);
+		if (!chains_failed) {
+			if (rc != VVM_OK || !lp.paired || lp.num_passes == 1) return rc;
+			bool all = true;
+			for (uint32_t k = 1; k < lp.num_passes && all; ++k) {
+				LinkedProgram trial;
+				std::string why;
+				bool failed = false;
+				all = link_program_as(s, force_narrow, trial, why, k, light, true, failed, nullptr) == VVM_OK;
+			}
+			if (all) return rc;
+		}
 		lp = LinkedProgram();
 		err.clear();
-		rc = link_program_as(s, force_narrow, lp, err, pass, light, false, chains_failed, out_select);
 	}
-	return rc;
+	return link_program_as(s, force_narrow, lp, err, 0, light, false, chains_failed, out_select);
 }
 
 static int link_program_as(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, std::string& err, uint32_t pass, bool light, bool allow_chains, bool& chains_failed,
@@ -535,25 +548,31 @@ static int link_program_as(const ThawedScript& s, bool force_narrow, LinkedProgr
 	// A script that runs acquireindex for several datasets is executed in one pass per dataset: every pass runs the whole
 	// script, but only the pass's dataset is compacted and written (the others' acquireindex and outputs are left out of the
 	// pass's program).  The instructions are pure functions of the inputs, so every pass computes the same values.
-	const bool chains = allow_chains && lp.acquire_order.size() == 2 && lp.id_uses.empty();
-	lp.num_chains = chains ? 2 : 1;
-	lp.num_passes = chains ? 1 : std::max<uint32_t>(1, (uint32_t)lp.acquire_order.size());
+	// (allow_chains: the datasets two to a pass, both acquireindex of a pair in one program, each with its own chain)
+	const uint32_t acquired = (uint32_t)lp.acquire_order.size();
+	lp.paired = allow_chains && acquired >= 2 && lp.id_uses.empty();
+	lp.num_passes = lp.paired ? (acquired + 1) / 2 : std::max<uint32_t>(1, acquired);
 	if (pass >= lp.num_passes) { err = "pass index out of range"; return VVM_E_INVALID_ARG; }
+	const uint32_t first_of_pass = lp.paired ? 2 * pass : pass;
+	const bool chains = lp.paired && first_of_pass + 1 < acquired;
+	lp.num_chains = chains ? 2 : 1;
 	for (const LinkedProgram::IdUse& u : lp.id_uses)
 		if (u.updates && u.acquires) {
 			if (lp.num_passes > 1) { err = "update_id and acquire_id on one dataset in a script that acquires several datasets are not supported by the GPU executor"; return VVM_E_UNSUPPORTED_OP; }
 			lp.serial_chunks = true;
 		}
 	const bool multi_pass = lp.num_passes > 1;
-	const uint32_t pass_dataset = lp.acquire_order.empty() ? 0 : lp.acquire_order[pass];
+	const uint32_t pass_dataset = lp.acquire_order.empty() ? 0 : lp.acquire_order[first_of_pass];
+	const uint32_t second_dataset = chains ? lp.acquire_order[first_of_pass + 1] : pass_dataset;
 	lp.pass_dataset = pass_dataset;
 	lp.chain_dataset[0] = pass_dataset;
-	lp.chain_dataset[1] = chains ? lp.acquire_order[1] : pass_dataset;
-	auto chain_of = [&](uint32_t dataset) -> uint32_t { return (chains && dataset == lp.acquire_order[1]) ? 1u : 0u; };
+	lp.chain_dataset[1] = second_dataset;
+	auto chain_of = [&](uint32_t dataset) -> uint32_t { return (chains && dataset == second_dataset) ? 1u : 0u; };
+	auto in_pass = [&](uint32_t dataset) { return dataset == pass_dataset || dataset == second_dataset; };
 	// update_id runs in its dataset's pass; acquire_id in every pass (its register results may feed any dataset's outputs; what it
 	// writes to the ID tables depends on the instance index alone, so every pass writes the same)
 	if (multi_pass)
-		lp.id_uses.erase(std::remove_if(lp.id_uses.begin(), lp.id_uses.end(), [&](const LinkedProgram::IdUse& u) { return u.updates && u.dataset != pass_dataset; }), lp.id_uses.end());
+		lp.id_uses.erase(std::remove_if(lp.id_uses.begin(), lp.id_uses.end(), [&](const LinkedProgram::IdUse& u) { return u.updates && !in_pass(u.dataset); }), lp.id_uses.end());
 	lp.uses_ids = !lp.id_uses.empty();
 	lp.updates_ids = false;
 	for (const LinkedProgram::IdUse& u : lp.id_uses) lp.updates_ids = lp.updates_ids || u.updates;
@@ -573,7 +592,7 @@ static int link_program_as(const ThawedScript& s, bool force_narrow, LinkedProgr
 		heavy = false; uses_perlin = false;
 		for (size_t k = ins.size(); k-- > 0;) {
 			const Decoded& d = ins[k];
-			const bool other_pass = multi_pass && d.dataset != pass_dataset;
+			const bool other_pass = multi_pass && !in_pass(d.dataset);
 			bool keep = true;
 			switch (d.kind) {
 			case K_OUTPUT:
@@ -799,7 +818,7 @@ static int link_program_as(const ThawedScript& s, bool force_narrow, LinkedProgr
 			break;
 		}
 		case K_ACQUIRE:
-			if (multi_pass && d.dataset != pass_dataset) break;       // another pass's dataset
+			if (multi_pass && !in_pass(d.dataset)) break;       // another pass's dataset
 			if (chain_of(d.dataset)) acquired_second = (int)d.dataset; else acquired_dataset = (int)d.dataset;
 			if (acquire_at == (size_t)-1) acquire_at = lp.code.size();
 			k.w0 = VVM_INS_W0(VVM_DOP_ACQUIRE, 1, 0, chain_of(d.dataset), d.in.size() == 2 ? d.fn : VVM_ACQ_SIGN);      // (fn: the folded compare, see fold_compares_into_acquires)
@@ -811,7 +830,7 @@ static int link_program_as(const ThawedScript& s, bool force_narrow, LinkedProgr
 			if (d.op == VVM_OP_outputdata_half) dop = VVM_DOP_OUTPUT16;
 			else if (d.op == VVM_OP_outputdata_half_from_half) dop = VVM_DOP_OUTPUT16_FROM16;
 			else if (d.op == VVM_OP_outputdata_float_from_half) dop = VVM_DOP_OUTPUT32_FROM16;
-			if (multi_pass && d.dataset != pass_dataset) break;       // another pass's dataset
+			if (multi_pass && !in_pass(d.dataset)) break;       // another pass's dataset
 			// An output that no acquireindex precedes, or whose dataset is not the acquired one, writes nothing
 			// (VectorVMRuntime.cpp:565, 769): its list entry stays empty.
 			const bool live = (acquired_dataset >= 0 && (uint32_t)acquired_dataset == d.dataset) || (acquired_second >= 0 && (uint32_t)acquired_second == d.dataset);
@@ -876,7 +895,7 @@ static int link_program_as(const ThawedScript& s, bool force_narrow, LinkedProgr
 			break;
 		}
 		case K_IDS: {
-			if (d.op == VVM_OP_update_id && multi_pass && d.dataset != pass_dataset) break;       // another pass's dataset
+			if (d.op == VVM_OP_update_id && multi_pass && !in_pass(d.dataset)) break;       // another pass's dataset
 			if (d.op == VVM_OP_update_id) {
 				// staged like an output: one entry of the output list, one staging slot (in[1], the tag register, is not read:
 				// VectorVMRuntime.cpp:1133 only loads its address)

@@ -68,10 +68,10 @@ struct LinkedProgram {
 	std::vector<uint32_t> acquire_order;     // those datasets in program order
 	uint32_t num_passes = 1;                 // one pass per acquired dataset (see link_program)
 	uint32_t pass_dataset = 0;               // the dataset this program compacts and writes
-	// A script that acquires exactly two datasets and needs neither the transcendental / noise / ID instructions nor the
-	// one-instance-per-lane kernel is linked as ONE pass with two chains instead (num_passes = 1, num_chains = 2): both
-	// acquireindex run in it, each with its own keep mask, count and look-back words, and every output belongs to the chain of
-	// its dataset.  chain_dataset[c] = the dataset of chain c (chain 0 = pass_dataset); out_chain[k] = the chain of output-list entry k.
+	// A script that acquires two or more datasets and needs neither the transcendental / noise / ID instructions nor the
+	// one-instance-per-lane kernel is linked with the datasets two to a pass (`paired`): a pass of two is ONE program with two
+	// chains (num_chains = 2; two datasets in all: num_passes = 1): both acquireindex run in it, each with its own keep mask,
+	// count and look-back words, and every output belongs to the chain of its dataset.  chain_dataset[c] = the dataset of chain c (chain 0 = pass_dataset); out_chain[k] = the chain of output-list entry k.
 	// Derived constants: an add / sub / mul (float or integer) whose operands are all constants of the script yields the same value
 	// for every instance; the linker takes such instructions out of the program and the host computes them when it fills an Exec's
 	// constants (the arithmetic is IEEE single precision / 32-bit wrap-around on both sides).  Uniform index num_consts + j names
@@ -79,6 +79,8 @@ struct LinkedProgram {
 	struct Derived { uint8_t op; uint16_t a, b; };
 	std::vector<Derived> derived;
 	uint32_t num_chains = 1;
+	bool     paired = false;                 // the script's acquired datasets are taken two to a pass: pass p has those at places 2 p and 2 p + 1
+	                                         // of acquire_order (the last pass of an odd number has one), num_passes = ceil(datasets / 2)
 	uint32_t chain_dataset[2] = {0, 0};
 	std::vector<uint8_t> out_chain;
 	// The script's random draws in program order (a random_2x makes two), whether or not this program keeps the instruction:
@@ -106,7 +108,9 @@ int thaw_blob(const uint8_t* blob, size_t n, ThawedScript& out, std::string& err
 // out_select: null, or one flag per output serial index: the program writes only the outputs whose flag is set (and computes and
 // loads only what those and the acquireindex need).  A script whose record is wider than the register file of the fast kernels is
 // linked a second time without the outputs that hand an input stream through (through_input); a copy kernel moves those.
+// pairing: for pass 0 leave at -1 (the linker decides whether the datasets go two to a pass, LinkedProgram::paired); for a later
+// pass, what pass 0 decided (1 or 0).
 int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& out, std::string& err, uint32_t pass = 0, bool light = false,
-                 const std::vector<uint8_t>* out_select = nullptr);
+                 const std::vector<uint8_t>* out_select = nullptr, int pairing = -1);
 
 }  // namespace vvm

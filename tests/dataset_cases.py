@@ -48,3 +48,32 @@ def expected(x: np.ndarray, y: np.ndarray, limit0, limit1, many_outputs: bool = 
         d0 += [(x * f32(3.0) + y)[k0]] * 9
     d1 = [(x + y)[k1], np.nonzero(k1)[0].astype(np.int32)]
     return d0, d1
+
+
+def many_dataset_script(k, order=None, trig_in=None):
+    """x, y, z in; dataset d keeps the instances with (x, y or z) below limit d and writes two floats and, on odd datasets, the
+    instance's index.  trig_in: that dataset's value goes through a sine (its pass then needs the kernel with the transcendental
+    functions, which has one chain)."""
+    s = Script()
+    xs = [s.input(0, FLOAT, i) for i in range(3)]
+    for d in (order or range(k)):
+        keep = s.temp()
+        s.op("cmplt", xs[d % 3], s.const(d), keep)
+        s.acquireindex(keep, d)
+        a, b = s.temps(2)
+        s.op("mad", xs[d % 3], s.const(k), xs[(d + 1) % 3], a)
+        if trig_in == d:
+            s.op("sin", a, a)
+        s.op("sub", xs[(d + 2) % 3], a, b)
+        s.output_data(FLOAT, d, [(a, s.output(d, FLOAT, 0)), (b, s.output(d, FLOAT, 1))])
+        if d % 2:
+            idx = s.temp()
+            s.op("exec_index", idx)
+            s.output_data(INT32, d, [(idx, s.output(d, INT32, 0))])
+    return s.build()
+
+
+def many_dataset_consts(k):
+    v = np.array([0.25 + 0.6 * ((d * 7) % k) / k for d in range(k)] + [1.5], np.float32)
+    pad = (-len(v)) % 4
+    return v.tobytes() + bytes(4 * pad)

@@ -216,6 +216,62 @@ def main():
             more = [torch.rand(n + PAD, dtype=torch.float32, device=dev) for _ in range(extra)]
             run_single(("fountain with a sine and an exponential, " if args.trig else "fountain with ") + "%d more attributes, %d of them computed with, the others handed through (%d streams in / %d out), %d instances" % (extra, min(args.more_math, extra), 8 + extra, 8 + extra, n), w, base + more, 8 + extra, n)
             del more
+    if "many_datasets" in which:
+        # the fountain update with a dataset for the particles that die this tick and one or two more event-like datasets (particles
+        # below a height, particles beyond a distance): 3 or 4 acquired datasets, every one reading the fountain's streams.  Run with
+        # VVM_NO_CHAINS=1 (one program and one launch per dataset) for the comparison.
+        from renderer_amd.assembler import FLOAT, Script
+        import struct
+        for K in (3, 4):
+            s = Script()
+            dt, drag = s.const(0), s.const(4)
+            pos = [s.input(0, FLOAT, k) for k in range(3)]
+            vel = [s.input(0, FLOAT, 3 + k) for k in range(3)]
+            age, life = s.input(0, FLOAT, 6), s.input(0, FLOAT, 7)
+            age1 = s.temp(); s.op("add", age, dt, age1)
+            alive, dead = s.temps(2)
+            s.op("cmplt", age1, life, alive)
+            s.op("cmpge", age1, life, dead)
+            s.acquireindex(alive, 0)
+            s.acquireindex(dead, 1)
+            v1, p1 = s.temps(3), s.temps(3)
+            for c in range(3):
+                s.op("mad_mul", s.const(1 + c), dt, vel[c], drag, v1[c])
+                s.op("mad", v1[c], dt, pos[c], p1[c])
+            s.output_data(FLOAT, 0, [(p1[c], s.output(0, FLOAT, c)) for c in range(3)] + [(v1[c], s.output(0, FLOAT, 3 + c)) for c in range(3)] +
+                          [(age1, s.output(0, FLOAT, 6)), (life, s.output(0, FLOAT, 7))])
+            s.output_data(FLOAT, 1, [(p1[c], s.output(1, FLOAT, c)) for c in range(3)] + [(age1, s.output(1, FLOAT, 3))])
+            for d in range(2, K):
+                hit = s.temp()
+                s.op("cmplt", p1[d - 2], s.const(5), hit)
+                s.acquireindex(hit, d)
+                s.output_data(FLOAT, d, [(p1[c], s.output(d, FLOAT, c)) for c in range(3)] + [(age1, s.output(d, FLOAT, 3))])
+            built = s.build()
+            consts = struct.pack("<6f", 1.0 / 60.0, 0.0, 0.0, -980.0, 0.98, 0.25) + bytes(8)
+            n = 64 * 1024 * 1024
+            ins = scripts.fountain_streams_torch(0, n, dev, kill_half=True, pad=PAD)
+            outs = [[torch.zeros(n + PAD, dtype=torch.float32, device=dev) for _ in range(8 if d == 0 else 4)] for d in range(K)]
+            torch.cuda.synchronize()
+            st = VectorVMState(built.blob, be)
+            frame = st.frame([abi.DataSet([t.data_ptr() for t in ins] if d == 0 else [], [t.data_ptr() for t in outs[d]], 0) for d in range(K)], n, [consts])
+            o = abi.ExecOptions(0, 0, 0, None, 0)
+            for _ in range(3):
+                st.exec(frame, o)
+            st.enable_timing(True)
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                st.exec_async(frame, o)
+            st.finish(frame)
+            el = time.perf_counter() - t0
+            ms, launches = st.collect_kernel_ms()
+            surv = [frame.survivors(d) for d in range(K)]
+            passes = (st.info().Flags >> 20) & 15
+            st.close()
+            alg = 32.0 * n + 32.0 * surv[0] + 16.0 * sum(surv[1:])
+            print(json.dumps({"config": "fountain with %d more datasets (8 streams in, 8 + %s out), 64Mi" % (K - 1, " + ".join(["4"] * (K - 1))), "particles": n, "survivors": surv,
+                              "passes": passes, "ms_per_step": el / args.steps * 1e3, "kernel_ms_per_exec": ms / max(launches, 1), "updates_per_s": n * args.steps / el,
+                              "algorithmic_GBps": alg / (ms / max(launches, 1)) / 1e6}), flush=True)
+            del outs
     if "two_datasets" in which:
         # the fountain update with a second dataset that receives the particles that die this tick (position and age): both
         # datasets' programs read all eight streams

@@ -17,7 +17,7 @@ int main(int argc, char** argv)
 			vvm::LinkedProgram lp;
 			int rc = vvm::link_program(s, mode == 1, lp, err, 0, mode == 2);
 			if (rc == 0)
-				for (uint32_t k = 1; k < lp.num_passes; ++k) { vvm::LinkedProgram more; vvm::link_program(s, mode == 1, more, err, k, false); }
+				for (uint32_t k = 1; k < lp.num_passes; ++k) { vvm::LinkedProgram more; vvm::link_program(s, mode == 1, more, err, k, false, nullptr, lp.paired ? 1 : 0); }
 			// the program without the outputs that hand a stream through (the lean form), and one with every other output only
 			if (rc == 0 && mode != 1 && !lp.through_input.empty()) {
 				std::vector<uint8_t> select(lp.through_input.size());
