@@ -560,16 +560,16 @@ def test_random_scripts_in_the_optimized_format(block):
         ins = [rng.uniform(-3, 3, n).astype(f32) for _ in range(nf)] + [rng.integers(-20, 20, n).astype(np.int32) for _ in range(ni)] + \
               [rng.uniform(-2, 2, n).astype(np.float16) for _ in range(nh)]
         consts = bytes([255] * 4) + np.array([0.5, -1.25, 2.0, 0.0], f32).tobytes() + np.array([3], np.int32).tobytes()
-        more = [fz.gen.second_dataset] if fz.gen.second_dataset else []          # (every fourth script acquires a second dataset)
+        more = fz.gen.more_datasets          # (every fourth script acquires a second dataset, some of those a third and a fourth)
         ref_more, got_more = [], []
         ref = run_oracle(built, [consts], ins, dts, n, seed=seed, more_datasets=more, more_results=ref_more, ext_fns=list(fz.gen.ext))
         got = run_hip(built, [consts], ins, dts, n, seed=seed, flags=abi.VVM_EXEC_FORCE_EIGHT_WIDE if seed % 2 else 0,
                       more_datasets=more, more_results=got_more, ext_fns=list(fz.gen.ext))
         assert got[1] == ref[1], seed
-        if more:
-            assert got_more[0][1] == ref_more[0][1], seed
-            for a, b, dt in zip(got_more[0][0], ref_more[0][0], more[0]):
-                a, b = a[:got_more[0][1]], b[:ref_more[0][1]]
+        for d in range(len(more)):
+            assert got_more[d][1] == ref_more[d][1], seed
+            for a, b, dt in zip(got_more[d][0], ref_more[d][0], more[d]):
+                a, b = a[:got_more[d][1]], b[:ref_more[d][1]]
                 nan = (np.isnan(a) & np.isnan(b)) if dt != np.int32 else np.zeros(len(a), bool)
                 assert np.array_equal(a.view(np.uint32)[~nan], b.view(np.uint32)[~nan]), seed
         for k, dt in enumerate(dts):

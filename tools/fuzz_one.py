@@ -32,7 +32,7 @@ def main():
     ins = [rng.uniform(-3, 3, max(n, 1)).astype(f32) for _ in range(nf)] + [rng.integers(-20, 20, max(n, 1)).astype(np.int32) for _ in range(ni)] + \
           [rng.uniform(-2, 2, max(n, 1)).astype(np.float16) for _ in range(nh)]
     consts = bytes([255] * 4) + np.array([0.5, -1.25, 2.0, 0.0], f32).tobytes() + np.array([3], np.int32).tobytes()
-    more = [gen.second_dataset] if gen.second_dataset else []
+    more = gen.more_datasets
     assert not gen.with_ids, "this helper does not set up ID tables"
     ref_more, got_more = [], []
     ref = run_oracle(built, [consts], ins, dts, n, seed=seed, instance_offset=offset, more_datasets=more, more_results=ref_more, ext_fns=list(gen.ext))

@@ -211,16 +211,18 @@ def gen(seed):
             dts.append({FLOAT: f32, HALF: np.float16}[typ])
         if group:
             s.output_data(typ, 0, group, from_half=True)
-    dts1 = []
-    if seed % 4 == 1:                               # a second acquired dataset with outputs of its own
-        s.acquireindex(r.choice(masks) if masks and r.random() < 0.8 else s.const(0), 1)
-        pairs_f = [(r.choice(fvals), s.output(1, FLOAT, i)) for i in range(r.randint(1, 3))]
-        s.output_data(FLOAT, 1, pairs_f)
-        dts1 += [f32] * len(pairs_f)
-        if ivals:
-            s.output_data(INT32, 1, [(r.choice(ivals), s.output(1, INT32, 0))])
-            dts1.append(np.int32)
-    gen.second_dataset = dts1
+    more_dts = []
+    if seed % 4 == 1:                               # a second acquired dataset with outputs of its own; of the scripts without ID instructions a third have a third, another third a fourth as well
+        for d in range(1, 2 + ((seed // 8) % 3 if seed % 8 == 1 else 1 if seed % 32 == 5 else 0)):      # (seed % 8 == 5: with ID instructions)
+            s.acquireindex(r.choice(masks) if masks and r.random() < 0.8 else s.const(0), d)
+            pairs_f = [(r.choice(fvals), s.output(d, FLOAT, i)) for i in range(r.randint(1, 3))]
+            s.output_data(FLOAT, d, pairs_f)
+            dts_d = [f32] * len(pairs_f)
+            if ivals:
+                s.output_data(INT32, d, [(r.choice(ivals), s.output(d, INT32, 0))])
+                dts_d.append(np.int32)
+            more_dts.append(dts_d)
+    gen.more_datasets = more_dts
     return s.build(alias_outputs=r.random() < 0.5), nf + nna + len(wide), ni, nh, dts
 
 
@@ -289,7 +291,7 @@ def run(first_seed, last_seed, report_every=100):
               [rng.uniform(-2, 2, max(n, 1)).astype(np.float16) for _ in range(nh)]
         consts = bytes([255] * 4) + np.array([0.5, -1.25, 2.0, 0.0], f32).tobytes() + np.array([3], np.int32).tobytes()
         try:
-            dts1 = gen.second_dataset
+            more = gen.more_datasets
             want_ids = got_ids = None
             if gen.both_ids:
                 m = max(n, 1)
@@ -302,11 +304,10 @@ def run(first_seed, last_seed, report_every=100):
                 want_ids = IdState(np.full(m + 7, -1, np.int32), np.full(2 * m + 16, -7, np.int32), num_free=5, max_used=3)
                 want_ids.free_table[:5] = [100001, 100002, 100003, 100004, 100005]
                 got_ids = want_ids.copy()
-            more = [dts1] if dts1 else []
             ref_more, got_more = [], []
             # every eleventh script draws from the reference's own generator (vvm_exec_options.RandXorwowState) instead of the counter-based
             # one; scripts that acquire two datasets in one pass have no kernel for it and keep the counter-based generator
-            xorwow = [(seed * 2654435761 + 97 * k) & 0xFFFFFFFF for k in range(24)] if seed % 11 == 0 and not dts1 and not gen.both_ids else None
+            xorwow = [(seed * 2654435761 + 97 * k) & 0xFFFFFFFF for k in range(24)] if seed % 11 == 0 and not more and not gen.both_ids else None
             in_batch = seed % 13 == 0 and xorwow is None
             # every nineteenth script goes through vvm_exec_noalloc where that entry point takes it (no ID instructions, a parameter
             # block of at most 1 KB, no injected generator state); a refusal for one of those reasons sends it through vvm_exec_ex
@@ -371,15 +372,20 @@ def run(first_seed, last_seed, report_every=100):
         if ok and want_ids is not None:
             ok = np.array_equal(got_ids.id_table, want_ids.id_table) and np.array_equal(got_ids.free_table, want_ids.free_table) and \
                 (got_ids.num_free, got_ids.max_used) == (want_ids.num_free, want_ids.max_used)
-        if ok and dts1:
-            ok = got_more[0][1] == ref_more[0][1]
-            for k, dt in enumerate(dts1):
+        for d, dts_d in enumerate(more):
+            if not ok:
+                break
+            ok = got_more[d][1] == ref_more[d][1]
+            for k, dt in enumerate(dts_d):
                 if not ok:
                     break
-                m = got_more[0][1]
-                x, y = got_more[0][0][k][offset:offset + m].view(np.uint32), ref_more[0][0][k][offset:offset + m].view(np.uint32)
+                m = got_more[d][1]
+                x, y = got_more[d][0][k][offset:offset + m].view(np.uint32), ref_more[d][0][k][offset:offset + m].view(np.uint32)
                 nan = np.isnan(x.view(f32)) & np.isnan(y.view(f32)) if dt == f32 else np.zeros(m, bool)
                 ok = np.array_equal(x[~nan], y[~nan])
+        if len(more) >= 2:
+            key = "three or more acquired datasets, %d passes" % ((info.Flags >> 20) & 15)
+            shapes[key] = shapes.get(key, 0) + 1
         if ok and in_batch and not neighbours.check():
             ok = False
             print("seed", seed, "the neighbours of the batch differ", flush=True)
