@@ -211,7 +211,8 @@ typedef struct vvm_exec_options {
 	                             * RandInstanceBase are not used.  The draws are laid out by a kernel of their own ahead of the Exec
 	                             * (4 bytes of device memory per draw and instance, held by the state) and the Exec runs four
 	                             * instances per lane or one.  Refused (VVM_E_UNSUPPORTED_OP): vvm_exec_noalloc, vvm_exec_batch /
-	                             * vvm_batch_*, scripts that acquire two datasets in one pass (set VVM_NO_CHAINS in the environment). */
+	                             * vvm_batch_*.  A script whose acquired datasets go two to a pass runs one program per dataset for
+	                             * such an Exec (the kernels that read the words have one chain). */
 } vvm_exec_options;
 
 enum {

@@ -194,6 +194,13 @@ struct vvm_state {
 	// a script with acquireindex on several datasets runs one pass per dataset: the programs of passes 1.. (pass 0 = wide / narrow)
 	std::vector<vvm::LinkedProgram> wide_more, narrow_more;
 	std::vector<VvmIns*> d_code_wide_more, d_code_narrow_more;
+	// ... and, where `wide` takes the datasets two to a pass (LinkedProgram::paired): the script as one program per dataset, linked on
+	// demand for the Execs that need kernels without a second chain (those that read the reference generator's words)
+	vvm::LinkedProgram solo;
+	std::vector<vvm::LinkedProgram> solo_more;
+	VvmIns* d_code_solo = nullptr;
+	std::vector<VvmIns*> d_code_solo_more;
+	bool solo_ready = false;
 
 	// A script whose record is too wide for the register file of the light eight-wide kernel, but whose extra width is streams that
 	// it hands through unchanged, also has this form: a program with everything the script computes (`lean`: for the light kernel,
@@ -551,6 +558,20 @@ int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, P
 		}
 		if (pass > st->narrow_more.size()) return fail(VVM_E_INVALID_ARG, "internal: pass index out of range");
 		pe.lp = pass ? &st->narrow_more[pass - 1] : &st->narrow; pe.d_code = pass ? st->d_code_narrow_more[pass - 1] : st->d_code_narrow;
+	} else if (opt && opt->RandXorwowState && !st->wide.rand_draws.empty() && st->wide.paired) {
+		// the kernels that read the reference generator's words have one chain: one program per dataset
+		if (!st->solo_ready) {
+			std::string err;
+			int rc = vvm::link_program(s, false, st->solo, err, 0, false, nullptr, 0);
+			if (rc != VVM_OK) return fail(rc, err);
+			rc = upload_code(st->solo, &st->d_code_solo);
+			if (rc != VVM_OK) return rc;
+			rc = link_more_passes(s, false, st->solo, st->solo_more, st->d_code_solo_more);
+			if (rc != VVM_OK) return rc;
+			st->solo_ready = true;
+		}
+		if (pass > st->solo_more.size()) return fail(VVM_E_INVALID_ARG, "internal: pass index out of range");
+		pe.lp = pass ? &st->solo_more[pass - 1] : &st->solo; pe.d_code = pass ? st->d_code_solo_more[pass - 1] : st->d_code_solo;
 	} else {
 		if (pass > st->wide_more.size()) return fail(VVM_E_INVALID_ARG, "internal: pass index out of range");
 		pe.lp = pass ? &st->wide_more[pass - 1] : &st->wide; pe.d_code = pass ? st->d_code_wide_more[pass - 1] : st->d_code_wide;
@@ -594,7 +615,7 @@ int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, P
 	}
 	if (pe.reference_random) {
 		if (pe.in_batch) return fail(VVM_E_UNSUPPORTED_OP, "RandXorwowState: not available to the members of a batch");
-		if (pe.lp->num_chains > 1) return fail(VVM_E_UNSUPPORTED_OP, "RandXorwowState: not available to a script that acquires two datasets in one pass (set VVM_NO_CHAINS)");
+		if (pe.lp->num_chains > 1) return fail(VVM_E_UNSUPPORTED_OP, "internal: RandXorwowState with a program of two chains");      // (prepare picks the one-chain programs above)
 		// (the random ops of the FULL kernels read the words; a program linked for the plain kernels runs on them as it is, given the LDS)
 		if ((size_t)vvm_kernel_lds_fixed_bytes((int)pe.instances_per_lane, 1) + (size_t)pe.lds_slots() * VVM_BLOCK_THREADS * 4u * pe.instances_per_lane > (size_t)(160 * 1024 - 64))
 			return fail(VVM_E_UNSUPPORTED_OP, "RandXorwowState: the script's registers leave no room in the LDS of the kernels that read the generator's words");
@@ -1118,6 +1139,8 @@ VVM_API void vvm_free_state(vvm_state* st)
 	if (st->d_ride) (void)hipFree(st->d_ride);
 	for (VvmIns* p : st->d_code_wide_more) if (p) (void)hipFree(p);
 	for (VvmIns* p : st->d_code_narrow_more) if (p) (void)hipFree(p);
+	if (st->d_code_solo) (void)hipFree(st->d_code_solo);
+	for (VvmIns* p : st->d_code_solo_more) if (p) (void)hipFree(p);
 	if (st->d_perlin) (void)hipFree(st->d_perlin);
 	if (st->d_launch) (void)hipFree(st->d_launch);
 	if (st->d_status) (void)hipFree(st->d_status);
@@ -1223,6 +1246,8 @@ static int exec_enqueue(vvm_exec_context* ctx, const vvm_exec_options* opt, bool
 		if ((size_t)std::max<uint32_t>(st->script.max_output_dataset, 1) + 4 > sizeof(((VvmLaunchState*)nullptr)->reserved) / 4)
 			return fail(VVM_E_TOO_LARGE, "vvm_exec_noalloc: too many output datasets for the scratch array's count words");
 	}
+	if (no_alloc && opt && opt->RandXorwowState && !st->wide.rand_draws.empty())
+		return fail(VVM_E_UNSUPPORTED_OP, "vvm_exec_noalloc: RandXorwowState needs a buffer sized per Exec");
 	PreparedExec pe;
 	pe.lean_max_tiles = no_alloc ? VVM_NOALLOC_RIDE_TILES : 0;
 	if (chunk) { pe.serial_chunk = true; pe.chunk_first = chunk->chunk_first; pe.out_base = chunk->out_base; pe.free_read_snapshot = chunk->free_read_snapshot; }

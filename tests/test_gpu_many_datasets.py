@@ -78,3 +78,42 @@ def test_three_datasets_through_the_entry_point_that_allocates_nothing():
     with pytest.MonkeyPatch.context() as mp:
         info, _ = _run(3, 300_007, "paired", mp, no_alloc=True)
     assert (info.Flags >> 20) & 15 == 2
+
+
+@pytest.mark.parametrize("k", [2, 3, 4])
+def test_several_datasets_on_the_reference_generator(k):
+    """vvm_exec_options.RandXorwowState: the kernels that read the generator's words have one chain, so a script whose datasets go
+    two to a pass runs one program per dataset for such an Exec; an Exec without the state, before and after, runs the pairs."""
+    from renderer_amd.assembler import FLOAT, Script
+    s = Script()
+    x = s.input(0, FLOAT, 0)
+    draws = []
+    for d in range(k):
+        keep, r = s.temps(2)
+        s.op("random", s.const(k), r)
+        draws.append(r)
+        s.op("cmplt", r, s.const(d), keep)
+        s.acquireindex(keep, d)
+        v = s.temp()
+        s.op("mad", r, x, draws[0], v)
+        s.output_data(FLOAT, d, [(v, s.output(d, FLOAT, 0)), (r, s.output(d, FLOAT, 1))])
+    built = s.build()
+    n = 41_003
+    consts = [_consts(k)]
+    rng = np.random.default_rng(k)
+    ins = [rng.random(n).astype(f32)]
+    more = [[f32, f32]] * (k - 1)
+    words = [(0x9E3779B9 * (i + 1) + k) & 0xFFFFFFFF for i in range(24)]
+    for xorwow in (None, words, None):
+        ref_more, got_more = [], []
+        ref, ref_n, _ = run_oracle(built, consts, ins, [f32, f32], n, seed=5, more_datasets=more, more_results=ref_more, xorwow=xorwow)
+        got, got_n, info = run_hip(built, consts, ins, [f32, f32], n, seed=5, more_datasets=more, more_results=got_more, xorwow=xorwow)
+        assert info.Flags & 0x40000 and (info.Flags >> 20) & 15 == (k + 1) // 2
+        assert got_n == ref_n and 0 < got_n < n
+        for a, b in zip(got, ref):
+            assert np.array_equal(a[:got_n].view(np.uint32), b[:ref_n].view(np.uint32))
+        for d in range(k - 1):
+            m = got_more[d][1]
+            assert m == ref_more[d][1] and 0 < m < n
+            for a, b in zip(got_more[d][0], ref_more[d][0]):
+                assert np.array_equal(a[:m].view(np.uint32), b[:m].view(np.uint32)), "dataset %d" % (d + 1)

@@ -306,8 +306,8 @@ def run(first_seed, last_seed, report_every=100):
                 got_ids = want_ids.copy()
             ref_more, got_more = [], []
             # every eleventh script draws from the reference's own generator (vvm_exec_options.RandXorwowState) instead of the counter-based
-            # one; scripts that acquire two datasets in one pass have no kernel for it and keep the counter-based generator
-            xorwow = [(seed * 2654435761 + 97 * k) & 0xFFFFFFFF for k in range(24)] if seed % 11 == 0 and not more and not gen.both_ids else None
+            # one (scripts whose datasets go two to a pass then run one program per dataset: the kernels that read the words have one chain)
+            xorwow = [(seed * 2654435761 + 97 * k) & 0xFFFFFFFF for k in range(24)] if seed % 11 == 0 and not gen.both_ids else None
             in_batch = seed % 13 == 0 and xorwow is None
             # every nineteenth script goes through vvm_exec_noalloc where that entry point takes it (no ID instructions, a parameter
             # block of at most 1 KB, no injected generator state); a refusal for one of those reasons sends it through vvm_exec_ex

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $root/gpurun_out/prof_$tag -o bench --output-format csv -- python3 $root/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $root/gpurun_out/prof_$tag.log 2>&1
 cd $root
 timeout -k 10 200 python bench.py > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err
-timeout -k 10 400 python tools/bench_configs.py --which arith,transcendental,kill_half,kill_half_250m,death_sweep,one_million,wide_record,batch > gpurun_out/configs_$tag.jsonl 2> gpurun_out/configs_$tag.err
+timeout -k 10 400 python tools/bench_configs.py --which arith,transcendental,kill_half,kill_half_250m,death_sweep,one_million,wide_record,two_datasets,many_datasets,batch > gpurun_out/configs_$tag.jsonl 2> gpurun_out/configs_$tag.err
 timeout -k 10 200 python tools/ulp_report.py > gpurun_out/ulp_$tag.json 2> gpurun_out/ulp_$tag.err
 ls gpurun_out/prof_$tag
 cd /tmp
