@@ -391,6 +391,8 @@ struct PreparedExec {
 	// within the whole Exec (advancing inputs, exec_index and the random generator's key start there) and the number of survivors the
 	// chunks before it have written (outputs and IDTable positions start there).
 	uint32_t chunk_first = 0, out_base = 0;
+	const int32_t* out_bases = nullptr;      // ... per dataset (a script that writes several), num_out_bases of them; else out_base for every output
+	uint32_t num_out_bases = 0;
 	bool     serial_chunk = false;
 	const int32_t* free_read_snapshot = nullptr;       // ... and where the copy of the FreeIDTable entries lies that the chunk's acquire_id reads
 	bool full() const { return lp->full_kernel || reference_random; }
@@ -788,7 +790,8 @@ int fill_params(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* op
 		if ((int)idx >= ds.OutputRegisters.num || !ds.OutputRegisters.data) return fail(VVM_E_INVALID_ARG, "output register index past OutputRegisters.num");
 		const uint64_t stride = (ty == 2) ? 2 : 4;
 		if (!ds.OutputRegisters.data[idx]) continue;
-		const uint64_t addr = (uint64_t)(uintptr_t)ds.OutputRegisters.data[idx] + (uint64_t)((int64_t)ds.InstanceOffset + (int64_t)pe.out_base) * stride;
+		const int64_t written_so_far = (pe.out_bases && dsi < pe.num_out_bases) ? (int64_t)pe.out_bases[dsi] : (int64_t)pe.out_base;
+		const uint64_t addr = (uint64_t)(uintptr_t)ds.OutputRegisters.data[idx] + (uint64_t)((int64_t)ds.InstanceOffset + written_so_far) * stride;
 		if (addr & ~VVM_OUT_ADDR_MASK) return fail(VVM_E_INVALID_ARG, "output register address does not fit 48 bits");
 		out_list[k] = addr | (lp.out_is16[k] ? VVM_OUT_IS16 : 0) | ((k < lp.out_chain.size() && lp.out_chain[k]) ? VVM_OUT_CHAIN1 : 0);
 	}
@@ -809,11 +812,12 @@ int fill_params(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* op
 		ids->id_scratch = st->d_id_scratch ? st->d_id_scratch + (size_t)pe.id_buffers * st->id_scratch_capacity : nullptr;
 		ids->max_id = d->counts + st->num_datasets() + use.dataset;      // the dataset's word behind the survivor counts
 		ids->survivors = d->counts + use.dataset;
-		ids->instance_offset = ds.InstanceOffset + (int32_t)pe.out_base;
+		ids->instance_offset = ds.InstanceOffset + ((pe.out_bases && use.dataset < pe.num_out_bases) ? pe.out_bases[use.dataset] : (int32_t)pe.out_base);
 		ids->num_free_start = *ds.NumFreeIDs;
 		const bool both = use.updates && use.acquires;      // (then this Exec is one chunk: prepare and exec_serial_chunks see to it)
 		ids->push_start = both ? *ds.NumFreeIDs - ctx->NumInstances : *ds.NumFreeIDs;
-		ids->free_read = (both && pe.free_read_snapshot) ? pe.free_read_snapshot - ((int64_t)*ds.NumFreeIDs - ctx->NumInstances) : ds.FreeIDTable->data;
+		// (a pass of another dataset runs the dataset's acquire_id too, and reads the same copy: its update_id's pass may have run by then)
+		ids->free_read = (use.serial && pe.free_read_snapshot) ? pe.free_read_snapshot - ((int64_t)*ds.NumFreeIDs - ctx->NumInstances) : ds.FreeIDTable->data;
 		ids->num_spawned_start = ds.NumSpawnedIDs ? *ds.NumSpawnedIDs : 0;
 		ids->acquire_tag = ds.IDAcquireTag;
 		ids->chunk_instances = pe.chunk_instances;
@@ -1175,7 +1179,7 @@ static int exec_serial_chunks(vvm_exec_context* ctx, const vvm_exec_options* opt
 		return fail(VVM_E_UNSUPPORTED_OP, "RandXorwowState: not available to a script with update_id and acquire_id on one dataset");
 	if (ctx->NumInstances < 0) return fail(VVM_E_INVALID_ARG, "negative NumInstances");
 	uint32_t both_dataset = 0;
-	for (const vvm::LinkedProgram::IdUse& u : st->wide.id_uses) if (u.updates && u.acquires) both_dataset = u.dataset;
+	for (const vvm::LinkedProgram::IdUse& u : st->wide.id_uses) if (u.serial) both_dataset = u.dataset;      // (every pass keeps the dataset's entry)
 	if ((int)both_dataset >= ctx->DataSets.num || !ctx->DataSets.data) return fail(VVM_E_INVALID_ARG, "the script's ID instructions name a dataset the context does not provide");
 	const vvm_dataset_meta& ds = ctx->DataSets.data[both_dataset];
 	if (!ds.FreeIDTable || !ds.FreeIDTable->data || !ds.NumFreeIDs) return fail(VVM_E_INVALID_ARG, "the script has ID instructions but the dataset has no FreeIDTable / NumFreeIDs");
@@ -1201,6 +1205,7 @@ static int exec_serial_chunks(vvm_exec_context* ctx, const vvm_exec_options* opt
 		where.serial_chunk = true;
 		where.chunk_first = first;
 		where.out_base = st->wide.pass_dataset < nd ? (uint32_t)written[st->wide.pass_dataset] : 0u;
+		where.out_bases = written.data(); where.num_out_bases = (uint32_t)nd;      // (every dataset's outputs go behind its own survivors so far)
 		const int32_t num_free = *ds.NumFreeIDs;
 		if (num_free < (int32_t)count) return fail(VVM_E_INVALID_ARG, "fewer free IDs than instances");              // check(), RT.cpp:1415
 		if (count) {
@@ -1250,7 +1255,7 @@ static int exec_enqueue(vvm_exec_context* ctx, const vvm_exec_options* opt, bool
 		return fail(VVM_E_UNSUPPORTED_OP, "vvm_exec_noalloc: RandXorwowState needs a buffer sized per Exec");
 	PreparedExec pe;
 	pe.lean_max_tiles = no_alloc ? VVM_NOALLOC_RIDE_TILES : 0;
-	if (chunk) { pe.serial_chunk = true; pe.chunk_first = chunk->chunk_first; pe.out_base = chunk->out_base; pe.free_read_snapshot = chunk->free_read_snapshot; }
+	if (chunk) { pe.serial_chunk = true; pe.chunk_first = chunk->chunk_first; pe.out_base = chunk->out_base; pe.out_bases = chunk->out_bases; pe.num_out_bases = chunk->num_out_bases; pe.free_read_snapshot = chunk->free_read_snapshot; }
 	int rc = prepare(st, ctx, opt, pe);
 	if (rc != VVM_OK) return rc;
 	if (no_alloc && pe.reference_random) return fail(VVM_E_UNSUPPORTED_OP, "vvm_exec_noalloc: RandXorwowState needs a buffer sized per Exec");
@@ -1307,7 +1312,7 @@ static int exec_enqueue(vvm_exec_context* ctx, const vvm_exec_options* opt, bool
 		if (rc != VVM_OK) return rc;
 	}
 	const uint32_t num_passes = pe.lp->num_passes;
-	if (num_passes > 1 && !no_alloc && !(opt && (opt->Flags & VVM_EXEC_SEPARATE_PASSES))) {
+	if (num_passes > 1 && !no_alloc && !chunk && !(opt && (opt->Flags & VVM_EXEC_SEPARATE_PASSES))) {      // (a chunk's passes carry the chunk's place: one launch each)
 		bool handled = false;
 		rc = enqueue_fused_passes(st, ctx, opt, num_passes, stream, d_launch, timed, handled);
 		if (rc != VVM_OK) return rc;
@@ -1468,26 +1473,31 @@ VVM_API int vvm_exec_finish(vvm_exec_context* ctx)
 	if (ran && st->any_ids) {
 		// the datasets' ID counters, as the reference leaves them (VectorVMRuntime.cpp:1175, 1383-1399, 1411-1429); a dataset's
 		// update_id sits in the program of its own pass, acquire_id in every pass's
-		std::vector<uint8_t> done(st->num_datasets(), 0);
-		auto settle = [&](const vvm::LinkedProgram& lp) {
+		struct Use { bool updates = false, acquires = false; };
+		std::vector<Use> uses(st->num_datasets());
+		auto gather = [&](const vvm::LinkedProgram& lp) {
 			for (const vvm::LinkedProgram::IdUse& use : lp.id_uses) {
-				if (done[use.dataset]) continue;
-				done[use.dataset] = 1;
-				vvm_dataset_meta& ds = ctx->DataSets.data[use.dataset];
-				int32_t num_free = st->id_num_free_start[use.dataset];
-				if (use.acquires) {
-					num_free -= ctx->NumInstances;
-					*ds.NumSpawnedIDs = st->id_num_spawned_start[use.dataset] + ctx->NumInstances;
-				}
-				if (use.updates) {
-					num_free += ctx->NumInstances - st->h_counts[use.dataset];
-					*ds.MaxUsedID = st->h_counts[st->num_datasets() + use.dataset];
-				}
-				*ds.NumFreeIDs = num_free;
+				uses[use.dataset].updates = uses[use.dataset].updates || use.updates;
+				uses[use.dataset].acquires = uses[use.dataset].acquires || use.acquires;
 			}
 		};
-		settle(st->wide);
-		for (const vvm::LinkedProgram& more : st->wide_more) settle(more);
+		gather(st->wide);
+		for (const vvm::LinkedProgram& more : st->wide_more) gather(more);
+		for (size_t dataset = 0; dataset < uses.size(); ++dataset) {
+			const Use use = uses[dataset];
+			if (!use.updates && !use.acquires) continue;
+			vvm_dataset_meta& ds = ctx->DataSets.data[dataset];
+			int32_t num_free = st->id_num_free_start[dataset];
+			if (use.acquires) {
+				num_free -= ctx->NumInstances;
+				*ds.NumSpawnedIDs = st->id_num_spawned_start[dataset] + ctx->NumInstances;
+			}
+			if (use.updates) {
+				num_free += ctx->NumInstances - st->h_counts[dataset];
+				*ds.MaxUsedID = st->h_counts[st->num_datasets() + dataset];
+			}
+			*ds.NumFreeIDs = num_free;
+		}
 	}
 	return write_back_counts(st, ctx, ran);
 }

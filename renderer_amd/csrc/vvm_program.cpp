@@ -556,9 +556,9 @@ static int link_program_as(const ThawedScript& s, bool force_narrow, LinkedProgr
 	const uint32_t first_of_pass = lp.paired ? 2 * pass : pass;
 	const bool chains = lp.paired && first_of_pass + 1 < acquired;
 	lp.num_chains = chains ? 2 : 1;
-	for (const LinkedProgram::IdUse& u : lp.id_uses)
+	for (LinkedProgram::IdUse& u : lp.id_uses)
 		if (u.updates && u.acquires) {
-			if (lp.num_passes > 1) { err = "update_id and acquire_id on one dataset in a script that acquires several datasets are not supported by the GPU executor"; return VVM_E_UNSUPPORTED_OP; }
+			u.serial = true;
 			lp.serial_chunks = true;
 		}
 	const bool multi_pass = lp.num_passes > 1;
@@ -571,8 +571,11 @@ static int link_program_as(const ThawedScript& s, bool force_narrow, LinkedProgr
 	auto in_pass = [&](uint32_t dataset) { return dataset == pass_dataset || dataset == second_dataset; };
 	// update_id runs in its dataset's pass; acquire_id in every pass (its register results may feed any dataset's outputs; what it
 	// writes to the ID tables depends on the instance index alone, so every pass writes the same)
-	if (multi_pass)
+	if (multi_pass) {
+		for (LinkedProgram::IdUse& u : lp.id_uses)
+			if (u.updates && u.acquires && !in_pass(u.dataset)) u.updates = false;      // (the dataset's acquire_id stays: `serial` says where it reads)
 		lp.id_uses.erase(std::remove_if(lp.id_uses.begin(), lp.id_uses.end(), [&](const LinkedProgram::IdUse& u) { return u.updates && !in_pass(u.dataset); }), lp.id_uses.end());
+	}
 	lp.uses_ids = !lp.id_uses.empty();
 	lp.updates_ids = false;
 	for (const LinkedProgram::IdUse& u : lp.id_uses) lp.updates_ids = lp.updates_ids || u.updates;

@@ -59,7 +59,7 @@ struct LinkedProgram {
 	// acquired from
 	// (updates and acquires both: a script that takes IDs from the dataset's free list and returns the IDs of its dead instances to it in
 	// one pass.  The reference then hands IDs from chunk to chunk, so such an Exec runs chunk after chunk: serial_chunks)
-	struct IdUse { uint32_t dataset; bool updates; bool acquires; };
+	struct IdUse { uint32_t dataset; bool updates; bool acquires; bool serial = false; };      // serial: the script (not necessarily this pass) has both on the dataset
 	std::vector<IdUse> id_uses;
 	bool     uses_ids = false;         // id_uses is not empty
 	bool     updates_ids = false;      // ... and has an update_id

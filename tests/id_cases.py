@@ -195,3 +195,30 @@ def np_spawn_and_update(st: IdState, keep: np.ndarray, chunk: int, instance_offs
                 st.max_used = m
         written += nout
     return st, all_ids
+
+
+def spawn_and_update_with_events_script(events_first: bool = False):
+    """spawn_and_update_script with a second acquired dataset that receives the instances that die (x and the ID they were given):
+    acquire_id and update_id on dataset 0 of a script that acquires two datasets."""
+    s = Script()
+    x = s.input(0, FLOAT, 0)
+    new_id, tag = s.temps(2)
+    s.acquire_id(new_id, tag, 0)
+    keep, dead = s.temps(2)
+    s.op("cmplt", x, s.const(0), keep)
+    s.op("cmpge", x, s.const(0), dead)
+
+    def events():
+        s.acquireindex(dead, 1)
+        s.output_data(FLOAT, 1, [(x, s.output(1, FLOAT, 0))])
+        s.output_data(INT32, 1, [(new_id, s.output(1, INT32, 0))])
+
+    if events_first:
+        events()
+    s.acquireindex(keep, 0)
+    s.update_id(new_id, tag, 0)
+    s.output_data(FLOAT, 0, [(x, s.output(0, FLOAT, 0))])
+    s.output_data(INT32, 0, [(new_id, s.output(0, INT32, 0)), (tag, s.output(0, INT32, 1))])
+    if not events_first:
+        events()
+    return s.build()

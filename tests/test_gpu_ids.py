@@ -212,6 +212,31 @@ def test_acquire_id_and_update_id_on_one_dataset(n, death, page_kb, from_temp, o
     assert (got.num_free, got.max_used, got.num_spawned) == (want.num_free, want.max_used, want.num_spawned)
 
 
+@pytest.mark.parametrize("n,death,page_kb,events_first,offset", [(1, 0.0, 64, False, 0), (1, 1.0, 64, True, 0), (5000, 0.4, 64, False, 2), (5000, 0.4, 16, True, 0),
+                                                                  (20001, 0.35, 8, False, 7), (20001, 0.9, 2, True, 0), (300_000, 0.5, 64, False, 0), (0, 0.5, 64, False, 0)])
+def test_acquire_id_and_update_id_on_one_dataset_of_a_script_with_two(n, death, page_kb, events_first, offset):
+    """The same with a second acquired dataset for the instances that die: every chunk runs one launch per dataset, the second
+    dataset's pass runs the acquire_id too (it writes the IDs out) and reads the same copy of the free-list entries, and every dataset's
+    outputs go behind its own survivors of the chunks before."""
+    x, st = _spawn_and_update_case(max(n, 1), n + page_kb)
+    limit = f32(1.0 - death)
+    script = id_cases.spawn_and_update_with_events_script(events_first)
+    consts = [id_cases.update_constants(limit)]
+    dtypes = [f32, np.int32, np.int32]
+    want, got = st.copy(), st.copy()
+    ref_more, got_more = [], []
+    ref, ref_n, _ = run_oracle(script, consts, [x], dtypes, n, ids=want, page_kb=page_kb, instance_offset=offset, more_datasets=[[f32, np.int32]], more_results=ref_more)
+    out, out_n, _ = run_hip(script, consts, [x], dtypes, n, ids=got, page_kb=page_kb, instance_offset=offset, more_datasets=[[f32, np.int32]], more_results=got_more)
+    assert out_n == ref_n == int((x[:n] < limit).sum())
+    assert got_more[0][1] == ref_more[0][1] == n - out_n
+    for a, b in zip(out, ref):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))          # (survivors and the untouched fill around them)
+    for a, b in zip(got_more[0][0], ref_more[0][0]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.array_equal(got.id_table, want.id_table) and np.array_equal(got.free_table, want.free_table)
+    assert (got.num_free, got.max_used, got.num_spawned) == (want.num_free, want.max_used, want.num_spawned)
+
+
 def test_acquire_id_and_update_id_on_one_dataset_twice_in_a_row():
     """Two Execs in a row on one state: the second starts from the tables and counters the first left.  (As a member of a batch, with
     page sizes, offsets and other instructions around it: tools/gpu_fuzz_linker.py, one script in sixteen.)"""

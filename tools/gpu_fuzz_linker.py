@@ -212,7 +212,7 @@ def gen(seed):
         if group:
             s.output_data(typ, 0, group, from_half=True)
     more_dts = []
-    if seed % 4 == 1:                               # a second acquired dataset with outputs of its own; of the scripts without ID instructions a third have a third, another third a fourth as well
+    if seed % 4 == 1 or (gen.both_ids and seed % 32 == 3):      # a second acquired dataset with outputs of its own; of the scripts without ID instructions a third have a third, another third a fourth as well
         for d in range(1, 2 + ((seed // 8) % 3 if seed % 8 == 1 else 1 if seed % 32 == 5 else 0)):      # (seed % 8 == 5: with ID instructions)
             s.acquireindex(r.choice(masks) if masks and r.random() < 0.8 else s.const(0), d)
             pairs_f = [(r.choice(fvals), s.output(d, FLOAT, i)) for i in range(r.randint(1, 3))]
