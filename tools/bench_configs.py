@@ -370,6 +370,21 @@ def main():
         w = scripts.fountain()
         ins1m = scripts.fountain_streams_torch(0, n, dev, pad=PAD)
         run_single("fountain 1Mi", w, ins1m, 8, n)
+        # (run_single brackets every Exec with two timing events; the same queue of Execs without them)
+        outs_plain = [torch.zeros(n + PAD, dtype=torch.float32, device=dev) for _ in range(8)]
+        sp = VectorVMState(w.script.blob, be)
+        fp = sp.frame([abi.DataSet([t.data_ptr() for t in ins1m], [t.data_ptr() for t in outs_plain], 0)], n, [w.constants])
+        op = abi.ExecOptions(0, 0, 0, None, 0)
+        for _ in range(3):
+            sp.exec(fp, op)
+        reps = max(args.steps, 10) * 8
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            sp.exec_async(fp, op)
+        sp.finish(fp)
+        el = time.perf_counter() - t0
+        print(json.dumps({"config": "fountain 1Mi, %d Execs queued through vvm_exec_async, no timing events" % reps, "particles": n, "us_per_exec": el / reps * 1e6}), flush=True)
+        sp.close()
         # the same Exec as nodes of a HIP graph: two states that hand the particles back and forth (A's outputs are B's inputs), sixteen
         # ticks of the pair captured once and replayed; no host work per Exec, so what is left is the kernel and the gap between kernels
         from renderer_amd import hip
