@@ -216,6 +216,10 @@ def main():
                     help="who runs the count exchange at N > 1: the library's own RCCL communicator (vvm_exec_sharded_async) or torch.distributed")
     ap.add_argument("--exchange-depth", type=int, default=2, choices=[1, 2, 3, 4],
                     help="count exchanges that may be pending (c-abi communicator): the host collects step k - depth before it enqueues step k")
+    ap.add_argument("--timing", default="span", choices=["span", "per-exec"],
+                    help="how the kernel's mean duration is taken with HIP events on the Execs' stream: one event pair around the K launches of the "
+                         "timed region (span / K: includes the gaps between kernels, adds nothing to the steps), or a pair around every launch "
+                         "(two events per step, about 8 us of stream time each step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -399,7 +403,7 @@ def main():
     drain()
     torch.cuda.synchronize()
 
-    state.enable_timing(True)
+    state.enable_timing(True, span=args.timing == "span")
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
@@ -473,6 +477,8 @@ def main():
                        else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": recorded_traffic(args.workload, n), "kernel": "vvm_exec_kernel", "kernel_ms": kernel_ms, "launches": launches,
+                         "kernel_ms_from": ("one HIP event pair around the %d launches on their stream, divided by %d" % (launches, launches)) if args.timing == "span"
+                                           else "mean of one HIP event pair per launch",
                          "algorithmic_bytes_per_launch": alg_bytes, "device_copy_GBps": copy_gbps},
         }
         if not args.no_cpu_baseline and world == 1:

@@ -493,7 +493,10 @@ VVM_API int   vvm_set_device(int ordinal);
 /* Kernel timing with HIP events recorded on the stream each kernel is enqueued on.  While enabled, every Exec of the state
  * records one event pair around its kernel (two event records per Exec, at most 4096 pairs between collects).
  * vvm_state_collect_kernel_ms blocks until the recorded kernels have finished, returns the sum of their durations and how
- * many there were, and starts a new collection. */
+ * many there were, and starts a new collection.  enable = 2: one event pair around ALL Execs between two collects instead (the
+ * first event ahead of the first Exec's kernel, the second behind the last, recorded by the vvm_exec_finish that follows it, else by the collect): the sum is then the span on
+ * the stream, gaps between the kernels included, and the Execs themselves carry no events (an event pair per Exec costs about
+ * 8 us of stream time).  Execs that run as several passes, or on a stream that also waits for other work, spread the span. */
 VVM_API int vvm_state_enable_timing(vvm_state* state, int enable);
 VVM_API int vvm_state_collect_kernel_ms(vvm_state* state, float* sum_ms, int32_t* launches);
 

@@ -248,6 +248,10 @@ struct vvm_state {
 
 	// kernel timing: one event pair per launch since the last collect, on the stream the kernel runs on
 	bool timing = false;
+	bool timing_span = false;              // ... with ONE event pair around all Execs between two collects instead of a pair per Exec
+	bool span_open = false;                // the span's first event has been recorded
+	bool span_closed = false;              // ... and its second one, by a vvm_exec_finish behind the last Exec so far
+	uint32_t span_launches = 0;
 	std::vector<hipEvent_t> ev_start, ev_stop;
 	size_t ev_used = 0;
 	uint32_t execs_since_status_reset = 0;
@@ -1298,7 +1302,19 @@ static int exec_enqueue(vvm_exec_context* ctx, const vvm_exec_options* opt, bool
 	unsigned long long* d_status = no_alloc ? (unsigned long long*)(scratch_ptr + VVM_NOALLOC_STATUS_OFF) : st->d_status;
 	st->cur_status = d_status;
 	st->cur_status_words = no_alloc ? (size_t)VVM_NOALLOC_MAX_TILES : (size_t)st->status_capacity;
-	const bool timed = st->timing && st->ev_used < 4096 && (!no_alloc || st->ev_used < st->ev_start.size());      // (no new events without allocating)
+	const bool span = st->timing && st->timing_span && !no_alloc;
+	const bool timed = st->timing && !st->timing_span && st->ev_used < 4096 && (!no_alloc || st->ev_used < st->ev_start.size());      // (no new events without allocating)
+	if (span) {
+		if (st->ev_start.empty()) {
+			hipEvent_t a = nullptr, b = nullptr;
+			HIP_TRY(hipEventCreate(&a));
+			HIP_TRY(hipEventCreate(&b));
+			st->ev_start.push_back(a); st->ev_stop.push_back(b);
+		}
+		if (!st->span_open) { HIP_TRY(hipEventRecord(st->ev_start[0], stream)); st->span_open = true; }
+		st->span_closed = false;
+		st->span_launches++;
+	}
 	if (timed) {
 		if (st->ev_used == st->ev_start.size()) {
 			hipEvent_t a = nullptr, b = nullptr;
@@ -1430,6 +1446,8 @@ VVM_API int vvm_exec_finish(vvm_exec_context* ctx)
 		const size_t with_ids = st->any_ids ? 2 * nc : nc;      // words to read back: the survivor counts, and the MaxUsedID words behind them
 		const bool pending = st->results_pending;
 		const bool with_caller = st->counts_src && st->counts_src != st->cur_counts;      // counts left with the caller
+		// (timing over a span of Execs: the span ends behind the last kernel, ahead of this call's read-back; a later finish moves it)
+		if (pending && st->timing_span && st->span_open) { HIP_TRY(hipEventRecord(st->ev_stop[0], st->last_stream)); st->span_closed = true; }
 		if (pending) {
 			if (with_caller) {
 				HIP_TRY(hipMemcpyAsync(st->h_counts, st->counts_src, nc * 4, hipMemcpyDeviceToHost, st->last_stream));
@@ -2289,7 +2307,11 @@ VVM_API int vvm_state_enable_timing(vvm_state* st, int enable)
 {
 	if (!st) return fail(VVM_E_INVALID_ARG, "null state");
 	st->timing = enable != 0;
+	st->timing_span = enable == 2;
 	st->ev_used = 0;
+	st->span_open = false;
+	st->span_closed = false;
+	st->span_launches = 0;
 	return VVM_OK;
 }
 
@@ -2297,6 +2319,20 @@ VVM_API int vvm_state_collect_kernel_ms(vvm_state* st, float* sum_ms, int32_t* l
 {
 	if (!st || !sum_ms || !launches) return fail(VVM_E_INVALID_ARG, "null argument");
 	float total = 0.0f;
+	if (st->timing_span) {
+		*sum_ms = 0.0f;
+		*launches = 0;
+		if (st->span_open && st->last_stream) {
+			if (!st->span_closed) HIP_TRY(hipEventRecord(st->ev_stop[0], st->last_stream));
+			HIP_TRY(hipEventSynchronize(st->ev_stop[0]));
+			HIP_TRY(hipEventElapsedTime(sum_ms, st->ev_start[0], st->ev_stop[0]));
+			*launches = (int32_t)st->span_launches;
+		}
+		st->span_open = false;
+		st->span_closed = false;
+		st->span_launches = 0;
+		return VVM_OK;
+	}
 	for (size_t i = 0; i < st->ev_used; ++i) {
 		HIP_TRY(hipEventSynchronize(st->ev_stop[i]));
 		float ms = 0.0f;

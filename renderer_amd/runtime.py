@@ -57,8 +57,10 @@ class VectorVMState:
         """Instances per lane of the kernel the last Exec ran on (8, 4 or 1)."""
         return int(self.backend.lib.vvm_state_last_exec_width(self.ptr))
 
-    def enable_timing(self, on: bool = True) -> None:
-        self.backend._check(self.backend.lib.vvm_state_enable_timing(self.ptr, 1 if on else 0), "vvm_state_enable_timing")
+    def enable_timing(self, on: bool = True, span: bool = False) -> None:
+        """span: one event pair around all Execs up to the next collect_kernel_ms (the Execs carry no events of their own) instead of
+        a pair per Exec."""
+        self.backend._check(self.backend.lib.vvm_state_enable_timing(self.ptr, (2 if span else 1) if on else 0), "vvm_state_enable_timing")
 
     def collect_kernel_ms(self):
         """(sum of kernel durations in ms, number of launches) since timing was enabled or last collected."""
