@@ -191,6 +191,10 @@ struct vvm_state {
 	vvm::LinkedProgram light;              // the script linked for the light eight-wide kernel, when it fits (linked at vvm_alloc_state)
 	bool light_ready = false;
 	VvmIns* d_code_light = nullptr;
+	// ... and of the later passes of a script with several acquired datasets, where a pass has one dataset and fits (entry pass - 1; no
+	// code: the pass has no light program)
+	std::vector<vvm::LinkedProgram> light_more;
+	std::vector<VvmIns*> d_code_light_more;
 	// a script with acquireindex on several datasets runs one pass per dataset: the programs of passes 1.. (pass 0 = wide / narrow)
 	std::vector<vvm::LinkedProgram> wide_more, narrow_more;
 	std::vector<VvmIns*> d_code_wide_more, d_code_narrow_more;
@@ -634,14 +638,15 @@ int prepare(vvm_state* st, vvm_exec_context* ctx, const vvm_exec_options* opt, P
 		// (the size of the Exec itself decides, also inside a batch: many small Execs measured faster four wide, 0.88 ms against
 		// 0.92 ms for 4096 Execs of 16 Ki instances)
 		// scripts that get by with eight registers have a program for the light eight-wide kernel (three workgroups per CU)
-		const bool light_ok = can && st->light_ready && pass == 0 && !narrow && !(flags & VVM_EXEC_NO_LIGHT_KERNEL);
+		const bool has_light = pass == 0 ? st->light_ready : (pass - 1 < st->d_code_light_more.size() && st->d_code_light_more[pass - 1] != nullptr);
+		const bool light_ok = can && has_light && pe.lp == (pass ? &st->wide_more[pass - 1] : &st->wide) && !narrow && !(flags & VVM_EXEC_NO_LIGHT_KERNEL);
 		// (a member of a batch shares its launch with the other members, so the light kernel pays off from a few tiles on: 4096
 		// emitters of 16 Ki instances, all fit for it, 0.735 ms against 0.904 ms four-wide; a single Exec of that size takes the
 		// same 13.5 us on either)
 		const bool big = ctx->NumInstances >= VVM_EIGHT_WIDE_MIN_INSTANCES || (pe.in_batch && light_ok && ctx->NumInstances >= VVM_BATCH_LIGHT_MIN_INSTANCES);
 		if (can && (big || (flags & VVM_EXEC_FORCE_EIGHT_WIDE))) {
 			pe.instances_per_lane = 8;
-			if (light_ok) { pe.lp = &st->light; pe.d_code = st->d_code_light; pe.light = true; }
+			if (light_ok) { pe.lp = pass ? &st->light_more[pass - 1] : &st->light; pe.d_code = pass ? st->d_code_light_more[pass - 1] : st->d_code_light; pe.light = true; }
 		}
 	}
 	const uint32_t tile = VVM_BLOCK_THREADS * pe.instances_per_lane;
@@ -1092,12 +1097,18 @@ VVM_API vvm_state* vvm_alloc_state(const uint8_t* blob, size_t num_bytes)
 	if (hipGetDevice(&st->device) != hipSuccess) { fail(VVM_E_HIP, "hipGetDevice"); vvm_free_state(st); return nullptr; }
 	if (upload_code(st->wide, &st->d_code_wide) != VVM_OK) { vvm_free_state(st); return nullptr; }
 	if (link_more_passes(st->script, false, st->wide, st->wide_more, st->d_code_wide_more) != VVM_OK) { vvm_free_state(st); return nullptr; }
-	if (st->wide.instances_per_lane == 4 && !st->wide.full_kernel && !st->wide.many_registers && st->wide.num_passes == 1) {
+	// the light program of every pass that has one dataset: pass p of `wide` is the dataset of the (2 p)-th acquireindex where the
+	// datasets go two to a pass, else of the p-th; that is the pass number of the script linked one dataset to a pass
+	st->light_more.resize(st->wide_more.size());
+	st->d_code_light_more.assign(st->wide_more.size(), nullptr);
+	for (uint32_t p = 0; p < st->wide.num_passes; ++p) {
+		const vvm::LinkedProgram& whole = p ? st->wide_more[p - 1] : st->wide;
+		if (whole.instances_per_lane != 4 || whole.full_kernel || whole.many_registers || whole.num_chains != 1 || whole.uses_ids) continue;
 		std::string why;
-		if (vvm::link_program(st->script, false, st->light, why, 0, true) == VVM_OK) {
-			if (upload_code(st->light, &st->d_code_light) != VVM_OK) { vvm_free_state(st); return nullptr; }
-			st->light_ready = true;
-		}
+		vvm::LinkedProgram& light = p ? st->light_more[p - 1] : st->light;
+		if (vvm::link_program(st->script, false, light, why, st->wide.paired ? 2 * p : p, true, nullptr, 0) != VVM_OK) continue;
+		if (upload_code(light, p ? &st->d_code_light_more[p - 1] : &st->d_code_light) != VVM_OK) { vvm_free_state(st); return nullptr; }
+		if (p == 0) st->light_ready = true;
 	}
 	if (plan_through(st) != VVM_OK) { vvm_free_state(st); return nullptr; }
 	hipError_t e;
@@ -1143,6 +1154,7 @@ VVM_API void vvm_free_state(vvm_state* st)
 	if (st->d_code_wide) (void)hipFree(st->d_code_wide);
 	if (st->d_code_narrow) (void)hipFree(st->d_code_narrow);
 	if (st->d_code_light) (void)hipFree(st->d_code_light);
+	for (VvmIns* p : st->d_code_light_more) if (p) (void)hipFree(p);
 	if (st->d_code_lean) (void)hipFree(st->d_code_lean);
 	if (st->d_ride) (void)hipFree(st->d_ride);
 	for (VvmIns* p : st->d_code_wide_more) if (p) (void)hipFree(p);
@@ -2250,8 +2262,8 @@ VVM_API int vvm_inspect_blob(const uint8_t* blob, size_t num_bytes, vvm_program_
 	// (the flags vvm_state_info adds for the state's other programs)
 	vvm::LinkedProgram other;
 	std::string why;
-	const bool fits_light = lp.instances_per_lane == 4 && !lp.full_kernel && !lp.many_registers && lp.num_passes == 1 &&
-	                        vvm::link_program(s, false, other, why, 0, true) == VVM_OK;
+	const bool fits_light = lp.instances_per_lane == 4 && !lp.full_kernel && !lp.many_registers && lp.num_chains == 1 && !lp.uses_ids &&
+	                        vvm::link_program(s, false, other, why, 0, true, nullptr, 0) == VVM_OK;      // (the first pass's, as vvm_alloc_state links it)
 	if (fits_light) out->Flags |= 0x20000u;
 	std::vector<uint32_t> through;
 	if (plan_through_programs(s, lp, fits_light, other, through)) out->Flags |= 0x80000u | ((uint32_t)std::min<size_t>(through.size(), 255) << 24);

@@ -341,6 +341,13 @@ int link_program(const ThawedScript& s, bool force_narrow, LinkedProgram& lp, st
 	const bool may_pair = !light && !force_narrow && !getenv("VVM_NO_CHAINS");
 	bool chains_failed = false;
 	if (pairing >= 0 || pass != 0) return link_program_as(s, force_narrow, lp, err, pass, light, may_pair && pairing == 1, chains_failed, out_select);
+	if (light) {
+		// a caller that asks for the script's light program without saying how the passes are numbered means the whole script: a script
+		// with several acquired datasets has none (its passes may have one each: pairing = 0 and the pass)
+		const int rc = link_program_as(s, force_narrow, lp, err, 0, true, false, chains_failed, out_select);
+		if (rc == VVM_OK && lp.num_passes != 1) { err = "script does not fit the light eight-wide kernel"; return VVM_E_UNSUPPORTED_OP; }
+		return rc;
+	}
 	if (may_pair) {
 		int rc = link_program_as(s, force_narrow, lp, err, 0, light, true, chains_failed, out_select);
 		if (!chains_failed) {
@@ -965,11 +972,12 @@ static int link_program_as(const ThawedScript& s, bool force_narrow, LinkedProgr
 	lp.out_chain.resize(lp.out_list.size(), 0);
 	if (light) {
 		// the light eight-wide kernel: eight resident registers, one load instruction of 32-bit streams into registers 0.., ops of at
-		// most four operands, none of the transcendental / noise / ID instructions, one acquired dataset, and at most eight outputs: with
+		// most four operands, none of the transcendental / noise / ID instructions, one acquired dataset (of a script with several: the pass's),
+		// and at most eight outputs: with
 		// three workgroups per CU the LDS has room for six staging slots each, two more 32-bit outputs wait in registers, and a second
 		// group of slots would have to resolve the tile's look-back on the spot (measured: 1.04 ms against 0.84 ms of the general
 		// kernel on eight outputs of 64 Mi instances; so was parking two outputs in global memory: 0.85 ms)
-		bool ok = packed <= 8 && V == 4 && !lp.full_kernel && !lp.uses_ids && lp.num_passes == 1 && prefetch16.empty() && !prefetch32.empty() && prefetch32.size() <= 8;
+		bool ok = packed <= 8 && V == 4 && !lp.full_kernel && !lp.uses_ids && lp.num_chains == 1 && prefetch16.empty() && !prefetch32.empty() && prefetch32.size() <= 8;
 		for (const VvmIns& k : lp.code) {
 			const uint32_t op = k.w0 & 0xFFu;
 			if (op != VVM_OP_done && op < VVM_DOP_LOADN16 && ((k.w0 >> 8) & 7u) > 4u) ok = false;

@@ -25,3 +25,14 @@ def test_a_transcendental_function_in_a_pair_undoes_the_pairing():
 def test_without_chains_one_program_per_dataset(monkeypatch):
     monkeypatch.setenv("VVM_NO_CHAINS", "1")
     assert _plan(dataset_cases.many_dataset_script(4)) == (4, False)
+
+
+def test_a_script_with_several_datasets_has_no_light_program_as_a_whole():
+    """The light eight-wide kernel has one chain.  Asked for "the script's light program" (no pass named), the linker refuses a script
+    that acquires two datasets -- a program for the first dataset alone would drop the second (found by the GPU fuzzer when the
+    passes of such scripts got light programs of their own: the lean form of a wide record with a second dataset asks this way)."""
+    be = abi.load_hip_backend()
+    with pytest.raises(abi.VVMError) as e:
+        be.inspect_code(dataset_cases.two_dataset_script().blob, 2)
+    assert e.value.code == abi.VVM_E_UNSUPPORTED_OP
+    assert not be.inspect_blob(dataset_cases.two_dataset_script().blob).Flags & 0x20000
