@@ -415,7 +415,11 @@ typedef struct vvm_program_info {
 	uint32_t InstancesPerLane;      /* 4 = 128-bit stream access, 1 = narrow fallback */
 	uint32_t LdsSpillRegisters;     /* registers living in LDS, on the kernel the script is linked for */
 	uint32_t BytesInPerInstance, BytesOutPerInstance; /* algorithmic stream bytes */
-	uint32_t Flags;
+	uint32_t Flags;                 /* [0:16) the script's EVectorVMFlags; 0x10000 the program needs the kernels with the transcendental /
+	                                 * noise / ID instructions; 0x20000 the script (its first pass) has a program for the light eight-wide
+	                                 * kernel; 0x40000 the first pass runs two acquired datasets (two chains); 0x80000 the script has a lean
+	                                 * form (VVM_EXEC_NO_THROUGH_KERNEL), [24:32) its handed-through streams; [20:24) passes, i.e. launches,
+	                                 * per Exec (one, unless the script acquires three or more datasets, or two that cannot share a pass) */
 } vvm_program_info;
 VVM_API int vvm_state_info(const vvm_state* state, vvm_program_info* out);
 
