@@ -16,7 +16,11 @@ when RCCL cannot be set up, and `config.parallelism` says which one ran.)
 
 Rank 0 prints ONE JSON line.  `roofline` prices the interpreter kernel against HBM: algorithmic bytes per launch
 (4 bytes x (input streams x instances + output streams x survivors)) over the kernel's mean duration, which is
-measured here with HIP events recorded on the kernel's own stream around every launch of the timed region.
+measured here with HIP events recorded on the kernel's own stream: one pair around the K launches of the timed region,
+divided by K (--timing per-exec: a pair around every launch).
+
+--workload batch is BASELINE.json configs[4]: 4096 emitters x 16 Ki particles with 64 distinct bytecode bodies, one
+vvm_exec_batch call per step; at N > 1 the emitters are dealt to the ranks in turn (strong scaling, no collective).
 `cpu_baseline` is the CPU oracle (a restatement of the reference interpreter in its own structure: interpreted
 bytecode, 4-wide SSE, 64 KB-page chunks, one thread) timed on a bounded sample on the host's cores.
 """
@@ -199,12 +203,105 @@ def launch_ranks(world, argv, timeout_s=1500.0, program=None):
     return 0
 
 
+def run_batch(args, real_stdout):
+    """configs[4]: every rank runs its share of the emitters (emitter e belongs to rank e mod N) as one vvm_exec_batch call per step."""
+    import torch
+    from renderer_amd import abi, scripts
+    from renderer_amd.runtime import VectorVMState
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            if local_rank >= torch.cuda.device_count():
+                sys.stderr.write("bench.py: rank %d has no GPU of its own (%d visible); --backend gloo rehearses the multi-rank path on one GPU\n"
+                                 % (rank, torch.cuda.device_count()))
+                sys.exit(2)
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+    else:
+        local_rank = 0
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank)
+    be = abi.load_hip_backend()
+    be._check(be.lib.vvm_set_device(dev.index), "vvm_set_device")
+    emitters, per = args.batch_emitters, args.batch_particles
+    mine = [e for e in range(emitters) if e % world == rank]
+    total_local = len(mine) * per
+    ins = scripts.fountain_streams_torch(rank * total_local, total_local, dev, kill_half=True, pad=PAD)
+    outs = [torch.zeros(total_local + PAD, dtype=torch.float32, device=dev) for _ in range(8)]
+    torch.cuda.synchronize()
+    workloads = [scripts.fountain(variant=v) for v in range(64)]
+    states, frames, opts = [], [], []
+    for k, e in enumerate(mine):
+        w = workloads[e % 64]
+        st = VectorVMState(w.script.blob, be)
+        states.append(st)
+        off = k * per * 4
+        frames.append(st.frame([abi.DataSet([t.data_ptr() + off for t in ins], [t.data_ptr() + off for t in outs], 0)], per, [w.constants]))
+        opts.append(abi.ExecOptions(0, 0, 0, None, 0))
+    arr, oarr = be.pack_batch(frames, opts)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+    for _ in range(max(args.warmup, 3) + 20):      # (host-bound: the first calls also measure the host's clocks ramping up)
+        be.exec_batch_packed(arr, oarr)
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        be.exec_batch_packed(arr, oarr)      # (synchronous: every emitter's count is back in its context when it returns)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    survivors = sum(f.survivors(0) for f in frames)
+    if dist is not None:
+        t = torch.tensor([elapsed, float(survivors)], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed, survivors = float(tmax[0].item()), int(t[1].item())
+    if rank == 0:
+        total = emitters * per
+        alg_bytes = 32.0 * total + 32.0 * survivors      # whole job, per step
+        ms = elapsed / args.steps * 1e3
+        achieved = alg_bytes / (ms * 1e-3) / 1e9
+        line = {"metric": "particle updates/sec", "value": float(total) * args.steps / elapsed, "unit": "particle updates/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "batch: %d emitters x %d particles, 64 distinct bytecode bodies, half of the particles dying, one vvm_exec_batch call per "
+                                       "step and rank (BASELINE.json configs[4])" % (emitters, per),
+                           "emitters_per_gpu": len(mine), "survivors": survivors,
+                           "parallelism": "emitters dealt to %d rank(s) in turn, no collective in the step" % world if world > 1 else "single GPU"},
+                "roofline": {"bound": "hbm", "achieved": achieved / world, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / world / HBM_PEAK_GBPS, "traffic": None,
+                             "kernel": "vvm_exec_kernel (several launches per call)", "note": "per GPU, from the wall clock of the synchronous call "
+                             "(upload of the parameter blocks, launches and read-back of the counts included): the call is host-bound"}}
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline("fountain_kill_half", args.cpu_seconds)
+        real_stdout.write(json.dumps(line) + "\n")
+        real_stdout.flush()
+    for st in states:
+        st.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="fountain", choices=["fountain", "fountain_kill_half"])
+    ap.add_argument("--workload", default="fountain", choices=["fountain", "fountain_kill_half", "batch"])
+    ap.add_argument("--batch-emitters", type=int, default=4096, help="--workload batch: emitters of the whole job")
+    ap.add_argument("--batch-particles", type=int, default=16384, help="--workload batch: particles per emitter")
     ap.add_argument("--particles", type=int, default=64 * 1024 * 1024, help="instances per GPU")
     ap.add_argument("--width", default="auto", choices=["auto", "4", "8"], help="instances per lane of the kernel (auto: the library's choice)")
     ap.add_argument("--no-light", action="store_true", help="keep the eight-wide Exec on the general kernel (comparison)")
@@ -234,6 +331,12 @@ def main():
     sys.stdout.flush()
     real_stdout = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
+
+    if args.workload == "batch":
+        if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+            sys.stderr.write("bench.py: --gpus %d, but the launcher started %s rank(s) (WORLD_SIZE)\n" % (args.gpus, os.environ.get("WORLD_SIZE", "1")))
+            sys.exit(2)
+        return run_batch(args, real_stdout)
 
     import torch
     from renderer_amd import abi, scripts
