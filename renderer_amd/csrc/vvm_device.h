@@ -215,8 +215,9 @@ struct VvmThroughArgs {
 //
 // Tiles are handed out in index order by ticket counters.  A device-scope atomic on ONE address completes about every 13 ns
 // on MI355X (65536 tiles would take 0.85 ms for the tickets alone), so there are VVM_TICKET_CLASSES counters, each on a cache
-// line of its own: workgroup b draws from counter b % classes, and draw c of counter x is tile c * classes + x.  Tiles still
-// start in (nearly) index order, which the look-back relies on, and every tile is claimed by a running workgroup.
+// line of its own: workgroup b draws from counter (b + b / 16) % classes (launches of fewer than 32 workgroups: b % classes), and
+// draw c of counter x is tile c * classes + x.  Tiles still start in (nearly) index order, which the look-back relies on, and every
+// tile is claimed by a running workgroup.  (Why not b % classes throughout: see where vvm_exec_kernel works out its class.)
 #define VVM_TICKET_CLASSES      16u
 #define VVM_TICKET_STRIDE_BYTES 256u
 struct VvmLaunchState {

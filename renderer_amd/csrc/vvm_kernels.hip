@@ -1735,7 +1735,17 @@ __global__ void __launch_bounds__(VVM_BLOCK_THREADS, (IS_LIGHT(V, SPILL) ? 3 : V
 	// ticket counter of this workgroup's class (see VvmLaunchState); with fewer workgroups than classes only the first
 	// gridDim.x counters are in use
 	const uint32_t classes = min(gridDim.x, VVM_TICKET_CLASSES);
-	const uint32_t cls = blockIdx.x % classes;
+	// Which class a workgroup draws from must not follow from where it runs.  Workgroups go to the XCDs in turn (workgroup b to XCD
+	// b % 8), so with class b % 16 all workgroups of a class sit on ONE XCD; when two such launches share the chip (two streams, or two
+	// processes) and each holds the slots of some XCDs while its workgroups for the others wait to be placed, each has classes nobody
+	// draws from, the tiles of those classes are never claimed, every later tile's look-back waits for them, and neither launch ever
+	// frees a slot: both sit until the look-back's poll limit ends them (seen with two processes of 4096 tiles each on one GPU, and
+	// once with two 64 Mi-instance Execs of one process on two streams).  With class (b + b / 16) % 16 the sixteen workgroups b = 16 g ..
+	// 16 g + 15 still take sixteen different classes (tiles start in index order as before), and every XCD holds workgroups of every
+	// class as soon as it holds sixteen of the launch's: a launch that is only partly placed claims every tile, so it finishes and
+	// makes room.  (It also spreads a class's tiles over the XCDs instead of tying them to one: 1 to 2 % faster on Execs of 64 Mi
+	// instances; an Exec small enough to find its streams in the XCDs' L2 from the Exec before loses that, 19.5 -> 20.8 us at 1 Mi.)
+	const uint32_t cls = gridDim.x >= 2u * VVM_TICKET_CLASSES ? (blockIdx.x + (blockIdx.x >> 4)) % VVM_TICKET_CLASSES : blockIdx.x % classes;
 	const uint32_t tag = env.tag ? env.tag : (SCALAR(__hip_atomic_load((gu32*)&env.ls->epoch, RLX_AGENT)) & 0x3FFFFFFFu);
 	bool perlin_ready = false;
 	uint32_t resolves = 0, started = 0;

@@ -1,0 +1,38 @@
+"""Several large launches on one GPU at the same time, from different processes.  Every launch is a grid of persistent workgroups
+sized for the whole chip, so none of them is placed completely while the others run; a launch must still claim all of its tiles
+with the workgroups it has (a tile's look-back waits for every earlier tile).  With the class of ticket counters that a workgroup
+draws from tied to the XCD it runs on, two such launches could each hold the slots the other needed and sit until the look-back's
+poll limit ended both ("look-back timed out"); this test failed about every second time on such a build."""
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.parametrize("processes, n, execs", [(2, 8 * 1024 * 1024, 12), (3, 3 * 1024 * 1024, 16)])
+def test_processes_sharing_the_gpu_all_finish(processes, n, execs):
+    with tempfile.TemporaryDirectory() as d:
+        go = os.path.join(d, "go")
+        ready = [os.path.join(d, "ready%d" % i) for i in range(processes)]
+        procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "two_process_case.py"), str(11 + i), str(n), str(execs), ready[i], go],
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for i in range(processes)]
+        try:
+            t_end = time.time() + 150.0
+            while not all(os.path.exists(r) for r in ready) and time.time() < t_end and all(p.poll() is None for p in procs):
+                time.sleep(0.01)
+            open(go, "w").close()
+            outs = []
+            for p in procs:
+                out, _ = p.communicate(timeout=150)
+                outs.append(out.decode(errors="replace"))
+            assert [p.returncode for p in procs] == [0] * processes, "\n".join(o[-2000:] for o in outs)
+        finally:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
