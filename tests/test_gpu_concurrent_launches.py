@@ -36,3 +36,25 @@ def test_processes_sharing_the_gpu_all_finish(processes, n, execs):
             for p in procs:
                 if p.poll() is None:
                     p.kill()
+
+
+def test_four_states_of_one_process_in_flight_together():
+    """The same within one process: four states (the library gives them its four streams in turn), mid-sized Execs of different sizes
+    queued on all of them before any is finished, several rounds; every state's last Exec equals the oracle."""
+    from batch_epoch_case import Emitter
+    from renderer_amd import abi
+    be = abi.load_hip_backend()
+    sizes = (700_001, 1_300_000, 2_100_003, 3_000_000)
+    ems = [Emitter(be, i, n, i % 2 == 0, 21 + i, cap=max(sizes) + 64) for i, n in enumerate(sizes)]      # (one stream length for all: the helper keeps it in a global)
+    try:
+        opt = abi.ExecOptions(0, 0, 0, None, 0)
+        for _ in range(10):
+            for e in ems:
+                be.exec_async(e.frame, opt)
+        for e in ems:
+            be.exec_finish(e.frame)
+        for i, e in enumerate(ems):
+            assert e.check("state %d" % i, tail=False)
+    finally:
+        for e in ems:
+            e.free()
