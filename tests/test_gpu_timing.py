@@ -28,7 +28,9 @@ def test_timing_per_exec_and_over_a_span():
             assert st.collect_kernel_ms() == (0.0, 0)
         st.enable_timing(False)
         assert e.check("after the timed Execs", tail=False)
-        # the span's mean holds the kernels and the gaps between them: not below the kernels' own mean by more than noise, not far above it
-        assert 0.8 * results["per exec"] < results["span"] < 2.0 * results["per exec"] + 0.05, results
+        # the span's mean holds the kernels and the gaps between them: the same order of magnitude as the kernels' own mean (wide bounds:
+        # another process may be using the GPU while one of the three is taken)
+        per = (results["per exec"], results["per exec again"])
+        assert 0.25 * min(per) < results["span"] < 4.0 * max(per) + 0.1, results
     finally:
         e.free()
