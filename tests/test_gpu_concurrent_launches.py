@@ -58,3 +58,27 @@ def test_four_states_of_one_process_in_flight_together():
     finally:
         for e in ems:
             e.free()
+
+
+def test_twelve_states_on_twelve_caller_streams():
+    """Twelve launches sized for the whole chip in flight together, each on a stream of the caller's (vvm_exec_options.Stream)."""
+    from batch_epoch_case import Emitter
+    from renderer_amd import abi, hip
+    be = abi.load_hip_backend()
+    n = 1_500_000
+    ems = [Emitter(be, i % 8, n - 1000 * i, i % 3 != 0, 40 + i, cap=n + 64) for i in range(12)]
+    streams = [hip.Stream() for _ in ems]
+    try:
+        opts = [abi.ExecOptions(0, 0, 0, s.value, 0) for s in streams]
+        for _ in range(6):
+            for e, o in zip(ems, opts):
+                be.exec_async(e.frame, o)
+        for e in ems:
+            be.exec_finish(e.frame)
+        for i, e in enumerate(ems):
+            assert e.check("state %d" % i, tail=False)
+    finally:
+        for e in ems:
+            e.free()
+        for s in streams:
+            s.destroy()
