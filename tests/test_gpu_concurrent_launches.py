@@ -82,3 +82,42 @@ def test_twelve_states_on_twelve_caller_streams():
             e.free()
         for s in streams:
             s.destroy()
+
+
+def test_host_threads_each_with_a_state_of_their_own():
+    """Six host threads call the library at once, each on its own state (ctypes releases the interpreter lock inside a call): synchronous
+    Execs of different sizes and kernel shapes, some through the entry point that allocates nothing (which takes turns on a lock), each
+    result against the oracle."""
+    import threading
+    from batch_epoch_case import Emitter
+    from renderer_amd import abi
+    be = abi.load_hip_backend()
+    sizes = (3_000, 70_001, 300_000, 9_001, 1_000_000, 150_000)
+    cap = max(sizes) + 64
+    ems = [Emitter(be, i, n, i % 2 == 1, 60 + i, cap=cap) for i, n in enumerate(sizes)]
+    errors = []
+
+    def work(i):
+        try:
+            e = ems[i]
+            opt = abi.ExecOptions(0, 0, 0, None, 0)
+            for k in range(40):
+                if i % 3 == 0 and k % 4 == 0:
+                    be.exec_noalloc(e.frame, opt)
+                else:
+                    be.exec_ex(e.frame, opt)
+        except Exception as ex:      # noqa: BLE001
+            errors.append((i, repr(ex)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(ems))]
+    try:
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(120)
+        assert not errors, errors
+        for i, e in enumerate(ems):
+            assert e.check("thread %d" % i, tail=False)
+    finally:
+        for e in ems:
+            e.free()
