@@ -11,7 +11,7 @@ for r in $(seq 1 $rounds); do for v in "$@"; do
 import sys, json
 for l in sys.stdin:
     d = json.loads(l)
-    k = d.get('kernel_ms', d.get('kernel_ms_per_exec', d.get('us_per_exec', d.get('ms_per_step'))))
+    k = d.get('kernel_ms', d.get('kernel_ms_per_exec', d.get('us_per_exec', d.get('kernel_us', d.get('ms_per_step')))))
     if k is not None: print('   %-70s %.4f' % (d['config'][:70], k))
 "
 done; done
