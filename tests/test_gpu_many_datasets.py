@@ -1,6 +1,6 @@
-"""Scripts that run acquireindex for three to five datasets (the reference serves any DataSetIdx in one sweep,
+"""Scripts that run acquireindex for three to thirteen datasets (the reference serves any DataSetIdx in one sweep,
 VectorVMRuntime.cpp:824-878; every dataset has its own keep mask, count and output positions).  The executor takes the
-datasets two to a pass, each pass one launch of a kernel with two chains (three datasets: two launches, four: two, five: three);
+datasets two to a pass, each pass one launch of a kernel with two chains (three datasets: two launches, four: two, five: three, thirteen: seven);
 with VVM_NO_CHAINS one program per dataset, fused into one launch or launched one after the other.  All three against the
 oracle, bit for bit, with nothing written past the survivors."""
 import numpy as np
@@ -48,7 +48,7 @@ def _run(k, n, mode, monkeypatch, order=None, trig_in=None, no_alloc=False):
 
 
 @pytest.mark.parametrize("mode", ["paired", "fused", "separate"])
-@pytest.mark.parametrize("k, n", [(3, 1), (3, 5003), (3, 300_007), (4, 77_777), (4, 600_001), (5, 300_007)])
+@pytest.mark.parametrize("k, n", [(3, 1), (3, 5003), (3, 300_007), (4, 77_777), (4, 600_001), (5, 300_007), (8, 40_009), (13, 9_001)])
 def test_three_to_five_datasets_match_the_oracle(k, n, mode, monkeypatch):
     info, widths = _run(k, n, mode, monkeypatch)
     passes = (info.Flags >> 20) & 15
